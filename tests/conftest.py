@@ -1,0 +1,70 @@
+"""pytest configuration: marker registration and shared fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN_DIR, f"msda_{name}.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+MSDA_GOLDEN_CASES = ["testpy_d2", "testpy_d30", "testpy_d32", "testpy_d64", "testpy_d71",
+                     "model_enc", "model_dec"]
+
+
+@pytest.fixture(params=MSDA_GOLDEN_CASES)
+def msda_golden(request):
+    g = load_golden(request.param)
+    g["name"] = request.param
+    return g
+
+
+def boundary_samples(g, tol=1e-5):
+    """bool [N,Lq,M,L,P]: samples sitting (within tol px) on an exclusion boundary.
+
+    At h_im == -1 / h_im == H (same for w) the reference's CUDA kernel drops the sample
+    (ms_deform_im2col_cuda.cuh:285-288) while its pure-PyTorch twin (grid_sample) keeps a
+    zero-weight corner whose *derivative* w.r.t. the location is non-zero.  grad_sampling_loc
+    is therefore discontinuous there and the two reference implementations disagree on a
+    measure-zero set; the oracle and the HIP kernels follow the CUDA kernel.  Golden
+    comparisons of grad_loc skip exactly these samples.
+    """
+    loc = g["loc"].astype(np.float64)
+    mask = np.zeros(loc.shape[:-1], dtype=bool)
+    for l, (H, W) in enumerate(g["shapes"]):
+        x = loc[:, :, :, l, :, 0] * W - 0.5
+        y = loc[:, :, :, l, :, 1] * H - 0.5
+        near = (np.abs(x + 1) < tol) | (np.abs(x - W) < tol) | (np.abs(y + 1) < tol) | (np.abs(y - H) < tol)
+        mask[:, :, :, l, :] = near
+    return mask
+
+
+def kink_samples(g, tol=1e-4):
+    """bool [N,Lq,M,L,P]: samples within tol px of an integer pixel coordinate.
+
+    grad_sampling_loc is piecewise constant in the fractional offsets and jumps when a
+    sample crosses a pixel centre (the floor() in ms_deform_im2col_cuda.cuh:92-93); in
+    float32 a sample planted exactly on a centre may round to either side, so float32
+    comparisons of grad_loc skip these samples (outputs and the other gradients are
+    continuous there and are always compared).
+    """
+    loc = g["loc"].astype(np.float64)
+    mask = np.zeros(loc.shape[:-1], dtype=bool)
+    for l, (H, W) in enumerate(g["shapes"]):
+        x = loc[:, :, :, l, :, 0] * W - 0.5
+        y = loc[:, :, :, l, :, 1] * H - 0.5
+        mask[:, :, :, l, :] = (np.abs(x - np.round(x)) < tol) | (np.abs(y - np.round(y)) < tol)
+    return mask

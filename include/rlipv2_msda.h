@@ -1,0 +1,134 @@
+/*
+ * rlipv2_msda.h -- C ABI of the MI355X-native multi-scale deformable attention library
+ * (librlipv2_msda.so, built from rlipv2_amd/csrc/ for gfx950).
+ *
+ * This is the drop-in boundary for the reference's native extension module
+ * "MultiScaleDeformableAttention" (reference: models/ops/src/vision.cpp:13-16, dispatch
+ * models/ops/src/ms_deform_attn.h:36-77, host launchers
+ * models/ops/src/cuda/ms_deform_attn_cuda.cu:20-80 and :83-153; the byte-identical twin lives
+ * under models/dab_deformable/ops/src/).  The reference binds its kernels through
+ * pybind/ATen; the entry points below carry the same operands as plain pointers and sizes
+ * so that any host (Python ctypes, C++, a torch extension) can bind them.  INTEGRATION.md
+ * shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions shared by every entry point
+ * ---------------------------------------
+ *  - All data pointers are DEVICE pointers on the current HIP device, contiguous row-major:
+ *      value           [N, S, M, D]        S = sum_l H_l * W_l, level-major, then (h, w)
+ *      spatial_shapes  int64 [L, 2]        (H_l, W_l)            -- on device, as in the
+ *      level_start     int64 [L]           first row of level l     reference (.cu:67-68)
+ *      sampling_loc    [N, Lq, M, L, P, 2] (x, y), normalised to the level extent
+ *      attn_weight     [N, Lq, M, L, P]
+ *      out / grad_out  [N, Lq, M*D]
+ *  - `dtype` selects the element type of value / out / grad_out:
+ *      MSDA_F32, MSDA_F64 : every tensor has that type (the reference's two types,
+ *                           AT_DISPATCH_FLOATING_TYPES at .cu:64).
+ *      MSDA_BF16          : value / out / grad_out are bfloat16; sampling_loc, attn_weight
+ *                           and ALL gradients (grad_value included) are float32; the
+ *                           accumulation is float32.  (New in this build; the reference has no
+ *                           16-bit path.)
+ *  - Inputs are borrowed; outputs are caller-allocated.  Nothing is allocated, freed or
+ *    synchronised inside; work is enqueued on `stream` (a hipStream_t; NULL = the default
+ *    stream) and the call returns immediately, like the reference's launch on
+ *    at::cuda::getCurrentCUDAStream() (.cu:65).  Re-entrant: no global scratch state.
+ *  - Return value: MSDA_OK (0) or a negative msda_status; msda_strerror() names it.  Unlike
+ *    the reference, which only printf()s a failed launch (ms_deform_im2col_cuda.cuh:948-952),
+ *    a launch failure is reported to the caller.
+ *  - The reference's `im2col_step` argument only chunks the batch loop on the host
+ *    (.cu:50-61) and does not change results; its divisibility precondition
+ *    (batch % min(batch, im2col_step) == 0, .cu:50-52) is checked by msda_check_im2col_step
+ *    so bindings can reproduce the reference's error.
+ */
+#ifndef RLIPV2_MSDA_H
+#define RLIPV2_MSDA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLIPV2_MSDA_ABI_VERSION 1
+
+typedef enum msda_dtype {
+    MSDA_F32 = 0,
+    MSDA_F64 = 1,
+    MSDA_BF16 = 2
+} msda_dtype;
+
+typedef enum msda_status {
+    MSDA_OK = 0,
+    MSDA_ERR_BAD_DTYPE = -1,
+    MSDA_ERR_BAD_SHAPE = -2,    /* a dimension <= 0 (empty tensors are MSDA_OK no-ops), or too large */
+    MSDA_ERR_NULL_POINTER = -3,
+    MSDA_ERR_IM2COL_STEP = -4,  /* batch % min(batch, im2col_step) != 0 */
+    MSDA_ERR_LAUNCH = -5,       /* hipGetLastError() != hipSuccess after a launch */
+    MSDA_ERR_BAD_VARIANT = -6,
+    MSDA_ERR_ALIGNMENT = -7     /* a pointer is not aligned for the vector width the fast path needs */
+} msda_status;
+
+/* Kernel selection.  MSDA_VARIANT_AUTO is what product code uses; the others exist so the
+ * benchmark and the parity tests can pin one implementation. */
+typedef enum msda_variant {
+    MSDA_VARIANT_AUTO = 0,
+    MSDA_VARIANT_GENERIC = 1,   /* any M, D, L, P; f32 / f64 / bf16: one wave per (n, q, m) */
+    MSDA_VARIANT_QUAD = 2,      /* D = 32, L*P = 16: four lanes per (n, q, m), direct gathers */
+    MSDA_VARIANT_WINDOW = 3     /* D = 32, L*P = 16: LDS-staged sampling windows per query tile */
+} msda_variant;
+
+/* Replaces ms_deform_attn_forward (reference models/ops/src/ms_deform_attn.h:36-53,
+ * cuda/ms_deform_attn_cuda.cu:20-80).  Writes every element of out. */
+int msda_forward(int dtype,
+                 const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                 const void *sampling_loc, const void *attn_weight,
+                 int N, int S, int M, int D, int L, int Lq, int P,
+                 void *out, void *stream);
+
+/* Replaces ms_deform_attn_backward (reference models/ops/src/ms_deform_attn.h:56-77,
+ * cuda/ms_deform_attn_cuda.cu:83-153).  grad_value is zero-filled INSIDE the call (an async
+ * memset on `stream`, the reference's at::zeros_like at .cu:121) and then accumulated into;
+ * grad_sampling_loc and grad_attn_weight are fully overwritten.  For MSDA_BF16, grad_value is
+ * float32 [N, S, M, D]. */
+int msda_backward(int dtype,
+                  const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                  const void *sampling_loc, const void *attn_weight, const void *grad_out,
+                  int N, int S, int M, int D, int L, int Lq, int P,
+                  void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                  void *stream);
+
+/* Flag OR-ed into the `variant` argument of msda_backward_ex: the caller has already zero-filled
+ * grad_value on `stream`, skip the memset inside (lets a profiler time the kernel alone). */
+#define MSDA_FLAG_GRAD_VALUE_ZEROED 0x100
+
+/* Same as the two calls above with an explicit kernel choice (msda_variant | flags). */
+int msda_forward_ex(int variant, int dtype,
+                    const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                    const void *sampling_loc, const void *attn_weight,
+                    int N, int S, int M, int D, int L, int Lq, int P,
+                    void *out, void *stream);
+int msda_backward_ex(int variant, int dtype,
+                     const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const void *sampling_loc, const void *attn_weight, const void *grad_out,
+                     int N, int S, int M, int D, int L, int Lq, int P,
+                     void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                     void *stream);
+
+/* The reference's batch-chunking precondition (cuda/ms_deform_attn_cuda.cu:50-52). */
+int msda_check_im2col_step(int batch, int im2col_step);
+
+/* Algorithmic bytes of one call (each tensor once, metadata ignored):
+ * forward  N*[S*M*D*sv + Lq*M*L*P*2*sl + Lq*M*L*P*sl + Lq*M*D*sv]
+ * backward N*[S*M*D*(sv+sg) + 2*Lq*M*L*P*2*sl + 2*Lq*M*L*P*sl + Lq*M*D*sv]
+ * with sv = sizeof(value element), sl = sizeof(loc element), sg = sizeof(grad_value element). */
+int64_t msda_algorithmic_bytes(int dtype, int backward, int N, int S, int M, int D, int L, int Lq, int P);
+
+const char *msda_strerror(int status);
+int msda_abi_version(void);
+/* Name of the kernel msda_{forward,backward} would pick for this problem ("generic", "quad", ...). */
+const char *msda_variant_name(int variant);
+int msda_pick_variant(int backward, int dtype, int N, int S, int M, int D, int L, int Lq, int P);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLIPV2_MSDA_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of librlipv2_msda.so (C ABI: include/rlipv2_msda.h).
+
+The library is built in-tree by ``rlipv2_amd/csrc/Makefile`` (hipcc, gfx950).  Loading fails
+loudly -- there is no fallback implementation behind this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librlipv2_msda.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+# enum msda_dtype / msda_variant (include/rlipv2_msda.h)
+MSDA_F32, MSDA_F64, MSDA_BF16 = 0, 1, 2
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_QUAD, VARIANT_WINDOW = 0, 1, 2, 3
+VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "quad": VARIANT_QUAD, "window": VARIANT_WINDOW}
+
+EXPORTS = (
+    "msda_forward", "msda_backward", "msda_forward_ex", "msda_backward_ex", "msda_check_im2col_step",
+    "msda_algorithmic_bytes", "msda_strerror", "msda_abi_version", "msda_variant_name", "msda_pick_variant",
+)
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C rlipv2_amd/csrc`). "
+            "rlipv2_amd has no CPU / PyTorch fallback for this op.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    dims = [i] * 7
+    L.msda_forward.argtypes = [i, vp, vp, vp, vp, vp, *dims, vp, vp]
+    L.msda_backward.argtypes = [i, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp]
+    L.msda_forward_ex.argtypes = [i, i, vp, vp, vp, vp, vp, *dims, vp, vp]
+    L.msda_backward_ex.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp]
+    for f in (L.msda_forward, L.msda_backward, L.msda_forward_ex, L.msda_backward_ex):
+        f.restype = i
+    L.msda_check_im2col_step.argtypes = [i, i]
+    L.msda_check_im2col_step.restype = i
+    L.msda_algorithmic_bytes.argtypes = [i, i, *dims]
+    L.msda_algorithmic_bytes.restype = ctypes.c_int64
+    L.msda_strerror.argtypes = [i]
+    L.msda_strerror.restype = ctypes.c_char_p
+    L.msda_abi_version.restype = i
+    L.msda_variant_name.argtypes = [i]
+    L.msda_variant_name.restype = ctypes.c_char_p
+    L.msda_pick_variant.argtypes = [i, i, *dims]
+    L.msda_pick_variant.restype = i
+    _lib = L
+    return L
+
+
+def strerror(status: int) -> str:
+    return lib().msda_strerror(int(status)).decode()
+
+
+def algorithmic_bytes(dtype: int, backward: bool, N, S, M, D, L, Lq, P) -> int:
+    return int(lib().msda_algorithmic_bytes(dtype, int(backward), N, S, M, D, L, Lq, P))

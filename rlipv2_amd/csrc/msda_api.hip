@@ -1,0 +1,215 @@
+// msda_api.hip -- the C ABI of librlipv2_msda.so (declared in include/rlipv2_msda.h).
+//
+// Host side of the drop-in for the reference's extension module (reference:
+// models/ops/src/vision.cpp:13-16 -> ms_deform_attn.h:36-77 -> cuda/ms_deform_attn_cuda.cu).
+// Argument checking mirrors what the reference asserts (contiguity / device are properties of
+// raw pointers the caller vouches for; the batch-chunk rule is msda_check_im2col_step);
+// kernel launch failures are RETURNED (the reference only printf()s them,
+// ms_deform_im2col_cuda.cuh:948-952).
+#include "msda_internal.h"
+
+using namespace msda;
+
+namespace {
+
+int validate(int dtype, int N, int S, int M, int D, int L, int Lq, int P)
+{
+    if (dtype != MSDA_F32 && dtype != MSDA_F64 && dtype != MSDA_BF16) return MSDA_ERR_BAD_DTYPE;
+    if (N < 0 || S < 0 || M < 0 || D < 0 || L < 0 || Lq < 0 || P < 0) return MSDA_ERR_BAD_SHAPE;
+    return MSDA_OK;
+}
+
+size_t value_elem(int dtype) { return dtype == MSDA_F64 ? 8 : dtype == MSDA_F32 ? 4 : 2; }
+size_t loc_elem(int dtype) { return dtype == MSDA_F64 ? 8 : 4; }
+size_t grad_value_elem(int dtype) { return dtype == MSDA_F64 ? 8 : 4; }
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int finish_launch()
+{
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}
+
+int pick(bool backward, const Problem &p)
+{
+    if (window_supports(p, backward)) return MSDA_VARIANT_WINDOW;
+    if (quad_supports(p)) return MSDA_VARIANT_QUAD;
+    return MSDA_VARIANT_GENERIC;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msda_abi_version(void) { return RLIPV2_MSDA_ABI_VERSION; }
+
+const char *msda_strerror(int status)
+{
+    switch (status) {
+        case MSDA_OK: return "ok";
+        case MSDA_ERR_BAD_DTYPE: return "unsupported dtype (expected MSDA_F32, MSDA_F64 or MSDA_BF16)";
+        case MSDA_ERR_BAD_SHAPE: return "bad shape: negative dimension or index range exceeded";
+        case MSDA_ERR_NULL_POINTER: return "null pointer for a non-empty tensor";
+        case MSDA_ERR_IM2COL_STEP: return "batch must divide im2col_step: batch % min(batch, im2col_step) != 0";
+        case MSDA_ERR_LAUNCH: return "HIP kernel launch failed";
+        case MSDA_ERR_BAD_VARIANT: return "requested kernel variant does not support this problem";
+        case MSDA_ERR_ALIGNMENT: return "tensor pointer not 16-byte aligned";
+        default: return "unknown status";
+    }
+}
+
+const char *msda_variant_name(int variant)
+{
+    switch (variant) {
+        case MSDA_VARIANT_AUTO: return "auto";
+        case MSDA_VARIANT_GENERIC: return "generic";
+        case MSDA_VARIANT_QUAD: return "quad";
+        case MSDA_VARIANT_WINDOW: return "window";
+        default: return "?";
+    }
+}
+
+int msda_check_im2col_step(int batch, int im2col_step)
+{
+    if (batch <= 0) return MSDA_OK;
+    const int step = batch < im2col_step ? batch : im2col_step;   // .cu:50
+    if (step <= 0 || batch % step != 0) return MSDA_ERR_IM2COL_STEP;
+    return MSDA_OK;
+}
+
+int64_t msda_algorithmic_bytes(int dtype, int backward, int N, int S, int M, int D, int L, int Lq, int P)
+{
+    const int64_t sv = (int64_t)value_elem(dtype), sl = (int64_t)loc_elem(dtype), sg = (int64_t)grad_value_elem(dtype);
+    const int64_t v = (int64_t)S * M * D, lo = (int64_t)Lq * M * L * P * 2, a = (int64_t)Lq * M * L * P,
+                  o = (int64_t)Lq * M * D;
+    if (!backward) return (int64_t)N * (v * sv + lo * sl + a * sl + o * sv);
+    return (int64_t)N * (v * (sv + sg) + 2 * lo * sl + 2 * a * sl + o * sv);
+}
+
+int msda_pick_variant(int backward, int dtype, int N, int S, int M, int D, int L, int Lq, int P)
+{
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    return pick(backward != 0, p);
+}
+
+int msda_forward_ex(int variant, int dtype, const void *value, const int64_t *spatial_shapes,
+                    const int64_t *level_start, const void *sampling_loc, const void *attn_weight, int N, int S,
+                    int M, int D, int L, int Lq, int P, void *out, void *stream)
+{
+    const int st = validate(dtype, N, S, M, D, L, Lq, P);
+    if (st != MSDA_OK) return st;
+    const long out_elems = (long)N * Lq * M * D;
+    if (out_elems == 0) return MSDA_OK;                      // empty output: nothing to do
+    if (!out) return MSDA_ERR_NULL_POINTER;
+    const long samples = (long)N * Lq * M * L * P;
+    if (samples == 0 || (long)N * S == 0) {                  // no samples / empty pyramid -> zeros (at::zeros, .cu:54)
+        return hipMemsetAsync(out, 0, out_elems * value_elem(dtype), (hipStream_t)stream) == hipSuccess
+                   ? MSDA_OK : MSDA_ERR_LAUNCH;
+    }
+    if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight) return MSDA_ERR_NULL_POINTER;
+    if ((long)N * Lq * M >= (1L << 31) / 64) return MSDA_ERR_BAD_SHAPE;
+
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.loc = sampling_loc; p.aw = attn_weight;
+    p.out = out; p.stream = (hipStream_t)stream;
+
+    int v = variant == MSDA_VARIANT_AUTO ? pick(false, p) : variant;
+    if (v != MSDA_VARIANT_GENERIC &&
+        !(aligned16(value) && aligned16(sampling_loc) && aligned16(attn_weight) && aligned16(out))) {
+        if (variant != MSDA_VARIANT_AUTO) return MSDA_ERR_ALIGNMENT;
+        v = MSDA_VARIANT_GENERIC;
+    }
+    (void)hipGetLastError();
+    switch (v) {
+        case MSDA_VARIANT_GENERIC: launch_generic_forward(p); break;
+        case MSDA_VARIANT_QUAD:
+            if (!quad_supports(p)) return MSDA_ERR_BAD_VARIANT;
+            launch_quad_forward(p);
+            break;
+        case MSDA_VARIANT_WINDOW:
+            if (!window_supports(p, false)) return MSDA_ERR_BAD_VARIANT;
+            launch_window_forward(p);
+            break;
+        default: return MSDA_ERR_BAD_VARIANT;
+    }
+    return finish_launch();
+}
+
+int msda_backward_ex(int variant, int dtype, const void *value, const int64_t *spatial_shapes,
+                     const int64_t *level_start, const void *sampling_loc, const void *attn_weight,
+                     const void *grad_out, int N, int S, int M, int D, int L, int Lq, int P, void *grad_value,
+                     void *grad_sampling_loc, void *grad_attn_weight, void *stream)
+{
+    const int st = validate(dtype, N, S, M, D, L, Lq, P);
+    if (st != MSDA_OK) return st;
+    const bool prezeroed = (variant & MSDA_FLAG_GRAD_VALUE_ZEROED) != 0;
+    variant &= 0xff;
+    hipStream_t hs = (hipStream_t)stream;
+    const long v_elems = (long)N * S * M * D;
+    const long samples = (long)N * Lq * M * L * P;
+    (void)hipGetLastError();
+    if (v_elems > 0) {
+        if (!grad_value) return MSDA_ERR_NULL_POINTER;
+        if (!prezeroed &&
+            hipMemsetAsync(grad_value, 0, v_elems * grad_value_elem(dtype), hs) != hipSuccess) return MSDA_ERR_LAUNCH;
+    }
+    if (samples == 0) return MSDA_OK;
+    if (!grad_sampling_loc || !grad_attn_weight) return MSDA_ERR_NULL_POINTER;
+    if (v_elems == 0 || D == 0) {   // samples exist but nothing to sample from: all-zero gradients
+        if (hipMemsetAsync(grad_sampling_loc, 0, samples * 2 * loc_elem(dtype), hs) != hipSuccess ||
+            hipMemsetAsync(grad_attn_weight, 0, samples * loc_elem(dtype), hs) != hipSuccess)
+            return MSDA_ERR_LAUNCH;
+        return MSDA_OK;
+    }
+    if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_out)
+        return MSDA_ERR_NULL_POINTER;
+    if ((long)N * Lq * M >= (1L << 31) / 64) return MSDA_ERR_BAD_SHAPE;
+
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.loc = sampling_loc; p.aw = attn_weight;
+    p.grad_out = grad_out; p.g_value = grad_value; p.g_loc = grad_sampling_loc; p.g_aw = grad_attn_weight;
+    p.stream = hs;
+
+    int v = variant == MSDA_VARIANT_AUTO ? pick(true, p) : variant;
+    if (v != MSDA_VARIANT_GENERIC &&
+        !(aligned16(value) && aligned16(sampling_loc) && aligned16(attn_weight) && aligned16(grad_out) &&
+          aligned16(grad_value) && aligned16(grad_sampling_loc) && aligned16(grad_attn_weight))) {
+        if (variant != MSDA_VARIANT_AUTO) return MSDA_ERR_ALIGNMENT;
+        v = MSDA_VARIANT_GENERIC;
+    }
+    switch (v) {
+        case MSDA_VARIANT_GENERIC: launch_generic_backward(p); break;
+        case MSDA_VARIANT_QUAD:
+            if (!quad_supports(p)) return MSDA_ERR_BAD_VARIANT;
+            launch_quad_backward(p);
+            break;
+        case MSDA_VARIANT_WINDOW:
+            if (!window_supports(p, true)) return MSDA_ERR_BAD_VARIANT;
+            launch_window_backward(p);
+            break;
+        default: return MSDA_ERR_BAD_VARIANT;
+    }
+    return finish_launch();
+}
+
+int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                 const void *sampling_loc, const void *attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
+                 void *out, void *stream)
+{
+    return msda_forward_ex(MSDA_VARIANT_AUTO, dtype, value, spatial_shapes, level_start, sampling_loc, attn_weight,
+                           N, S, M, D, L, Lq, P, out, stream);
+}
+
+int msda_backward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                  const void *sampling_loc, const void *attn_weight, const void *grad_out, int N, int S, int M,
+                  int D, int L, int Lq, int P, void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                  void *stream)
+{
+    return msda_backward_ex(MSDA_VARIANT_AUTO, dtype, value, spatial_shapes, level_start, sampling_loc, attn_weight,
+                            grad_out, N, S, M, D, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// msda_internal.h -- host-side declarations shared by the kernel files and the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rlipv2_msda.h"
+
+namespace msda {
+
+struct Problem {
+    int dtype;
+    int N, S, M, D, L, Lq, P;
+    const void *value;
+    const int64_t *shapes;  // device, [L,2] (H, W)
+    const int64_t *starts;  // device, [L]
+    const void *loc;
+    const void *aw;
+    // forward
+    void *out;
+    // backward
+    const void *grad_out;
+    void *g_value;
+    void *g_loc;
+    void *g_aw;
+    hipStream_t stream;
+};
+
+// each launcher enqueues on p.stream and returns; the caller checks hipGetLastError()
+void launch_generic_forward(const Problem &p);
+void launch_generic_backward(const Problem &p);
+
+bool quad_supports(const Problem &p);
+void launch_quad_forward(const Problem &p);
+void launch_quad_backward(const Problem &p);
+
+bool window_supports(const Problem &p, bool backward);
+void launch_window_forward(const Problem &p);
+void launch_window_backward(const Problem &p);
+
+}  // namespace msda

@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference's MSDA operator interface, bound to the HIP library.
+
+Drop-in surface (same names, argument order and error behaviour as the reference):
+
+* ``ms_deform_attn_forward`` / ``ms_deform_attn_backward`` -- the two functions the reference's
+  extension module ``MultiScaleDeformableAttention`` exports (models/ops/src/vision.cpp:13-16;
+  semantics models/ops/src/cuda/ms_deform_attn_cuda.cu:20-153).
+* ``MSDeformAttnFunction`` -- the autograd Function of
+  models/ops/functions/ms_deform_attn_func.py:25-42 (6 positional args, gradients for
+  value / sampling_locations / attention_weights, once-differentiable).
+
+Differences, all additive: bfloat16 ``value`` is accepted (sampling locations and attention
+weights are then float32, or bfloat16 which is upcast; gradients come back in the inputs'
+dtypes); a failed kernel launch raises instead of being printf()'d
+(ms_deform_im2col_cuda.cuh:948-952).  CPU tensors raise "Not implemented on the CPU" exactly as
+the reference does (models/ops/src/ms_deform_attn.h:54) -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.MSDA_F32, torch.float64: _lib.MSDA_F64, torch.bfloat16: _lib.MSDA_BF16}
+
+# kernel override for benchmarks / tests ("auto" in product use)
+_variant = _lib.VARIANT_AUTO
+
+
+def set_variant(name: str) -> None:
+    """Pin one kernel implementation ("auto", "generic", "quad", "window")."""
+    global _variant
+    _variant = _lib.VARIANTS[name]
+
+
+def _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=()):
+    named = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+             ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), *extra]
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")          # ms_deform_attn.h:54
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")   # ms_deform_attn_cuda.cu:28-32
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")         # ms_deform_attn_cuda.cu:34-38
+        if t.device != value.device:
+            raise RuntimeError(f"{name} is on {t.device}, value is on {value.device}")
+    if value.dtype not in _DTYPES:
+        raise RuntimeError(f"ms_deform_attn: unsupported dtype {value.dtype}")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("expected value [N,S,M,D], sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P]")
+
+
+def _dims(value, spatial_shapes, sampling_loc):
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    return N, S, M, D, L, Lq, P
+
+
+def _aux_dtype(value):
+    """dtype of sampling_loc / attn_weight / all gradients as the kernels see them."""
+    return torch.float64 if value.dtype == torch.float64 else torch.float32
+
+
+def _raise(status):
+    raise RuntimeError(f"ms_deform_attn: {_lib.strerror(status)} (status {status})")
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """Reference: ms_deform_attn_forward (vision.cpp:14) -> out [N, Lq, M*D]."""
+    _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    L = _lib.lib()
+    N, S, M, D, nL, Lq, P = _dims(value, spatial_shapes, sampling_loc)
+    st = L.msda_check_im2col_step(N, int(im2col_step))
+    if st:
+        _raise(st)
+    aux = _aux_dtype(value)
+    loc = sampling_loc if sampling_loc.dtype == aux else sampling_loc.to(aux)
+    aw = attn_weight if attn_weight.dtype == aux else attn_weight.to(aux)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        st = L.msda_forward_ex(_variant, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                               level_start_index.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                               N, S, M, D, nL, Lq, P, out.data_ptr(), stream)
+    if st:
+        _raise(st)
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step):
+    """Reference: ms_deform_attn_backward (vision.cpp:15) -> [grad_value, grad_sampling_loc, grad_attn_weight]."""
+    _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                  extra=(("grad_output", grad_output),))
+    L = _lib.lib()
+    N, S, M, D, nL, Lq, P = _dims(value, spatial_shapes, sampling_loc)
+    st = L.msda_check_im2col_step(N, int(im2col_step))
+    if st:
+        _raise(st)
+    aux = _aux_dtype(value)
+    loc = sampling_loc if sampling_loc.dtype == aux else sampling_loc.to(aux)
+    aw = attn_weight if attn_weight.dtype == aux else attn_weight.to(aux)
+    go = grad_output if grad_output.dtype == value.dtype else grad_output.to(value.dtype)
+    g_value = torch.empty(value.shape, dtype=aux, device=value.device)   # zero-filled inside the library
+    g_loc = torch.empty(sampling_loc.shape, dtype=aux, device=value.device)
+    g_aw = torch.empty(attn_weight.shape, dtype=aux, device=value.device)
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        st = L.msda_backward_ex(_variant, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                                level_start_index.data_ptr(), loc.data_ptr(), aw.data_ptr(), go.data_ptr(),
+                                N, S, M, D, nL, Lq, P, g_value.data_ptr(), g_loc.data_ptr(), g_aw.data_ptr(),
+                                stream)
+    if st:
+        _raise(st)
+    if g_value.dtype != value.dtype:
+        g_value = g_value.to(value.dtype)
+    if g_loc.dtype != sampling_loc.dtype:
+        g_loc = g_loc.to(sampling_loc.dtype)
+    if g_aw.dtype != attn_weight.dtype:
+        g_aw = g_aw.to(attn_weight.dtype)
+    return [g_value, g_loc, g_aw]
+
+
+class MSDeformAttnFunction(Function):
+    """Reference: models/ops/functions/ms_deform_attn_func.py:25-42."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                        attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                              attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, loc, aw = ctx.saved_tensors
+        g_value, g_loc, g_aw = ms_deform_attn_backward(value, shapes, starts, loc, aw, grad_output.contiguous(),
+                                                       ctx.im2col_step)
+        return g_value, None, None, g_loc, g_aw, None

@@ -1,0 +1,111 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol the
+header declares; host-side argument checks reproduce the reference's error behaviour.
+No compute is launched here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from rlipv2_amd import _lib, msda
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "rlipv2_msda.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(msda_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = _declared_functions()
+    assert set(declared) == set(_lib.EXPORTS), (declared, _lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/rlipv2_msda.h but not exported"
+
+
+def test_abi_version_and_strerror():
+    L = _lib.lib()
+    assert L.msda_abi_version() == 1
+    assert _lib.strerror(0) == "ok"
+    for st in range(-7, 0):
+        assert _lib.strerror(st) not in ("ok", "unknown status")
+    assert _lib.strerror(-99) == "unknown status"
+    assert L.msda_variant_name(2) == b"quad"
+
+
+def test_im2col_step_rule_matches_reference():
+    # reference: ms_deform_attn_cuda.cu:50-52 -- batch % min(batch, im2col_step) == 0
+    L = _lib.lib()
+    for batch in range(1, 70):
+        for step in (1, 2, 3, 4, 8, 64):
+            want_ok = batch % min(batch, step) == 0
+            assert (L.msda_check_im2col_step(batch, step) == 0) == want_ok, (batch, step)
+
+
+def test_algorithmic_bytes_match_baseline_table():
+    # 800x1333 pyramid, M8 D32 L4 P4, per image
+    dims = (1, 22223, 8, 32, 4, 22223, 4)
+    assert _lib.algorithmic_bytes(_lib.MSDA_F32, False, *dims) == 79647232
+    assert _lib.algorithmic_bytes(_lib.MSDA_BF16, False, *dims) == 56890880
+    assert _lib.algorithmic_bytes(_lib.MSDA_F32, True, *dims) == 136538112
+    dec = (1, 22223, 8, 32, 4, 300, 4)
+    assert round(_lib.algorithmic_bytes(_lib.MSDA_F32, False, *dec) / 1e6, 2) == 23.52
+
+
+def test_variant_choice_is_static():
+    L = _lib.lib()
+    enc = (4, 22223, 8, 32, 4, 22223, 4)
+    assert L.msda_pick_variant(0, _lib.MSDA_F64, *enc) == _lib.VARIANT_GENERIC
+    assert L.msda_pick_variant(0, _lib.MSDA_F32, 1, 30, 2, 2, 2, 2, 2) == _lib.VARIANT_GENERIC
+    assert L.msda_pick_variant(0, _lib.MSDA_F32, *enc) in (_lib.VARIANT_QUAD, _lib.VARIANT_WINDOW)
+
+
+def test_bad_arguments_are_reported_not_launched():
+    L = _lib.lib()
+    # bad dtype / negative dims are rejected before anything touches the device
+    assert L.msda_forward(7, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, None, None) == -1
+    assert L.msda_forward(0, None, None, None, None, None, -1, 1, 1, 1, 1, 1, 1, None, None) == -2
+    # empty output is a no-op success (empty batch / no queries)
+    assert L.msda_forward(0, None, None, None, None, None, 0, 10, 8, 32, 4, 5, 4, None, None) == 0
+    assert L.msda_forward(0, None, None, None, None, None, 2, 10, 8, 32, 4, 0, 4, None, None) == 0
+
+
+def _cpu_inputs():
+    shapes = torch.tensor([[6, 4], [3, 2]], dtype=torch.long)
+    starts = torch.tensor([0, 24], dtype=torch.long)
+    value = torch.rand(1, 30, 2, 2)
+    loc = torch.rand(1, 2, 2, 2, 2, 2)
+    aw = torch.rand(1, 2, 2, 2, 2)
+    return value, shapes, starts, loc, aw
+
+
+def test_cpu_tensors_raise_like_the_reference():
+    # reference: models/ops/src/ms_deform_attn.h:54 AT_ERROR("Not implemented on the CPU")
+    value, shapes, starts, loc, aw = _cpu_inputs()
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        msda.MSDeformAttnFunction.apply(value, shapes, starts, loc, aw, 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, torch.rand(1, 2, 4), 64)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librlipv2_msda.so")
+    with pytest.raises(RuntimeError, match="no CPU / PyTorch fallback"):
+        _lib.lib()
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "rlipv2_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"

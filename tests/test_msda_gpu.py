@@ -1,0 +1,369 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP kernels, called through the
+C ABI, against the CPU oracle and the committed golden vectors.
+
+Tolerances
+----------
+float64 : rtol 1e-5 / atol 1e-8 -- torch.allclose defaults, the reference's own bar
+          (models/ops/test.py:44).
+float32 : rtol 1e-4, atol 1e-5 x max|ref| -- two orders tighter than the reference's
+          rtol 1e-2 / atol 1e-3 (test.py:60); grad_value sums up to hundreds of float atomics
+          in arbitrary order, hence the relative-to-max floor.
+bfloat16: value / grad_out are rounded to bf16 BEFORE the oracle sees them (the kernels
+          accumulate in float32), so outputs differ only by the final rounding of `out` to
+          bf16: rtol 2^-7.  Gradients are float32 and use the float32 tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import MSDA_GOLDEN_CASES, boundary_samples, kink_samples, load_golden
+from oracle import msda_oracle as O
+from rlipv2_amd import _lib, msda
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _starts(shapes):
+    hw = shapes[:, 0] * shapes[:, 1]
+    return np.concatenate([[0], np.cumsum(hw)[:-1]]).astype(np.int64)
+
+
+def _to_dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def run_hip(variant, tdtype, value, shapes, starts, loc, aw, grad_out=None):
+    """numpy in -> numpy out through rlipv2_amd.msda (C ABI underneath)."""
+    aux = torch.float64 if tdtype == torch.float64 else torch.float32
+    msda.set_variant(variant)
+    try:
+        v = _to_dev(value, tdtype)
+        sh, st = _to_dev(shapes), _to_dev(starts)
+        l, a = _to_dev(loc, aux), _to_dev(aw, aux)
+        out = msda.ms_deform_attn_forward(v, sh, st, l, a, 64)
+        res = [out.float().cpu().numpy() if tdtype == torch.bfloat16 else out.cpu().numpy()]
+        if grad_out is not None:
+            go = _to_dev(grad_out, tdtype)
+            gv, gl, ga = msda.ms_deform_attn_backward(v, sh, st, l, a, go, 64)
+            res += [gv.float().cpu().numpy() if tdtype == torch.bfloat16 else gv.cpu().numpy(),
+                    gl.cpu().numpy(), ga.cpu().numpy()]
+        torch.cuda.synchronize()
+    finally:
+        msda.set_variant("auto")
+    return res
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().float().numpy()
+
+
+def close32(got, ref, rtol=1e-4, atol_rel=1e-5):
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol_rel * max(1.0, float(np.abs(ref).max())))
+
+
+def variants_for(D, L, P, tdtype):
+    v = ["generic"]
+    if D == 32 and L == 4 and P == 4 and tdtype != torch.float64:
+        v.append("quad")
+        if _lib.lib().msda_pick_variant(0, 0, 1, 100, 8, 32, 4, 100, 4) == _lib.VARIANT_WINDOW:
+            v.append("window")
+    v.append("auto")
+    return v
+
+
+def random_problem(rng, N, shapes, M, D, Lq, P, spread=2.0, enc=False):
+    shapes = np.asarray(shapes, dtype=np.int64)
+    L = shapes.shape[0]
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = rng.standard_normal((N, S, M, D)).astype(np.float32)
+    if enc:
+        ref = []
+        for (H, W) in shapes:
+            ys, xs = np.meshgrid((np.arange(H) + 0.5) / H, (np.arange(W) + 0.5) / W, indexing="ij")
+            ref.append(np.stack([xs.ravel(), ys.ravel()], -1))
+        ref = np.concatenate(ref, 0)[None].repeat(N, 0)
+        Lq = S
+    else:
+        ref = rng.uniform(-0.05, 1.05, size=(N, Lq, 2))
+    off = rng.standard_normal((N, Lq, M, L, P, 2)) * spread
+    norm = np.stack([shapes[:, 1], shapes[:, 0]], -1).astype(np.float64)
+    loc = (ref[:, :, None, None, None, :] + off / norm[None, None, None, :, None, :]).astype(np.float32)
+    logits = rng.standard_normal((N, Lq, M, L * P))
+    aw = np.exp(logits - logits.max(-1, keepdims=True))
+    aw = (aw / aw.sum(-1, keepdims=True)).reshape(N, Lq, M, L, P).astype(np.float32)
+    grad_out = rng.standard_normal((N, Lq, M * D)).astype(np.float32)
+    return value, shapes, _starts(shapes), loc, aw, grad_out
+
+
+# ---------------------------------------------------------------------------------------------
+# golden vectors (reference-generated)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", MSDA_GOLDEN_CASES)
+def test_golden_f64(case):
+    g = load_golden(case)
+    out, gv, gl, ga = run_hip("generic", torch.float64, g["value"], g["shapes"], g["starts"], g["loc"], g["aw"],
+                              g["grad_out"])
+    np.testing.assert_allclose(out, g["out_f64"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(gv, g["g_value_f64"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(ga, g["g_aw_f64"], rtol=1e-5, atol=1e-8)
+    keep = ~boundary_samples(g)
+    np.testing.assert_allclose(gl[keep], g["g_loc_f64"][keep], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("case", MSDA_GOLDEN_CASES)
+def test_golden_f32_all_variants(case):
+    g = load_golden(case)
+    N, S, M, D = g["value"].shape
+    L, P = g["loc"].shape[3], g["loc"].shape[4]
+    keep = ~kink_samples(g)
+    for variant in variants_for(D, L, P, torch.float32):
+        out, gv, gl, ga = run_hip(variant, torch.float32, g["value"], g["shapes"], g["starts"], g["loc"], g["aw"],
+                                  g["grad_out"])
+        close32(out, g["out_f32"])
+        close32(gv, g["g_value_f32"])
+        close32(ga, g["g_aw_f32"])
+        close32(gl[keep], g["g_loc_f32"][keep])
+
+
+@pytest.mark.parametrize("case", ["model_enc", "model_dec", "testpy_d32", "testpy_d71"])
+def test_golden_bf16_all_variants(case):
+    g = load_golden(case)
+    N, S, M, D = g["value"].shape
+    L, P = g["loc"].shape[3], g["loc"].shape[4]
+    vb, gob = bf16_round(g["value"]), bf16_round(g["grad_out"])
+    args = (vb.astype(np.float64), g["shapes"], g["starts"], g["loc"].astype(np.float64), g["aw"].astype(np.float64))
+    ref_out = O.forward(*args)
+    ref_gv, ref_gl, ref_ga = O.backward(*args, gob.astype(np.float64))
+    keep = ~kink_samples(g)
+    for variant in variants_for(D, L, P, torch.bfloat16):
+        out, gv, gl, ga = run_hip(variant, torch.bfloat16, vb, g["shapes"], g["starts"], g["loc"], g["aw"], gob)
+        np.testing.assert_allclose(out, ref_out, rtol=2.0 ** -7, atol=1e-3 * float(np.abs(ref_out).max()))
+        # grad_value comes back rounded to bf16 through the torch-facing wrapper
+        np.testing.assert_allclose(gv, ref_gv, rtol=2.0 ** -7, atol=1e-3 * float(np.abs(ref_gv).max()))
+        close32(ga, ref_ga)
+        close32(gl[keep], ref_gl[keep])
+
+
+# ---------------------------------------------------------------------------------------------
+# seeded random problems vs the oracle (sizes the oracle finishes in seconds)
+# ---------------------------------------------------------------------------------------------
+PYRAMID = [(25, 34), (13, 17), (7, 9), (4, 5)]
+
+
+@pytest.mark.parametrize("enc", [True, False])
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.bfloat16])
+def test_random_model_shape_vs_oracle(enc, tdtype):
+    rng = np.random.default_rng(5 + int(enc))
+    value, shapes, starts, loc, aw, go = random_problem(rng, 3, PYRAMID, 8, 32, 77, 4, spread=3.0, enc=enc)
+    if tdtype == torch.bfloat16:
+        value, go = bf16_round(value), bf16_round(go)
+    ref_out = O.forward(value.astype(np.float64), shapes, starts, loc.astype(np.float64), aw.astype(np.float64))
+    ref = O.backward(value.astype(np.float64), shapes, starts, loc.astype(np.float64), aw.astype(np.float64),
+                     go.astype(np.float64))
+    g = dict(loc=loc, shapes=shapes)
+    keep = ~kink_samples(g)
+    for variant in variants_for(32, 4, 4, tdtype):
+        out, gv, gl, ga = run_hip(variant, tdtype, value, shapes, starts, loc, aw, go)
+        if tdtype == torch.bfloat16:
+            np.testing.assert_allclose(out, ref_out, rtol=2.0 ** -7, atol=1e-3)
+            np.testing.assert_allclose(gv, ref[0], rtol=2.0 ** -7, atol=2e-3 * float(np.abs(ref[0]).max()))
+        else:
+            close32(out, ref_out)
+            close32(gv, ref[0])
+        close32(gl[keep], ref[1][keep])
+        close32(ga, ref[2])
+
+
+@pytest.mark.parametrize("M,D,L,P", [(2, 2, 2, 2), (3, 30, 1, 5), (8, 64, 4, 4), (1, 71, 3, 2), (4, 32, 4, 2),
+                                     (2, 130, 2, 3)])
+def test_generic_shapes_vs_oracle(M, D, L, P):
+    rng = np.random.default_rng(M * 1000 + D)
+    shapes = [(9, 11), (5, 6), (3, 3), (2, 2)][:L]
+    value, shapes, starts, loc, aw, go = random_problem(rng, 2, shapes, M, D, 13, P)
+    for tdtype, npdt in ((torch.float64, np.float64), (torch.float32, np.float32)):
+        ref_out = O.forward(value.astype(npdt), shapes, starts, loc.astype(npdt), aw.astype(npdt))
+        ref = O.backward(value.astype(npdt), shapes, starts, loc.astype(npdt), aw.astype(npdt), go.astype(npdt))
+        out, gv, gl, ga = run_hip("auto", tdtype, value, shapes, starts, loc, aw, go)
+        if tdtype == torch.float64:
+            for a, b in ((out, ref_out), (gv, ref[0]), (gl, ref[1]), (ga, ref[2])):
+                np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
+        else:
+            keep = ~kink_samples(dict(loc=loc, shapes=shapes))
+            close32(out, ref_out); close32(gv, ref[0]); close32(ga, ref[2]); close32(gl[keep], ref[1][keep])
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own test recipe (models/ops/test.py): autograd Function + gradcheck in float64
+# ---------------------------------------------------------------------------------------------
+def _testpy_inputs(D, dtype):
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long, device=DEV)
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    value = (torch.rand(N, S, M, D, device=DEV) * 0.01).to(dtype)
+    loc = torch.rand(N, Lq, M, L, P, 2, device=DEV).to(dtype)
+    aw = torch.rand(N, Lq, M, L, P, device=DEV) + 1e-5
+    aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).to(dtype)
+    return value, shapes, starts, loc, aw
+
+
+@pytest.mark.parametrize("D", [30, 32, 64, 71, 1025])
+def test_reference_gradcheck_recipe(D):
+    # models/ops/test.py:67-82, channels from test.py:89-90 (2048 / 3096 run the same kernel as 1025)
+    value, shapes, starts, loc, aw = _testpy_inputs(D, torch.float64)
+    value.requires_grad_(True); loc.requires_grad_(True); aw.requires_grad_(True)
+    assert torch.autograd.gradcheck(msda.MSDeformAttnFunction.apply, (value, shapes, starts, loc, aw, 2))
+
+
+def test_autograd_function_returns_grads_in_input_dtypes():
+    rng = np.random.default_rng(0)
+    value, shapes, starts, loc, aw, go = random_problem(rng, 2, PYRAMID, 8, 32, 20, 4)
+    for vdt, adt in ((torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                     (torch.bfloat16, torch.bfloat16)):
+        v = _to_dev(value, vdt).requires_grad_(True)
+        l = _to_dev(loc, adt).requires_grad_(True)
+        a = _to_dev(aw, adt).requires_grad_(True)
+        out = msda.MSDeformAttnFunction.apply(v, _to_dev(shapes), _to_dev(starts), l, a, 64)
+        assert out.dtype == vdt and out.shape == (2, 20, 256)
+        out.backward(_to_dev(go, vdt))
+        assert v.grad.dtype == vdt and l.grad.dtype == adt and a.grad.dtype == adt
+        assert torch.isfinite(v.grad.float()).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases: empty / ragged / out-of-range inputs, argument errors
+# ---------------------------------------------------------------------------------------------
+def test_empty_queries_and_empty_batch():
+    shapes = torch.tensor([[4, 5], [2, 3], [1, 2], [1, 1]], dtype=torch.long, device=DEV)
+    starts = torch.tensor([0, 20, 26, 28], dtype=torch.long, device=DEV)
+    value = torch.randn(2, 29, 8, 32, device=DEV)
+    loc = torch.rand(2, 0, 8, 4, 4, 2, device=DEV)
+    aw = torch.rand(2, 0, 8, 4, 4, device=DEV)
+    out = msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64)
+    assert out.shape == (2, 0, 256)
+    gv, gl, ga = msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, torch.zeros(2, 0, 256, device=DEV), 64)
+    assert gv.shape == value.shape and float(gv.abs().sum()) == 0.0 and gl.numel() == 0 and ga.numel() == 0
+
+
+def test_all_samples_outside_give_zero():
+    rng = np.random.default_rng(1)
+    value, shapes, starts, loc, aw, go = random_problem(rng, 1, PYRAMID, 8, 32, 9, 4)
+    loc = loc * 0 + np.float32(7.5)
+    for variant in variants_for(32, 4, 4, torch.float32):
+        out, gv, gl, ga = run_hip(variant, torch.float32, value, shapes, starts, loc, aw, go)
+        assert not out.any() and not gv.any() and not gl.any() and not ga.any()
+
+
+def test_nan_location_is_skipped_like_reference():
+    rng = np.random.default_rng(2)
+    value, shapes, starts, loc, aw, go = random_problem(rng, 1, PYRAMID, 8, 32, 5, 4)
+    loc[0, 1, 2, 1, 3, 0] = np.nan
+    ref = O.forward(value, shapes, starts, loc, aw)
+    for variant in variants_for(32, 4, 4, torch.float32):
+        out = run_hip(variant, torch.float32, value, shapes, starts, loc, aw)[0]
+        assert np.isfinite(out).all()
+        close32(out, ref)
+
+
+def test_ragged_query_counts_cover_partial_waves():
+    rng = np.random.default_rng(3)
+    for Lq in (1, 2, 3, 7, 15, 17, 63, 65):
+        value, shapes, starts, loc, aw, go = random_problem(rng, 1, PYRAMID, 8, 32, Lq, 4)
+        ref_out = O.forward(value, shapes, starts, loc, aw)
+        ref = O.backward(value, shapes, starts, loc, aw, go)
+        keep = ~kink_samples(dict(loc=loc, shapes=shapes))
+        for variant in variants_for(32, 4, 4, torch.float32):
+            out, gv, gl, ga = run_hip(variant, torch.float32, value, shapes, starts, loc, aw, go)
+            close32(out, ref_out); close32(gv, ref[0]); close32(ga, ref[2]); close32(gl[keep], ref[1][keep])
+
+
+def test_im2col_step_error_matches_reference():
+    rng = np.random.default_rng(4)
+    value, shapes, starts, loc, aw, go = random_problem(rng, 3, PYRAMID, 8, 32, 4, 4)
+    args = [_to_dev(x) for x in (value, shapes, starts, loc, aw)]
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        msda.ms_deform_attn_forward(*args, 2)            # 3 % 2 != 0  (ms_deform_attn_cuda.cu:52)
+    msda.ms_deform_attn_forward(*args, 64)               # min(batch, 64) = 3 -> fine
+
+
+def test_non_contiguous_input_raises():
+    rng = np.random.default_rng(4)
+    value, shapes, starts, loc, aw, go = random_problem(rng, 2, PYRAMID, 8, 32, 4, 4)
+    v = _to_dev(value).transpose(2, 3)
+    with pytest.raises(RuntimeError, match="has to be contiguous"):
+        msda.ms_deform_attn_forward(v, _to_dev(shapes), _to_dev(starts), _to_dev(loc), _to_dev(aw), 64)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size (BASELINE config 2: N=4, 800x1333 pyramid) through size-independent properties
+# ---------------------------------------------------------------------------------------------
+FULL = [(100, 167), (50, 84), (25, 42), (13, 21)]
+
+
+def _full_inputs(dtype, Lq=None, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    shapes = torch.tensor(FULL, dtype=torch.long, device=DEV)
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    N, M, D, L, P = 4, 8, 32, 4, 4
+    Lq = S if Lq is None else Lq
+    value = torch.randn(N, S, M, D, device=DEV, generator=g).to(dtype)
+    loc = torch.rand(N, Lq, M, L, P, 2, device=DEV, generator=g) * 1.1 - 0.05
+    aw = torch.softmax(torch.randn(N, Lq, M, L * P, device=DEV, generator=g), -1).view(N, Lq, M, L, P)
+    return value, shapes, starts, loc, aw
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_size_variants_agree_and_constant_field_is_reproduced(dtype):
+    value, shapes, starts, loc, aw = _full_inputs(dtype)
+    outs = {}
+    for variant in variants_for(32, 4, 4, dtype):
+        msda.set_variant(variant)
+        outs[variant] = msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64).float()
+    msda.set_variant("auto")
+    base = outs["generic"]
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    for k, o in outs.items():
+        assert (o - base).abs().max().item() <= tol * max(1.0, base.abs().max().item()), k
+    # partition of unity: interior samples of a constant field return the constant
+    loc_in = loc.clamp(0.02, 0.98)
+    ones = torch.ones_like(value)
+    o = msda.ms_deform_attn_forward(ones, shapes, starts, loc_in, aw, 64).float()
+    assert (o - 1).abs().max().item() < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+def test_full_size_linearity_and_adjoint_identity():
+    value, shapes, starts, loc, aw = _full_inputs(torch.float32, seed=1)
+    v2 = torch.randn_like(value)
+    f = lambda v: msda.ms_deform_attn_forward(v, shapes, starts, loc, aw, 64)
+    lhs = f(value * 0.5 + v2 * 2.0)
+    rhs = f(value) * 0.5 + f(v2) * 2.0
+    assert (lhs - rhs).abs().max().item() < 1e-4 * rhs.abs().max().item()
+    # <grad_out, J v> == <J^T grad_out, v>: forward and grad_value are adjoint linear maps
+    go = torch.randn_like(lhs)
+    gv, gl, ga = msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, go, 64)
+    a = (go.double() * f(v2).double()).sum().item()
+    b = (gv.double() * v2.double()).sum().item()
+    assert abs(a - b) <= 1e-4 * max(abs(a), abs(b), 1.0)
+    # grad_attn_weight is the per-sample bilinear value contracted with grad_out: summing
+    # aw * g_aw over samples gives <grad_out, out>
+    c = (ga.double() * aw.double()).sum().item()
+    d = (go.double() * f(value).double()).sum().item()
+    assert abs(c - d) <= 1e-4 * max(abs(c), abs(d), 1.0)
+
+
+def test_full_size_decoder_shape_variants_agree():
+    value, shapes, starts, loc, aw = _full_inputs(torch.float32, Lq=300, seed=2)
+    go = torch.randn(4, 300, 256, device=DEV)
+    res = {}
+    for variant in variants_for(32, 4, 4, torch.float32):
+        msda.set_variant(variant)
+        res[variant] = msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, go, 64)
+    msda.set_variant("auto")
+    for k, r in res.items():
+        for x, y in zip(r, res["generic"]):
+            assert (x - y).abs().max().item() <= 1e-4 * max(1.0, y.abs().max().item()), k

@@ -32,8 +32,11 @@ int finish_launch()
 
 int pick(bool backward, const Problem &p)
 {
-    if (window_supports(p, backward)) return MSDA_VARIANT_WINDOW;
-    if (quad_supports(p)) return MSDA_VARIANT_QUAD;
+    if (window_supports(p, backward) && p.S >= 1024) return MSDA_VARIANT_WINDOW;   // enough tiles to matter
+    // backward without a window: the quad kernel's strided 4-byte global atomics touch 8x more
+    // 32-byte sectors than the generic kernel's 128-byte rows (measured 34 ms vs 4.6 ms at the
+    // encoder shape, 526 us vs 91 us at Lq = 300), so the generic kernel is the better scatter.
+    if (!backward && quad_supports(p)) return MSDA_VARIANT_QUAD;
     return MSDA_VARIANT_GENERIC;
 }
 

@@ -26,13 +26,15 @@ from . import _lib
 _DTYPES = {torch.float32: _lib.MSDA_F32, torch.float64: _lib.MSDA_F64, torch.bfloat16: _lib.MSDA_BF16}
 
 # kernel override for benchmarks / tests ("auto" in product use)
-_variant = _lib.VARIANT_AUTO
+_variant_fwd = _lib.VARIANT_AUTO
+_variant_bwd = _lib.VARIANT_AUTO
 
 
-def set_variant(name: str) -> None:
-    """Pin one kernel implementation ("auto", "generic", "quad", "window")."""
-    global _variant
-    _variant = _lib.VARIANTS[name]
+def set_variant(forward: str, backward: str = None) -> None:
+    """Pin one kernel implementation ("auto", "generic", "quad", "window") per direction."""
+    global _variant_fwd, _variant_bwd
+    _variant_fwd = _lib.VARIANTS[forward]
+    _variant_bwd = _lib.VARIANTS[forward if backward is None else backward]
 
 
 def _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=()):
@@ -85,7 +87,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
-        st = L.msda_forward_ex(_variant, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+        st = L.msda_forward_ex(_variant_fwd, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
                                level_start_index.data_ptr(), loc.data_ptr(), aw.data_ptr(),
                                N, S, M, D, nL, Lq, P, out.data_ptr(), stream)
     if st:
@@ -112,7 +114,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     g_aw = torch.empty(attn_weight.shape, dtype=aux, device=value.device)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
-        st = L.msda_backward_ex(_variant, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+        st = L.msda_backward_ex(_variant_bwd, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
                                 level_start_index.data_ptr(), loc.data_ptr(), aw.data_ptr(), go.data_ptr(),
                                 N, S, M, D, nL, Lq, P, g_value.data_ptr(), g_loc.data_ptr(), g_aw.data_ptr(),
                                 stream)

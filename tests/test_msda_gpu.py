@@ -38,7 +38,7 @@ def _to_dev(a, dtype=None):
 def run_hip(variant, tdtype, value, shapes, starts, loc, aw, grad_out=None):
     """numpy in -> numpy out through rlipv2_amd.msda (C ABI underneath)."""
     aux = torch.float64 if tdtype == torch.float64 else torch.float32
-    msda.set_variant(variant)
+    msda.set_variant(*variant) if isinstance(variant, tuple) else msda.set_variant(variant)
     try:
         v = _to_dev(value, tdtype)
         sh, st = _to_dev(shapes), _to_dev(starts)
@@ -64,13 +64,18 @@ def close32(got, ref, rtol=1e-4, atol_rel=1e-5):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol_rel * max(1.0, float(np.abs(ref).max())))
 
 
-def variants_for(D, L, P, tdtype):
-    v = ["generic"]
+WINDOW_FWD = False   # msda_window.hip implements: backward only (this round)
+WINDOW_BWD = True
+
+
+def variants_for(D, L, P, tdtype, S=0, Lq=-1):
+    """(forward, backward) kernel pairs to exercise for a problem."""
+    v = [("generic", "generic")]
     if D == 32 and L == 4 and P == 4 and tdtype != torch.float64:
-        v.append("quad")
-        if _lib.lib().msda_pick_variant(0, 0, 1, 100, 8, 32, 4, 100, 4) == _lib.VARIANT_WINDOW:
-            v.append("window")
-    v.append("auto")
+        v.append(("quad", "quad"))
+        if S == Lq and S > 0:      # encoder-like call: queries are the pyramid's pixels
+            v.append(("window" if WINDOW_FWD else "quad", "window" if WINDOW_BWD else "quad"))
+    v.append(("auto", "auto"))
     return v
 
 
@@ -119,7 +124,7 @@ def test_golden_f32_all_variants(case):
     N, S, M, D = g["value"].shape
     L, P = g["loc"].shape[3], g["loc"].shape[4]
     keep = ~kink_samples(g)
-    for variant in variants_for(D, L, P, torch.float32):
+    for variant in variants_for(D, L, P, torch.float32, S, g["loc"].shape[1]):
         out, gv, gl, ga = run_hip(variant, torch.float32, g["value"], g["shapes"], g["starts"], g["loc"], g["aw"],
                                   g["grad_out"])
         close32(out, g["out_f32"])
@@ -138,7 +143,7 @@ def test_golden_bf16_all_variants(case):
     ref_out = O.forward(*args)
     ref_gv, ref_gl, ref_ga = O.backward(*args, gob.astype(np.float64))
     keep = ~kink_samples(g)
-    for variant in variants_for(D, L, P, torch.bfloat16):
+    for variant in variants_for(D, L, P, torch.bfloat16, S, g["loc"].shape[1]):
         out, gv, gl, ga = run_hip(variant, torch.bfloat16, vb, g["shapes"], g["starts"], g["loc"], g["aw"], gob)
         np.testing.assert_allclose(out, ref_out, rtol=2.0 ** -7, atol=1e-3 * float(np.abs(ref_out).max()))
         # grad_value comes back rounded to bf16 through the torch-facing wrapper
@@ -165,7 +170,7 @@ def test_random_model_shape_vs_oracle(enc, tdtype):
                      go.astype(np.float64))
     g = dict(loc=loc, shapes=shapes)
     keep = ~kink_samples(g)
-    for variant in variants_for(32, 4, 4, tdtype):
+    for variant in variants_for(32, 4, 4, tdtype, value.shape[1], loc.shape[1]):
         out, gv, gl, ga = run_hip(variant, tdtype, value, shapes, starts, loc, aw, go)
         if tdtype == torch.bfloat16:
             np.testing.assert_allclose(out, ref_out, rtol=2.0 ** -7, atol=1e-3)
@@ -253,7 +258,7 @@ def test_all_samples_outside_give_zero():
     rng = np.random.default_rng(1)
     value, shapes, starts, loc, aw, go = random_problem(rng, 1, PYRAMID, 8, 32, 9, 4)
     loc = loc * 0 + np.float32(7.5)
-    for variant in variants_for(32, 4, 4, torch.float32):
+    for variant in variants_for(32, 4, 4, torch.float32, value.shape[1], loc.shape[1]):
         out, gv, gl, ga = run_hip(variant, torch.float32, value, shapes, starts, loc, aw, go)
         assert not out.any() and not gv.any() and not gl.any() and not ga.any()
 
@@ -263,7 +268,7 @@ def test_nan_location_is_skipped_like_reference():
     value, shapes, starts, loc, aw, go = random_problem(rng, 1, PYRAMID, 8, 32, 5, 4)
     loc[0, 1, 2, 1, 3, 0] = np.nan
     ref = O.forward(value, shapes, starts, loc, aw)
-    for variant in variants_for(32, 4, 4, torch.float32):
+    for variant in variants_for(32, 4, 4, torch.float32, value.shape[1], loc.shape[1]):
         out = run_hip(variant, torch.float32, value, shapes, starts, loc, aw)[0]
         assert np.isfinite(out).all()
         close32(out, ref)
@@ -276,7 +281,7 @@ def test_ragged_query_counts_cover_partial_waves():
         ref_out = O.forward(value, shapes, starts, loc, aw)
         ref = O.backward(value, shapes, starts, loc, aw, go)
         keep = ~kink_samples(dict(loc=loc, shapes=shapes))
-        for variant in variants_for(32, 4, 4, torch.float32):
+        for variant in variants_for(32, 4, 4, torch.float32, value.shape[1], loc.shape[1]):
             out, gv, gl, ga = run_hip(variant, torch.float32, value, shapes, starts, loc, aw, go)
             close32(out, ref_out); close32(gv, ref[0]); close32(ga, ref[2]); close32(gl[keep], ref[1][keep])
 
@@ -321,16 +326,17 @@ def _full_inputs(dtype, Lq=None, seed=0):
 def test_full_size_variants_agree_and_constant_field_is_reproduced(dtype):
     value, shapes, starts, loc, aw = _full_inputs(dtype)
     outs = {}
-    for variant in variants_for(32, 4, 4, dtype):
-        msda.set_variant(variant)
+    for variant in variants_for(32, 4, 4, dtype, value.shape[1], loc.shape[1]):
+        msda.set_variant(*variant)
         outs[variant] = msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64).float()
     msda.set_variant("auto")
-    base = outs["generic"]
+    base = outs[("generic", "generic")]
     tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
     for k, o in outs.items():
         assert (o - base).abs().max().item() <= tol * max(1.0, base.abs().max().item()), k
-    # partition of unity: interior samples of a constant field return the constant
-    loc_in = loc.clamp(0.02, 0.98)
+    # partition of unity: samples whose 4 corners are all inside return the constant of a constant
+    # field (coarsest level is 13x21: pixel coordinate >= 0 needs loc >= 0.5/13)
+    loc_in = loc.clamp(0.04, 0.96)
     ones = torch.ones_like(value)
     o = msda.ms_deform_attn_forward(ones, shapes, starts, loc_in, aw, 64).float()
     assert (o - 1).abs().max().item() < (1e-2 if dtype == torch.bfloat16 else 1e-5)
@@ -360,10 +366,37 @@ def test_full_size_decoder_shape_variants_agree():
     value, shapes, starts, loc, aw = _full_inputs(torch.float32, Lq=300, seed=2)
     go = torch.randn(4, 300, 256, device=DEV)
     res = {}
-    for variant in variants_for(32, 4, 4, torch.float32):
-        msda.set_variant(variant)
+    for variant in variants_for(32, 4, 4, torch.float32, value.shape[1], loc.shape[1]):
+        msda.set_variant(*variant)
         res[variant] = msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, go, 64)
     msda.set_variant("auto")
     for k, r in res.items():
-        for x, y in zip(r, res["generic"]):
+        for x, y in zip(r, res[("generic", "generic")]):
             assert (x - y).abs().max().item() <= 1e-4 * max(1.0, y.abs().max().item()), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["model", "uniform", "far"])
+def test_full_size_encoder_backward_variants_agree(dtype, mode):
+    """Encoder shape at BASELINE batch 4: the LDS-window backward against the generic kernel, on
+    model-like locations (windows fit), uniform locations (windows overflow -> global-atomic
+    fallback for most corners) and far offsets (every window is clipped)."""
+    from tools.msda_inputs import make_inputs
+    inp = make_inputs(4, mode="uniform" if mode == "uniform" else "model", dtype=dtype, device=DEV, seed=7)
+    loc = inp["loc"]
+    if mode == "far":
+        loc = (loc + 0.17).contiguous()
+    a = (inp["value"], inp["shapes"], inp["starts"], loc, inp["aw"], inp["grad_out"])
+    res = {}
+    for variant in variants_for(32, 4, 4, dtype, inp["dims"][1], inp["dims"][5]):
+        if variant[1] == "quad":
+            continue                      # 34 ms of scattered global atomics; covered at small sizes
+        msda.set_variant(*variant)
+        res[variant] = [t.float() for t in msda.ms_deform_attn_backward(*a, 64)]
+    msda.set_variant("auto")
+    base = res[("generic", "generic")]
+    tol = 4e-3 if dtype == torch.bfloat16 else 1e-4      # grad_value returns rounded to bf16
+    for k, r in res.items():
+        for name, x, y in zip(("g_value", "g_loc", "g_aw"), r, base):
+            err = (x - y).abs().max().item() / max(1e-6, y.abs().max().item())
+            assert err <= (tol if name == "g_value" else 1e-4), (k, name, err)

@@ -15,7 +15,7 @@ timeout 900 python tools/msda_microbench.py --quick --out $OUT/microbench.json 2
 echo "== bench"
 timeout 900 python bench.py --steps 10 --warmup 2 2>&1 | tail -3 | tee $OUT/bench.json
 echo "== rocprof"
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 find $OUT/prof -name "*kernel_stats*" | head -3
 for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -12 $f | cut -c1-200; cp $f $OUT/kernel_stats.csv; done
 # keep the merge-back small

@@ -26,9 +26,24 @@
 //            same XCD so that their loads of grad_out / loc and their partial-line stores of
 //            grad_loc / grad_aw meet in one L2.
 //
-// LDS layout: pixel p of the window holds 32 floats; channel c sits at ((c + (p & 7)) & 31) so
-// that the 32 lanes of a half-wave (8 quads = 8 neighbouring pixels, 4 lanes x stride-8 channels)
-// hit 32 different banks in one ds_add_f32.
+//   bands  = a box taller than the LDS capacity is processed in row bands (zero / accumulate /
+//            flush per band) from per-point scatter records kept in registers, so no sample ever
+//            falls back to scattered global atomics unless the box is wider than the capacity.
+//
+// LDS cells are 64-bit FIXED POINT, not float: measured on MI355X (tools/ubench/lds_atomics.hip)
+// ds_add_f32 retires 0.38 lane-updates/clk/CU (it is ~36x slower than ds_add_u32 at 13.8;
+// ds_add_f64 3.4, ds_add_u64 5.7-6.2), so float LDS atomics made this kernel SLOWER than global
+// atomics (9.3 ms).  Each block scales its contributions by a power of two chosen from the
+// largest |grad_out| it holds so that one contribution is a 31-bit integer (relative resolution
+// 2^-30 of that maximum: finer than the float32 atomics of the reference) and adds it, sign
+// extended, into a 64-bit cell (room for 2^33 contributions).  Integer addition is associative,
+// so a window's sum does not depend on the order the lanes arrive in.
+//
+// LDS layout: pixel p of the window holds 32 cells; channel c sits at ((c + 4 * (p & 7)) & 31).
+// A scatter instruction adds channel 4k + sub for every lane, so the lanes of a 16-lane group
+// (4 quads = 4 neighbouring pixels x 4 lanes x 2 banks per cell) hit 32 different banks.
+#include <cstdlib>
+
 #include "msda_device.h"
 #include "msda_internal.h"
 
@@ -39,7 +54,7 @@ namespace {
 constexpr int kL = 4, kP = 4, kD = 32;
 constexpr int kTile = 16;                       // 16 x 16 queries per block
 constexpr int kThreads = kTile * kTile * 4;     // 1024: one quad per query
-constexpr int kWinCap = 640;                    // window capacity in pixels (x 128 B = 80 KB)
+constexpr int kWinCap = 318;                    // window capacity in pixels (x 256 B): 2 blocks fit in 160 KB
 constexpr int kXcds = 8;
 
 struct TileInfo {
@@ -49,16 +64,15 @@ struct TileInfo {
 // number of 16x16 tiles of a level
 __host__ __device__ inline int tiles_of(int H, int W) { return ((H + kTile - 1) / kTile) * ((W + kTile - 1) / kTile); }
 
-__device__ __forceinline__ int lds_slot(int p, int c) { return p * kD + ((c + (p & 7)) & 31); }
 
 template <typename VT>
 __global__ __launch_bounds__(kThreads) void window_backward_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ aw, const VT *__restrict__ grad_out, int N, int S,
-    int M, float *__restrict__ g_value, float *__restrict__ g_loc, float *__restrict__ g_aw)
+    int M, float *__restrict__ g_value, float *__restrict__ g_loc, float *__restrict__ g_aw, int dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) float win[];   // kWinCap * 32 floats + 4 ints
-    int *box = reinterpret_cast<int *>(win + kWinCap * kD);      // {min_y, min_x, max_y, max_x}
+    extern __shared__ __attribute__((aligned(16))) long long win[];   // kWinCap * 32 cells + 8 ints
+    int *box = reinterpret_cast<int *>(win + kWinCap * kD);          // {min_y, min_x, max_y, max_x, max|g| bits}
 
     // The pyramid shape lives on the device (as in the reference), so the grid cannot be sized
     // from it on the host: the launch is persistent -- a fixed number of blocks walks the items.
@@ -114,107 +128,148 @@ __global__ __launch_bounds__(kThreads) void window_backward_kernel(
     float tg[8];
     Vec8<VT>::load(grad_out + qm * kD + sub * 8, tg);
 
-    // ---- pass 1: bounding box of the touched corners ----------------------------------------------
-    if (tid < 4) box[tid] = tid < 2 ? 0x7fffffff : -1;
-    __syncthreads();
-    {
-        const float h_im = fmaf(xy.y, (float)H, -0.5f), w_im = fmaf(xy.x, (float)W, -0.5f);
-        const bool inside = live && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
-        const int h0 = (int)floorf(inside ? h_im : 0.f), w0 = (int)floorf(inside ? w_im : 0.f);
-        int y_lo = inside ? max(h0, 0) : 0x7fffffff, x_lo = inside ? max(w0, 0) : 0x7fffffff;
-        int y_hi = inside ? min(h0 + 1, H - 1) : -1, x_hi = inside ? min(w0 + 1, W - 1) : -1;
+    // grad_out a second time, channel-interleaved (channel 4k + sub): the scatter instructions then
+    // cover 16 contiguous bytes per quad (LDS: conflict-free banks; global fallback: 4x fewer
+    // 32-byte sectors per atomic instruction than an 8-channels-per-lane stride)
+    float tgi[8];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            y_lo = min(y_lo, __shfl_xor(y_lo, off, 64)); x_lo = min(x_lo, __shfl_xor(x_lo, off, 64));
-            y_hi = max(y_hi, __shfl_xor(y_hi, off, 64)); x_hi = max(x_hi, __shfl_xor(x_hi, off, 64));
-        }
-        if ((tid & 63) == 0) {
-            atomicMin(&box[0], y_lo); atomicMin(&box[1], x_lo);
-            atomicMax(&box[2], y_hi); atomicMax(&box[3], x_hi);
-        }
-    }
-    __syncthreads();
-    const int wy0 = box[0], wx0 = box[1];
-    int wh = box[2] - wy0 + 1, ww = box[3] - wx0 + 1;
-    if (box[2] < 0) { wh = 0; ww = 0; }                      // no sample of this block is inside the level
-    if (ww > kWinCap) ww = kWinCap;
-    if (wh * ww > kWinCap) wh = kWinCap / ww;                // clip rows; the rest uses global atomics
-    const int npix = wh * ww;
+    for (int k = 0; k < 8; ++k) tgi[k] = Elem<float, VT>::ld(grad_out + qm * kD + 4 * k + sub);
+    float gmax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gmax = fmaxf(gmax, live ? fabsf(tgi[k]) : 0.f);
 
-    // ---- zero the window ---------------------------------------------------------------------------
-    for (int i = tid; i < npix * (kD / 4); i += kThreads)
-        reinterpret_cast<float4 *>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    // ---- pass 2: the four points of this level --------------------------------------------------------
+    // ---- pass 1: geometry, value gathers, channel reductions; remember what to scatter --------------
     const int row = M * kD;
+    int ys0[kP], xs0[kP];          // top-left corner (clamped) of each point; other corner = +1 (clamped)
+    int ys1[kP], xs1[kP];
+    float cw[kP][4];               // scatter weight per corner, 0 when the corner does not exist
     float my_ga = 0.f, my_gx = 0.f, my_gy = 0.f;
+    int y_lo = 0x7fffffff, x_lo = 0x7fffffff, y_hi = -1, x_hi = -1;
 
-    auto one_point = [&](float x, float y, float w, float &g_a, float &g_w, float &g_h) {
-        const float h_im = fmaf(y, (float)H, -0.5f), w_im = fmaf(x, (float)W, -0.5f);
-        const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
-        const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;
-        const float hf = floorf(hs), wf = floorf(ws);
-        const int h_low = (int)hf, w_low = (int)wf;
-        const float lh = hs - hf, lw = ws - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool hl = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl = w_low >= 0, wh_ok = w_low + 1 <= W - 1;
-        const bool ok[4] = {inside && hl && wl, inside && hl && wh_ok, inside && hh_ok && wl, inside && hh_ok && wh_ok};
-        const float wgt = inside ? w : 0.f;
-        const int ys[2] = {max(h_low, 0), min(h_low + 1, H - 1)};
-        const int xs[2] = {max(w_low, 0), min(w_low + 1, W - 1)};
-        const float cw[4] = {hh * hw * wgt, hh * lw * wgt, lh * hw * wgt, lh * lw * wgt};
-        float e[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int yy = ys[k >> 1], xx = xs[k & 1];
-            const int off = (start + yy * W + xx) * row + head_chan;
-            float v[8];
-            Vec8<VT>::load(vimg + off, v);
-            float d = v[0] * tg[0];
-#pragma unroll
-            for (int c = 1; c < 8; ++c) d = fmaf(v[c], tg[c], d);
-            e[k] = quad_sum(ok[k] ? d : 0.f);
-            if (ok[k] && live) {
-                const int py = yy - wy0, px = xx - wx0;
-                if ((unsigned)py < (unsigned)wh && (unsigned)px < (unsigned)ww) {
-                    const int p = py * ww + px;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) atomicAdd(&win[lds_slot(p, sub * 8 + c)], cw[k] * tg[c]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) atomic_add(gimg + off + c, cw[k] * tg[c]);
-                }
-            }
-        }
-        g_a = hh * (hw * e[0] + lw * e[1]) + lh * (hw * e[2] + lw * e[3]);
-        g_w = (float)W * wgt * (hh * (e[1] - e[0]) + lh * (e[3] - e[2]));
-        g_h = (float)H * wgt * (hw * (e[2] - e[0]) + lw * (e[3] - e[1]));
-    };
-
-    {
-        float a, gw, gh;
-        one_point(quad_bcast<0>(xy.x), quad_bcast<0>(xy.y), quad_bcast<0>(wgt_in), a, gw, gh);
-        if (sub == 0) { my_ga = a; my_gx = gw; my_gy = gh; }
-        one_point(quad_bcast<1>(xy.x), quad_bcast<1>(xy.y), quad_bcast<1>(wgt_in), a, gw, gh);
-        if (sub == 1) { my_ga = a; my_gx = gw; my_gy = gh; }
-        one_point(quad_bcast<2>(xy.x), quad_bcast<2>(xy.y), quad_bcast<2>(wgt_in), a, gw, gh);
-        if (sub == 2) { my_ga = a; my_gx = gw; my_gy = gh; }
-        one_point(quad_bcast<3>(xy.x), quad_bcast<3>(xy.y), quad_bcast<3>(wgt_in), a, gw, gh);
-        if (sub == 3) { my_ga = a; my_gx = gw; my_gy = gh; }
+    // (compile-time point index: runtime-indexed register arrays would be demoted to scratch)
+#define MSDA_WIN_POINT(PT)                                                                                     \
+    {                                                                                                          \
+        const float x = quad_bcast<PT>(xy.x), y = quad_bcast<PT>(xy.y), w = quad_bcast<PT>(wgt_in);            \
+        const float h_im = fmaf(y, (float)H, -0.5f), w_im = fmaf(x, (float)W, -0.5f);                          \
+        const bool inside = live && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);  \
+        const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;                                        \
+        const float hf = floorf(hs), wf = floorf(ws);                                                          \
+        const int h_low = (int)hf, w_low = (int)wf;                                                            \
+        const float lh = hs - hf, lw = ws - wf, hh = 1.f - lh, hw = 1.f - lw;                                  \
+        const bool hl = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl = w_low >= 0, wh_ok = w_low + 1 <= W - 1;   \
+        const bool ok[4] = {inside && hl && wl, inside && hl && wh_ok, inside && hh_ok && wl,                  \
+                            inside && hh_ok && wh_ok};                                                         \
+        const float wgt = inside ? w : 0.f;                                                                    \
+        ys0[PT] = max(h_low, 0); ys1[PT] = min(h_low + 1, H - 1);                                              \
+        xs0[PT] = max(w_low, 0); xs1[PT] = min(w_low + 1, W - 1);                                              \
+        const float bw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};                                              \
+        float e[4];                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                        \
+            const int yy = (k >> 1) ? ys1[PT] : ys0[PT], xx = (k & 1) ? xs1[PT] : xs0[PT];                     \
+            float v[8];                                                                                        \
+            Vec8<VT>::load(vimg + ((dbg & 4) ? 0 : (start + yy * W + xx) * row) + head_chan, v);               \
+            float d = v[0] * tg[0];                                                                            \
+            _Pragma("unroll") for (int c = 1; c < 8; ++c) d = fmaf(v[c], tg[c], d);                            \
+            e[k] = quad_sum(ok[k] ? d : 0.f);                                                                  \
+            cw[PT][k] = ok[k] ? bw[k] * wgt : 0.f;                                                             \
+        }                                                                                                      \
+        if (inside) {                                                                                          \
+            y_lo = min(y_lo, ys0[PT]); y_hi = max(y_hi, ys1[PT]);                                              \
+            x_lo = min(x_lo, xs0[PT]); x_hi = max(x_hi, xs1[PT]);                                              \
+        }                                                                                                      \
+        const float g_a = hh * (hw * e[0] + lw * e[1]) + lh * (hw * e[2] + lw * e[3]);                         \
+        const float g_w = (float)W * wgt * (hh * (e[1] - e[0]) + lh * (e[3] - e[2]));                          \
+        const float g_h = (float)H * wgt * (hw * (e[2] - e[0]) + lw * (e[3] - e[1]));                          \
+        if (sub == PT) { my_ga = g_a; my_gx = g_w; my_gy = g_h; }                                              \
+        __builtin_amdgcn_sched_barrier(0); /* keep the next point's gathers from being hoisted (spills) */     \
     }
+    MSDA_WIN_POINT(0)
+    MSDA_WIN_POINT(1)
+    MSDA_WIN_POINT(2)
+    MSDA_WIN_POINT(3)
+#undef MSDA_WIN_POINT
     if (live) {
         reinterpret_cast<float2 *>(g_loc)[sidx] = make_float2(my_gx, my_gy);
         g_aw[sidx] = my_ga;
     }
-    __syncthreads();
 
-    // ---- flush the window: one lane per (pixel, channel), 128 contiguous bytes per pixel ----------------
-    const int c = tid & 31;
-    for (int p = tid >> 5; p < npix; p += kThreads / 32) {
-        const float v = win[lds_slot(p, c)];
-        if (v != 0.f) {
-            const int py = p / ww, px = p - py * ww;
-            atomic_add(gimg + (long)(start + (wy0 + py) * W + wx0 + px) * row + m * kD + c, v);
+    // ---- bounding box of the block's scatter targets -----------------------------------------------
+    if (tid < 5) box[tid] = tid < 2 ? 0x7fffffff : (tid < 4 ? -1 : 0);
+    __syncthreads();
+    int gbits = __float_as_int(gmax);       // non-negative floats order like their bit patterns
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        y_lo = min(y_lo, __shfl_xor(y_lo, off, 64)); x_lo = min(x_lo, __shfl_xor(x_lo, off, 64));
+        y_hi = max(y_hi, __shfl_xor(y_hi, off, 64)); x_hi = max(x_hi, __shfl_xor(x_hi, off, 64));
+        gbits = max(gbits, __shfl_xor(gbits, off, 64));
+    }
+    if ((tid & 63) == 0) {
+        if (y_hi >= 0) {
+            atomicMin(&box[0], y_lo); atomicMin(&box[1], x_lo);
+            atomicMax(&box[2], y_hi); atomicMax(&box[3], x_hi);
+        }
+        atomicMax(&box[4], gbits);
+    }
+    __syncthreads();
+    // fixed-point scale 2^fx: the block's largest |grad_out| (times a weight <= 1) stays below 2^30.
+    // NaN / Inf gradients cannot be represented: such a block scatters with float global atomics.
+    const int gexp = (box[4] >> 23) & 0xff;                   // biased exponent of the maximum
+    const bool fixed_ok = gexp != 0xff;
+    const int fx = 29 - (gexp - 127);
+    float tgs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tgs[k] = ldexpf(tgi[k], fx);
+    const int by0 = box[0], wx0 = box[1], by1 = box[2];
+    const int ww = min(box[3] - wx0 + 1, kWinCap);          // columns beyond the cap: global atomics
+    const int band = by1 >= 0 ? kWinCap / ww : 0;            // rows of the box one LDS window holds
+
+    // ---- pass 2: the box in row bands -- zero, accumulate with LDS atomics, flush ---------------------
+    if (!(dbg & 8))
+    for (int wy0 = by0; wy0 <= by1; wy0 += band) {
+        const int wh = min(band, by1 - wy0 + 1);
+        const int npix = wh * ww;
+        __syncthreads();                                   // previous band's flush is done
+        for (int i = tid; i < npix * (kD / 2); i += kThreads)
+            reinterpret_cast<uint4 *>(win)[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+#pragma unroll
+        for (int pt = 0; pt < kP; ++pt) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float wk = cw[pt][k];
+                // opaque to the optimiser: otherwise the 128 products wk * tgi[c] are hoisted out of
+                // the band loop as loop invariants and spill to scratch
+                asm volatile("" : "+v"(wk));
+                const int yy = (k >> 1) ? ys1[pt] : ys0[pt], xx = (k & 1) ? xs1[pt] : xs0[pt];
+                const int py = yy - wy0, px = xx - wx0;
+                if (wk != 0.f && (unsigned)py < (unsigned)wh && !(dbg & 1)) {
+                    if (px < ww && fixed_ok) {
+                        const int p = py * ww + px;
+                        unsigned long long *dst = reinterpret_cast<unsigned long long *>(win) + p * kD;
+                        const int rot = 4 * (p & 7) + sub;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const int q31 = __float2int_rn(wk * tgs[c]);          // |.| < 2^30
+                            atomicAdd(dst + ((4 * c + rot) & 31), (unsigned long long)(long long)q31);
+                        }
+                    } else {
+                        float *dst = gimg + (long)(start + yy * W + xx) * row + m * kD + sub;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) atomic_add(dst + 4 * c, wk * tgi[c]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // flush: one lane per (pixel, channel), 128 contiguous bytes per pixel, untouched lanes skipped
+        const int c = tid & 31;
+        for (int p = tid >> 5; p < npix; p += kThreads / 32) {
+            const long long cell = win[p * kD + ((c + 4 * (p & 7)) & 31)];
+            const float v = ldexpf((float)cell, -fx);
+            if (cell != 0 && !(dbg & 2)) {
+                const int py = p / ww, px = p - py * ww;
+                atomic_add(gimg + (long)(start + (wy0 + py) * W + wx0 + px) * row + m * kD + c, v);
+            }
         }
     }
   }   // item loop
@@ -241,18 +296,21 @@ void launch_window_forward(const Problem &) {}
 void launch_window_backward(const Problem &p)
 {
     // persistent grid: 2 blocks of 1024 threads per CU (LDS- and wave-limited), 256 CUs
-    const int grid = 256 * 2;
-    const size_t lds = (size_t)kWinCap * kD * sizeof(float) + 16;
+    const char *e = getenv("RLIPV2_MSDA_DEBUG");       // ablation switches for profiling only
+    const int dbg = e ? atoi(e) : 0;
+    const char *g = getenv("RLIPV2_MSDA_GRID");
+    const int grid = g ? atoi(g) : 256 * 2;
+    const size_t lds = (size_t)kWinCap * kD * sizeof(long long) + 32;
     if (p.dtype == MSDA_F32) {
         hipLaunchKernelGGL((window_backward_kernel<float>), dim3(grid), dim3(kThreads), lds, p.stream,
                            (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                            (const float *)p.grad_out, p.N, p.S, p.M, (float *)p.g_value, (float *)p.g_loc,
-                           (float *)p.g_aw);
+                           (float *)p.g_aw, dbg);
     } else {
         hipLaunchKernelGGL((window_backward_kernel<bf16_t>), dim3(grid), dim3(kThreads), lds, p.stream,
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                            (const bf16_t *)p.grad_out, p.N, p.S, p.M, (float *)p.g_value, (float *)p.g_loc,
-                           (float *)p.g_aw);
+                           (float *)p.g_aw, dbg);
     }
 }
 

@@ -32,10 +32,11 @@ int finish_launch()
 
 int pick(bool backward, const Problem &p)
 {
-    if (window_supports(p, backward) && p.S >= 1024) return MSDA_VARIANT_WINDOW;   // enough tiles to matter
-    // backward without a window: the quad kernel's strided 4-byte global atomics touch 8x more
-    // 32-byte sectors than the generic kernel's 128-byte rows (measured 34 ms vs 4.6 ms at the
-    // encoder shape, 526 us vs 91 us at Lq = 300), so the generic kernel is the better scatter.
+    // backward, model head shape: reduce kernel + sorted scatter kernel (msda_window.hip).  The quad
+    // kernel's own scatter (strided 4-byte global atomics, 64 sectors per instruction) measured
+    // 34 ms at the encoder shape against 4.6 ms for the generic kernel's 128-byte rows and 1.1 ms
+    // for the sorted scatter, so it is never picked automatically.
+    if (window_supports(p, backward)) return MSDA_VARIANT_WINDOW;
     if (!backward && quad_supports(p)) return MSDA_VARIANT_QUAD;
     return MSDA_VARIANT_GENERIC;
 }

@@ -148,7 +148,7 @@ __device__ __forceinline__ void scatter8(float *__restrict__ g, float w, const f
 
 // One sample of the backward pass.  Returns (d out / d attn_weight, d out / d x, d out / d y)
 // contracted with grad_out, identical in all four lanes of the quad.
-template <typename VT>
+template <typename VT, bool SCATTER>
 __device__ __forceinline__ void bwd_sample(const VT *__restrict__ vimg, float *__restrict__ gimg, float x, float y,
                                            float w, int H, int W, int start, int M, int head_chan, bool live,
                                            const float (&tg)[8], float &g_a, float &g_w, float &g_h)
@@ -161,7 +161,7 @@ __device__ __forceinline__ void bwd_sample(const VT *__restrict__ vimg, float *_
     Vec8<VT>::load(vimg + c.o4, v4);
     // grad_value: w_k * attn * grad_out, 8 channels per corner per lane
     const float a_h = c.hh * c.wgt, b_h = c.lh * c.wgt;
-    if (live) {
+    if (SCATTER && live) {
         if (c.ok1) scatter8(gimg + c.o1, a_h * c.hw, tg);
         if (c.ok2) scatter8(gimg + c.o2, a_h * c.lw, tg);
         if (c.ok3) scatter8(gimg + c.o3, b_h * c.hw, tg);
@@ -177,7 +177,9 @@ __device__ __forceinline__ void bwd_sample(const VT *__restrict__ vimg, float *_
     g_h = (float)H * c.wgt * (c.hw * (e3 - e1) + c.lw * (e4 - e2));
 }
 
-template <typename VT, int WAVES>
+// SCATTER = false: only grad_sampling_loc / grad_attn_weight ("K1"; grad_value is then produced by
+// the sorted scatter of msda_window.hip).
+template <typename VT, int WAVES, bool SCATTER>
 __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ aw, const VT *__restrict__ grad_out, int total_qm,
@@ -204,16 +206,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_kernel(
     for (int l = 0; l < kL; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
         float4 ra, rb, rw;   // this level's results: (gx,gy) x 4 points, g_aw x 4 points
-        bwd_sample<VT>(vimg, gimg, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start, M,
+        bwd_sample<VT, SCATTER>(vimg, gimg, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start, M,
                        head_chan, live, tg, rw.x, ra.x, ra.y);
         __builtin_amdgcn_sched_barrier(0);
-        bwd_sample<VT>(vimg, gimg, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start, M,
+        bwd_sample<VT, SCATTER>(vimg, gimg, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start, M,
                        head_chan, live, tg, rw.y, ra.z, ra.w);
         __builtin_amdgcn_sched_barrier(0);
-        bwd_sample<VT>(vimg, gimg, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, M,
+        bwd_sample<VT, SCATTER>(vimg, gimg, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, M,
                        head_chan, live, tg, rw.z, rb.x, rb.y);
         __builtin_amdgcn_sched_barrier(0);
-        bwd_sample<VT>(vimg, gimg, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, M,
+        bwd_sample<VT, SCATTER>(vimg, gimg, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, M,
                        head_chan, live, tg, rw.w, rb.z, rb.w);
         if (sub == l) { gla = ra; glb = rb; ga = rw; }   // quad lane l owns level l's outputs
         quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
@@ -257,12 +259,28 @@ void launch_quad_backward(const Problem &p)
     const int total_qm = p.N * p.Lq * p.M;
     const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
     if (p.dtype == MSDA_F32)
-        hipLaunchKernelGGL((quad_backward_kernel<float, 3>), dim3(grid), dim3(kBlock), 0, p.stream,
+        hipLaunchKernelGGL((quad_backward_kernel<float, 3, true>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                            (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, (float *)p.g_value,
                            (float *)p.g_loc, (float *)p.g_aw);
     else
-        hipLaunchKernelGGL((quad_backward_kernel<bf16_t, 4>), dim3(grid), dim3(kBlock), 0, p.stream,
+        hipLaunchKernelGGL((quad_backward_kernel<bf16_t, 4, true>), dim3(grid), dim3(kBlock), 0, p.stream,
+                           (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
+                           (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, (float *)p.g_value,
+                           (float *)p.g_loc, (float *)p.g_aw);
+}
+
+void launch_quad_backward_reduce(const Problem &p)
+{
+    const int total_qm = p.N * p.Lq * p.M;
+    const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
+    if (p.dtype == MSDA_F32)
+        hipLaunchKernelGGL((quad_backward_kernel<float, 4, false>), dim3(grid), dim3(kBlock), 0, p.stream,
+                           (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
+                           (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, (float *)p.g_value,
+                           (float *)p.g_loc, (float *)p.g_aw);
+    else
+        hipLaunchKernelGGL((quad_backward_kernel<bf16_t, 4, false>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                            (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, (float *)p.g_value,
                            (float *)p.g_loc, (float *)p.g_aw);

@@ -73,8 +73,8 @@ def variants_for(D, L, P, tdtype, S=0, Lq=-1):
     v = [("generic", "generic")]
     if D == 32 and L == 4 and P == 4 and tdtype != torch.float64:
         v.append(("quad", "quad"))
-        if S == Lq and S > 0:      # encoder-like call: queries are the pyramid's pixels
-            v.append(("window" if WINDOW_FWD else "quad", "window" if WINDOW_BWD else "quad"))
+        # "window" backward = reduce kernel + sorted scatter kernel; valid for any Lq
+        v.append(("window" if WINDOW_FWD else "quad", "window" if WINDOW_BWD else "quad"))
     v.append(("auto", "auto"))
     return v
 

@@ -1,0 +1,120 @@
+"""DAB deformable decoders of RLIPv2-ParSeDA (human-object pair decoder and verb decoder).
+
+Reference: DeformableTransformerDecoderLayer (models/dab_deformable/deformable_transformer.py:1346-1401)
+and DABDeformableTransformerDecoderHOI (:1404-1552).  Parameter names match the reference.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .blocks import MLP, inverse_sigmoid, sine_embed_for_position
+from .deform_attn import MSDeformAttn
+from .encoder import _activation, _clones
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    """self-attention over the queries (+LN) -> deformable cross-attention into the image memory
+    (+LN) -> FFN (+LN), post-norm."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4,
+                 do_self_attn=True):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.do_self_attn = do_self_attn
+        if do_self_attn:
+            self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+            self.dropout2 = nn.Dropout(dropout)
+            self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                src_padding_mask=None):
+        if self.do_self_attn:
+            qk = (tgt if query_pos is None else tgt + query_pos).transpose(0, 1)
+            sa = self.self_attn(qk, qk, tgt.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
+            tgt = self.norm2(tgt + self.dropout2(sa))
+        ca = self.cross_attn(tgt if query_pos is None else tgt + query_pos, reference_points, src,
+                             src_spatial_shapes, level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(ca))
+        ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(ffn))
+
+
+class DABDeformableTransformerDecoderHOI(nn.Module):
+    """ParSe=True : queries are [subjects | objects]; each half refines its own anchor boxes.
+    ParSe=False: verb queries; the cross-attention reference is the mean of the (sub, obj) boxes.
+    Refined boxes are detached between layers (reference :1525, :1541)."""
+
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False, use_dab=False, d_model=256,
+                 high_dim_query_update=False, no_sine_embed=False, ParSe=False):
+        super().__init__()
+        self.layers = _clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.sub_bbox_embed = None          # set by the model (aliases of its box heads)
+        self.obj_bbox_embed = None
+        self.class_embed = None
+        self.use_dab = use_dab
+        self.d_model = d_model
+        self.no_sine_embed = no_sine_embed
+        if use_dab:
+            self.query_scale = MLP(d_model, d_model, d_model, 2)
+            self.ref_point_head = MLP(4, d_model, d_model, 3) if no_sine_embed else MLP(2 * d_model, d_model, d_model, 2)
+        self.high_dim_query_update = high_dim_query_update
+        if high_dim_query_update:
+            self.high_dim_query_proj = MLP(d_model, d_model, d_model, 2)
+        self.ParSe = ParSe
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
+                query_pos=None, src_padding_mask=None):
+        output = tgt
+        if self.use_dab:
+            assert query_pos is None
+        bs = src.shape[0]
+        sub_ref, obj_ref = reference_points
+        if self.ParSe:
+            sub_ref = sub_ref[None].repeat(bs, 1, 1)
+            obj_ref = obj_ref[None].repeat(bs, 1, 1)
+        assert sub_ref.shape[-1] == 4 and obj_ref.shape[-1] == 4
+        n_pair = obj_ref.shape[1]
+        ratios4 = torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]          # [N,1,L,4]
+
+        inter, inter_sub, inter_obj = [], [], []
+        for lid, layer in enumerate(self.layers):
+            if self.ParSe:
+                ref_in = torch.cat((sub_ref[:, :, None] * ratios4, obj_ref[:, :, None] * ratios4), dim=1)
+            else:
+                ref_in = 0.5 * (sub_ref + obj_ref)[:, :, None] * ratios4
+            if self.use_dab:
+                raw = self.ref_point_head(ref_in) if self.no_sine_embed else \
+                    self.ref_point_head(sine_embed_for_position(ref_in[:, :, 0, :]))
+                query_pos = raw if lid == 0 else self.query_scale(output) * raw
+            if self.high_dim_query_update and lid != 0:
+                query_pos = query_pos + self.high_dim_query_proj(output)
+
+            output = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
+                           src_padding_mask)
+
+            if self.sub_bbox_embed is not None:
+                h = output[:, :n_pair] if self.ParSe else output
+                sub_ref = (self.sub_bbox_embed[lid](h) + inverse_sigmoid(sub_ref)).sigmoid().detach()
+            if self.obj_bbox_embed is not None:
+                h = output[:, n_pair:] if self.ParSe else output
+                obj_ref = (self.obj_bbox_embed[lid](h) + inverse_sigmoid(obj_ref)).sigmoid().detach()
+            if self.return_intermediate:
+                inter.append(output)
+                inter_sub.append(sub_ref)
+                inter_obj.append(obj_ref)
+
+        if self.return_intermediate:
+            refs = torch.stack((torch.stack(inter_sub), torch.stack(inter_obj)), dim=0).transpose(0, 1)
+            return torch.stack(inter), refs
+        return output, reference_points

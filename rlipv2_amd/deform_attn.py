@@ -1,0 +1,110 @@
+"""MSDeformAttn module (boundary B2): same constructor, forward signature, parameter names and
+initialisation as the reference (models/ops/modules/ms_deform_attn.py:34-119 and its twin under
+models/dab_deformable/ops/modules/), with the sampling + aggregation done by the HIP kernels
+behind ``MSDeformAttnFunction``.
+
+Host-side differences (results identical): the two query projections (`sampling_offsets`,
+`attention_weights`) are issued as one GEMM over the concatenated weights, and the padding-mask
+fill is applied to the projected value without an extra copy.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from . import msda
+
+# the autograd op; a module attribute so that CPU unit tests can substitute a checker
+msda_function = msda.MSDeformAttnFunction
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError('d_model must be divisible by n_heads, but got {} and {}'.format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a head dimension that is not a power of 2 runs on the generic kernel; "
+                          "the gfx950 fast paths are specialised for 32 channels per head.")
+        self.im2col_step = 64
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # reference ms_deform_attn.py:66-80: zero offset weights, bias = per-head compass direction
+        # scaled by the point index; uniform attention; xavier value / output projections
+        constant_(self.sampling_offsets.weight.data, 0.)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2)
+        grid = grid.repeat(1, self.n_levels, self.n_points, 1)
+        grid = grid * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, -1, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.reshape(-1))
+        constant_(self.attention_weights.weight.data, 0.)
+        constant_(self.attention_weights.bias.data, 0.)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """query [N, Lq, C]; reference_points [N, Lq, L, 2|4] in [0, 1]; input_flatten [N, S, C];
+        input_spatial_shapes int64 [L, 2]; input_level_start_index int64 [L]; input_padding_mask
+        [N, S] (True = padding).  Returns [N, Lq, C]."""
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        # (the reference asserts sum(H*W) == Len_in on the device, a host sync per call
+        #  (ms_deform_attn.py:96); the HIP library validates shapes without one)
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.view(N, Len_in, M, self.d_model // M)
+
+        n_off = M * L * P * 2
+        qproj = F.linear(query,
+                         torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
+                         torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+        offsets = qproj[..., :n_off].reshape(N, Len_q, M, L, P, 2)
+        logits = qproj[..., n_off:].reshape(N, Len_q, M, L * P)
+        if logits.dtype in (torch.bfloat16, torch.float16):
+            logits = logits.float()                    # softmax and sampling geometry stay in float32
+        weights = F.softmax(logits, -1).view(N, Len_q, M, L, P)
+
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, None, :] \
+                + offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            locations = reference_points[:, :, None, :, None, :2] \
+                + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(
+                'Last dim of reference_points must be 2 or 4, but get {} instead.'.format(reference_points.shape[-1]))
+        if value.dtype == torch.bfloat16:
+            locations = locations.float()
+        output = msda_function.apply(value, input_spatial_shapes, input_level_start_index,
+                                     locations.contiguous(), weights.contiguous(), self.im2col_step)
+        return self.output_proj(output)

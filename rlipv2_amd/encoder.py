@@ -1,0 +1,117 @@
+"""The ALIF-fused deformable encoder of RLIPv2.
+
+Reference: DeformableTransformerEncoderLayer (models/dab_deformable/deformable_transformer.py:1261-1300,
+twin models/deformable_transformer.py:719-758) and RLIPv2_DeformableTransformerEncoder
+(models/deformable_transformer.py:791-884).  Parameter names match the reference.
+"""
+from __future__ import annotations
+
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .deform_attn import MSDeformAttn
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def _activation(name):
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return F.gelu
+    if name == "glu":
+        return F.glu
+    raise RuntimeError(f"activation should be relu/gelu, not {name}.")
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    """Post-norm block: MSDeformAttn(src + pos) -> +res -> LN -> FFN -> +res -> LN."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _activation(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        q = src if pos is None else src + pos
+        src = self.norm1(src + self.dropout1(
+            self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)))
+        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(ffn))
+
+
+def encoder_reference_points(spatial_shapes_list, valid_ratios, device):
+    """Pixel-centre reference points of every pyramid cell, per level scaled by the valid ratios:
+    [N, S, L, 2] (reference: models/deformable_transformer.py:803-815).  `spatial_shapes_list` is
+    the host copy [(H, W), ...] so no device->host sync is needed."""
+    refs = []
+    for lvl, (H, W) in enumerate(spatial_shapes_list):
+        ys = torch.linspace(0.5, H - 0.5, H, dtype=torch.float32, device=device)
+        xs = torch.linspace(0.5, W - 0.5, W, dtype=torch.float32, device=device)
+        ref_y, ref_x = torch.meshgrid(ys, xs, indexing="ij")
+        ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H)
+        ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W)
+        refs.append(torch.stack((ref_x, ref_y), -1))
+    ref = torch.cat(refs, 1)
+    return ref[:, :, None] * valid_ratios[:, None]
+
+
+class RLIPv2_DeformableTransformerEncoder(nn.Module):
+    """Every `fusion_interval`-th layer is preceded by an ALIF fusion (on the last pyramid level
+    only when `fusion_last_vis`) and a language layer on the fused text states."""
+
+    def __init__(self, encoder_layer, roberta_layer, VLFuse_layer, num_layers, fusion_interval=2,
+                 fusion_last_vis=False, lang_aux_loss=False):
+        super().__init__()
+        self.layers = _clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.fusion_interval = fusion_interval
+        self.roberta_layers = _clones(roberta_layer, num_layers // fusion_interval)
+        self.VLFuse_layers = _clones(VLFuse_layer, num_layers // fusion_interval)
+        self.fusion_last_vis = fusion_last_vis
+        self.lang_aux_loss = lang_aux_loss
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
+                lang_hidden=None, lang_masks=None, spatial_shapes_list=None):
+        if spatial_shapes_list is None:                      # reference behaviour: read them back
+            spatial_shapes_list = [(int(h), int(w)) for h, w in spatial_shapes.tolist()]
+        last_start = sum(h * w for h, w in spatial_shapes_list[:-1])
+        reference_points = encoder_reference_points(spatial_shapes_list, valid_ratios, src.device)
+        # the fusion is handed inverted (True = valid) bool masks; see alif.py Q1 for what they do
+        vis_mask = ~padding_mask
+        lang_mask = ~lang_masks
+        if self.fusion_last_vis:
+            vis_mask, vis_pos = vis_mask[:, last_start:], pos[:, last_start:]
+        else:
+            vis_pos = pos
+        output, hidden = src, lang_hidden
+        collected = []
+        for idx, layer in enumerate(self.layers):
+            if idx % self.fusion_interval == 0:
+                k = idx // self.fusion_interval
+                part = output[:, last_start:] if self.fusion_last_vis else output
+                fused = self.VLFuse_layers[k]({"visual": {"src": part, "padding_mask": vis_mask, "pos": vis_pos},
+                                               "lang": {"hidden": hidden, "masks": lang_mask}})
+                part, hidden = fused["visual"]["src"], fused["lang"]["hidden"]
+                # Q4: the fused last-level slice replaces that slice of the full sequence
+                output = torch.cat([output[:, :last_start], part], 1) if self.fusion_last_vis else part
+                hidden = self.roberta_layers[k](hidden_states=hidden, attention_mask=lang_mask)
+                collected.append(hidden)
+            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+        if self.lang_aux_loss:
+            lang = torch.stack(collected if self.fusion_interval == 2 else collected[::2], dim=0)
+        else:
+            lang = collected[-1]
+        return output, lang

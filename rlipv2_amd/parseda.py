@@ -1,0 +1,356 @@
+"""RLIPv2-ParSeDA: the two-phase transformer and the top-level model.
+
+Reference: RLIP_ParSeDABDeformableTransformer_v2 (models/dab_deformable/deformable_transformer.py:234-744)
+and RLIP_ParSeDA (models/hoi.py:1871-2256).  Constructor arguments, the two-phase
+``model(samples, encode_and_save=True, text=...) -> memory_cache`` /
+``model(samples, encode_and_save=False, memory_cache=...) -> outputs`` protocol (engine.py:99-100),
+output keys and state_dict names follow the reference.
+
+Text: the reference tokenises label strings on the CPU and runs RoBERTa-base every step
+(deformable_transformer.py:486-522).  Here ``text`` may be
+  * the pre-encoded tuple the reference's evaluation path uses,
+    ``(text_attention_mask [n_text, N] bool, text_memory [n_text, N, 768], obj_pred_names_sums [[n_obj, n_verb]])``
+    (deformable_transformer.py:569-595), or
+  * ``{"input_ids": [n_text, T], "attention_mask": [n_text, T], "obj_pred_names_sums": [[n_obj, n_verb]]}``
+    -- token ids for ``self.text_encoder`` (any module returning an object with `.pooler_output`);
+    one embedding per label, shared by the whole batch (Q12), masked by the sign of its feature sum (Q2).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import normal_
+
+from .alif import RLIPv2_VLFuse, RobertaLayer
+from .blocks import (MLP, FeatureResizer, MultiBranchFusion, NestedTensor, inverse_sigmoid,
+                     nested_tensor_from_tensor_list)
+from .decoder import DABDeformableTransformerDecoderHOI, DeformableTransformerDecoderLayer
+from .deform_attn import MSDeformAttn
+from .encoder import DeformableTransformerEncoderLayer, RLIPv2_DeformableTransformerEncoder, _clones
+
+
+def default_args(**overrides):
+    """The flags of scripts/RLIP_ParSeDA/train_RLIP_ParSeDA_v2_mixed_vgcoco_resnet.sh that reach the model."""
+    a = SimpleNamespace(
+        hidden_dim=256, nheads=8, enc_layers=6, dec_layers=3, dim_feedforward=2048, dropout=0.0,
+        num_feature_levels=4, enc_n_points=4, dec_n_points=4, num_queries=200, with_box_refine=True,
+        subject_class=True, fusion_type="GLIP_attn", gating_mechanism="VXAc", verb_query_tgt_type="vanilla_MBF",
+        fusion_interval=2, fusion_last_vis=True, lang_aux_loss=True, pseudo_verb=True, use_dab=True,
+        text_encoder_type="roberta-base", freeze_text_encoder=False, use_checkpoint_fusion=False,
+        stable_softmax_2d=False, clamp_min_for_underflow=False, clamp_max_for_overflow=False,
+        separate_bidirectional=False, do_lang_proj_outside_checkpoint=False, aux_loss=True)
+    for k, v in overrides.items():
+        setattr(a, k, v)
+    return a
+
+
+class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
+                 dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4,
+                 dec_n_points=4, enc_n_points=4, two_stage=False, two_stage_num_proposals=300, use_dab=False,
+                 high_dim_query_update=False, no_sine_embed=False, pass_pos_and_query=True,
+                 text_encoder_type="roberta-base", freeze_text_encoder=False, args=None, text_encoder=None):
+        super().__init__()
+        assert not two_stage, "two-stage proposals are not part of the RLIPv2 ParSeDA path"
+        assert use_dab, "RLIP_ParSeDA uses dynamic anchor boxes"
+        assert args.fusion_type == "GLIP_attn", "the ParSeDA scripts use ALIF fusion (GLIP_attn)"
+        self.d_model, self.nhead = d_model, nhead
+        self.two_stage, self.use_dab = two_stage, use_dab
+        self.fusion_type = args.fusion_type
+
+        dec_layer = DeformableTransformerDecoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, dec_n_points)
+        self.ho_decoder = DABDeformableTransformerDecoderHOI(
+            dec_layer, num_decoder_layers, return_intermediate_dec, use_dab=use_dab, d_model=d_model,
+            high_dim_query_update=high_dim_query_update, no_sine_embed=no_sine_embed, ParSe=True)
+        self.verb_decoder = DABDeformableTransformerDecoderHOI(
+            dec_layer, num_decoder_layers, return_intermediate_dec, use_dab=use_dab, d_model=d_model,
+            high_dim_query_update=high_dim_query_update, no_sine_embed=no_sine_embed, ParSe=False)
+        self.verb_tgt_generator = MultiBranchFusion(256, 256, 256, 16)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+
+        enc_layer = DeformableTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                      num_feature_levels, nhead, enc_n_points)
+        self.encoder = RLIPv2_DeformableTransformerEncoder(
+            enc_layer, RobertaLayer(), RLIPv2_VLFuse(args), num_encoder_layers,
+            fusion_interval=args.fusion_interval, fusion_last_vis=args.fusion_last_vis,
+            lang_aux_loss=args.lang_aux_loss)
+        self.high_dim_query_update = high_dim_query_update
+        self._reset_parameters()
+
+        # text encoder: supplied by the caller (RoBERTa-base shaped); hidden size 768
+        self.text_encoder = text_encoder
+        if text_encoder is not None and freeze_text_encoder:
+            for p in self.text_encoder.parameters():
+                p.requires_grad_(False)
+        self.resizer = FeatureResizer(input_feat_size=768, output_feat_size=d_model, dropout=0.1)
+        self.verb_query_tgt_type = args.verb_query_tgt_type
+        if "MBF" in self.verb_query_tgt_type:
+            self.verb_tgt_generator = MultiBranchFusion(256, 256, 256, 16)
+
+    def _reset_parameters(self):
+        # reference :364-374 -- xavier on every matrix, then the MSDeformAttn-specific init, then N(0,1) levels
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        normal_(self.level_embed)
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, H, W = mask.shape
+        valid_h = torch.sum(~mask[:, :, 0], 1).float() / H
+        valid_w = torch.sum(~mask[:, 0, :], 1).float() / W
+        return torch.stack([valid_w, valid_h], -1)
+
+    # ---- phase A ---------------------------------------------------------------------------------
+    def _encode_text(self, text, bs, device):
+        if isinstance(text, tuple):                       # pre-encoded (reference :569-571)
+            text_attention_mask, text_memory, sums = text
+            return text_attention_mask, text_memory, sums
+        ids, am = text["input_ids"].to(device), text["attention_mask"].to(device)
+        pooled = self.text_encoder(input_ids=ids, attention_mask=am).pooler_output          # [n_text, 768]
+        text_memory = pooled[:, None, :]                                                    # [n_text, 1, 768]
+        text_attention_mask = ~(text_memory.sum(dim=-1) > 0)                                # Q2
+        if text_memory.shape[1] != bs:                                                      # Q12
+            text_memory = text_memory.repeat(1, bs, 1)
+            text_attention_mask = text_attention_mask.repeat(1, bs)
+        return text_attention_mask, text_memory, text["obj_pred_names_sums"]
+
+    def forward(self, srcs=None, masks=None, pos_embeds=None, query_embed=None, text=None, encode_and_save=True,
+                text_memory=None, img_memory=None, text_attention_mask=None, obj_pred_names_sums=None,
+                spatial_shapes=None, level_start_index=None, valid_ratios=None, spatial_shapes_list=None):
+        assert query_embed is not None
+        if encode_and_save:
+            shapes_list = [tuple(s.shape[-2:]) for s in srcs]
+            bs = srcs[0].shape[0]
+            src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+            mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
+            lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
+                                 for l, p in enumerate(pos_embeds)], 1)
+            spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=src_flatten.device)
+            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+
+            text_attention_mask, text_memory, obj_pred_names_sums = self._encode_text(text, bs, src_flatten.device)
+            img_memory, lang = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, lvl_pos,
+                                            mask_flatten, lang_hidden=text_memory.transpose(0, 1),
+                                            lang_masks=text_attention_mask.transpose(0, 1),
+                                            spatial_shapes_list=shapes_list)
+            # [N, n_text, 768] or, with lang_aux_loss, [n_fusions, N, n_text, 768] -> text-major + resize
+            text_memory_resized = self.resizer(lang.transpose(0, 1) if lang.dim() == 3 else lang.transpose(1, 2))
+            return {
+                # raw label features on the token path; on the pre-encoded path the reference's variable
+                # has been overwritten by the encoder's language output by now (:571 vs :599)
+                "text_memory_bf_resize": lang if isinstance(text, tuple) else text_memory,
+                "text_memory_resized": text_memory_resized,
+                "text_memory": text_memory_resized,
+                "img_memory": img_memory,
+                "masks": mask_flatten,
+                "text_attention_mask": text_attention_mask,
+                "pos_embed": lvl_pos,
+                "ho_query_embed": query_embed,
+                "obj_pred_names_sums": obj_pred_names_sums,
+                "spatial_shapes": spatial_shapes,
+                "level_start_index": level_start_index,
+                "valid_ratios": valid_ratios,
+                "spatial_shapes_list": shapes_list,
+            }
+
+        # ---- phase B --------------------------------------------------------------------------------
+        bs = img_memory.shape[0]
+        d = self.d_model
+        anchors = query_embed[..., 2 * d:].sigmoid()
+        nq = query_embed.shape[0]
+        ref_sub, ref_obj = anchors[:nq // 2], anchors[nq // 2:]
+        tgt = query_embed[..., :d].unsqueeze(0).expand(bs, -1, -1)
+        verb_tgt = query_embed[..., d:2 * d].unsqueeze(0).expand(bs, -1, -1)
+        init_reference = (ref_sub, ref_obj)
+
+        hs_ho, inter_refs = self.ho_decoder(tgt, init_reference, img_memory, spatial_shapes, level_start_index,
+                                            valid_ratios, query_pos=None, src_padding_mask=masks)
+        last_sub, last_obj = hs_ho[-1][:, :nq // 2], hs_ho[-1][:, nq // 2:]
+        kind = self.verb_query_tgt_type
+        if kind == "vanilla":
+            verb_in = verb_tgt[:, :nq // 2] + verb_tgt[:, nq // 2:]
+        elif kind == "MBF":
+            verb_in = self.verb_tgt_generator(last_sub, last_obj)
+        elif kind == "vanilla_MBF":
+            verb_in = self.verb_tgt_generator(last_sub, last_obj) + verb_tgt[:, :nq // 2] + verb_tgt[:, nq // 2:]
+        else:
+            raise AssertionError(kind)
+        hs_verb, _ = self.verb_decoder(verb_in, inter_refs[-1], img_memory, spatial_shapes, level_start_index,
+                                       valid_ratios, query_pos=None, src_padding_mask=masks)
+        n_layer = hs_ho.shape[0]
+        if text_memory.dim() == 4 and text_memory.shape[0] == n_layer:
+            text_dec = text_memory
+        else:
+            text_dec = text_memory.unsqueeze(0).repeat(n_layer, 1, 1, 1)
+        return hs_ho, hs_verb, text_dec, init_reference, inter_refs, hs_ho, hs_verb, None, None
+
+
+class RLIP_ParSeDA(nn.Module):
+    def __init__(self, backbone, transformer, num_queries, num_feature_levels, aux_loss=True, with_box_refine=True,
+                 two_stage=False, use_dab=True, num_patterns=0, random_refpoints_xy=False, subject_class=False,
+                 pseudo_verb=False, args=None):
+        super().__init__()
+        assert use_dab and not two_stage and num_patterns == 0
+        self.num_queries = num_queries
+        self.transformer = transformer
+        hidden = transformer.d_model
+        self.num_feature_levels = num_feature_levels
+        self.use_dab, self.num_patterns, self.random_refpoints_xy = use_dab, num_patterns, random_refpoints_xy
+        self.projection_text = nn.Linear(hidden, hidden)
+        self.bias_c = -math.log((1 - 0.01) / 0.01)
+        self.bias_obj_a = nn.Parameter(torch.zeros((256,), dtype=torch.float32), requires_grad=True)
+        self.bias_pred_a = nn.Parameter(torch.zeros((256,), dtype=torch.float32), requires_grad=True)
+        self.tgt_embed = nn.Embedding(num_queries, hidden)
+        self.verb_tgt_embed = nn.Embedding(num_queries, hidden)
+        self.refpoint_embed = nn.Embedding(num_queries, 4)
+        if random_refpoints_xy:
+            self.refpoint_embed.weight.data[:, :2].uniform_(0, 1)
+            self.refpoint_embed.weight.data[:, :2] = inverse_sigmoid(self.refpoint_embed.weight.data[:, :2])
+
+        n_out = len(backbone.strides)
+        projs = []
+        for i in range(n_out):
+            projs.append(nn.Sequential(nn.Conv2d(backbone.num_channels[i], hidden, kernel_size=1),
+                                       nn.GroupNorm(32, hidden)))
+        in_ch = backbone.num_channels[n_out - 1]
+        for _ in range(num_feature_levels - n_out):
+            projs.append(nn.Sequential(nn.Conv2d(in_ch, hidden, kernel_size=3, stride=2, padding=1),
+                                       nn.GroupNorm(32, hidden)))
+            in_ch = hidden
+        self.input_proj = nn.ModuleList(projs)
+        self.backbone = backbone
+        self.aux_loss, self.with_box_refine, self.two_stage = aux_loss, with_box_refine, two_stage
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+
+        sub = MLP(hidden, hidden, 4, 3)
+        obj = MLP(hidden, hidden, 4, 3)
+        for head in (sub, obj):
+            nn.init.constant_(head.layers[-1].weight.data, 0)
+            nn.init.constant_(head.layers[-1].bias.data, 0)
+        n_pred = transformer.ho_decoder.num_layers
+        if with_box_refine:
+            # 2*n_pred clones each: the first half refines inside the ho decoder and predicts the
+            # boxes, the second half is handed to the verb decoder (reference hoi.py:1980-1990)
+            self.sub_bbox_embed = _clones(sub, n_pred * 2)
+            self.obj_bbox_embed = _clones(obj, n_pred * 2)
+            nn.init.constant_(self.sub_bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+            nn.init.constant_(self.obj_bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+            transformer.ho_decoder.sub_bbox_embed = self.sub_bbox_embed[:n_pred]
+            transformer.verb_decoder.sub_bbox_embed = self.sub_bbox_embed[n_pred:]
+            transformer.ho_decoder.obj_bbox_embed = self.obj_bbox_embed[:n_pred]
+            transformer.verb_decoder.obj_bbox_embed = self.obj_bbox_embed[n_pred:]
+        else:
+            nn.init.constant_(sub.layers[-1].bias.data[2:], -2.0)
+            nn.init.constant_(obj.layers[-1].bias.data[2:], -2.0)
+            self.sub_bbox_embed = nn.ModuleList([sub for _ in range(n_pred)])
+            self.obj_bbox_embed = nn.ModuleList([obj for _ in range(n_pred)])
+        self.subject_class = subject_class
+        self.pseudo_verb = pseudo_verb
+        self.pseudo_verb_mode = "online"
+
+    # ---- phase A: backbone + input projections + ALIF encoder -------------------------------------------
+    def _encode(self, samples, text):
+        features, pos = self.backbone(samples)
+        srcs, masks = [], []
+        for l, feat in enumerate(features):
+            src, mask = feat.decompose()
+            assert mask is not None
+            srcs.append(self.input_proj[l](src))
+            masks.append(mask)
+        for l in range(len(srcs), self.num_feature_levels):
+            src = self.input_proj[l](features[-1].tensors if l == len(features) else srcs[-1])
+            mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]   # Q13
+            pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
+            srcs.append(src)
+            masks.append(mask)
+        query_embeds = torch.cat((self.tgt_embed.weight, self.verb_tgt_embed.weight, self.refpoint_embed.weight), 1)
+        return self.transformer(srcs=srcs, masks=masks, pos_embeds=pos, query_embed=query_embeds, text=text,
+                                encode_and_save=True)
+
+    def forward(self, samples, encode_and_save=True, memory_cache=None, **kwargs):
+        if not isinstance(samples, NestedTensor):
+            samples = nested_tensor_from_tensor_list(samples)
+        if encode_and_save:
+            return self._encode(samples, kwargs['text'])
+
+        mc = memory_cache
+        hs_ho, hs_verb, text_dec, init_reference, inter_references, _, _, _, _ = self.transformer(
+            masks=mc["masks"], query_embed=mc["ho_query_embed"], encode_and_save=False,
+            text_memory=mc["text_memory_resized"], img_memory=mc["img_memory"],
+            text_attention_mask=mc["text_attention_mask"], obj_pred_names_sums=mc["obj_pred_names_sums"],
+            spatial_shapes=mc["spatial_shapes"], level_start_index=mc["level_start_index"],
+            valid_ratios=mc["valid_ratios"])
+        half = self.num_queries // 2
+        hs_h, hs_o = hs_ho[:, :, :half], hs_ho[:, :, half:]
+        sums = mc["obj_pred_names_sums"]
+        n_obj, n_verb = int(sums[:, 0].max()), int(sums[:, 1].max())
+
+        sub_cls, obj_cls, verb_cls, sub_box, obj_box = [], [], [], [], []
+        for lvl in range(hs_h.shape[0]):
+            ref_s, ref_o = init_reference if lvl == 0 else inter_references[lvl - 1]
+            sub_box.append((self.sub_bbox_embed[lvl](hs_h[lvl]) + inverse_sigmoid(ref_s)).sigmoid())
+            obj_box.append((self.obj_bbox_embed[lvl](hs_o[lvl]) + inverse_sigmoid(ref_o)).sigmoid())
+            text = F.normalize(text_dec[lvl].transpose(0, 1), p=2, dim=-1)
+            proj = self.projection_text(text / 2.0)
+            assert n_obj + n_verb == proj.shape[1]
+            obj_text, verb_text = proj[:, :n_obj], proj[:, n_obj:n_obj + n_verb]
+            obj_cls.append(torch.matmul(hs_o[lvl] + self.bias_obj_a, obj_text.transpose(1, 2)) + self.bias_c)
+            verb_cls.append(torch.matmul(hs_verb[lvl] + self.bias_pred_a, verb_text.transpose(1, 2)) + self.bias_c)
+            if self.subject_class:
+                sub_cls.append(torch.matmul(hs_h[lvl] + self.bias_obj_a, obj_text.transpose(1, 2)) + self.bias_c)
+
+        keys = ["pred_obj_logits", "pred_verb_logits", "pred_sub_boxes", "pred_obj_boxes"]
+        stacks = [obj_cls, verb_cls, sub_box, obj_box]
+        if self.subject_class:
+            keys, stacks = ["pred_sub_logits"] + keys, [sub_cls] + stacks
+        out = {k: v[-1] for k, v in zip(keys, stacks)}
+        if self.aux_loss:
+            out["aux_outputs"] = [{k: v[i] for k, v in zip(keys, stacks)} for i in range(len(obj_cls) - 1)]
+
+        if self.pseudo_verb:
+            # soft verb targets from pairwise distances of the raw verb label features (reference :2197-2239)
+            verb_feat = mc["text_memory_bf_resize"][:, 0][n_obj:n_obj + n_verb]
+            # F.pairwise_distance adds eps=1e-6 to the difference before the norm (the reference uses it)
+            dist = F.pairwise_distance(verb_feat.repeat(1, n_verb).view(-1, verb_feat.shape[1]),
+                                       verb_feat.repeat(n_verb, 1).view(-1, verb_feat.shape[1]), p=2).view(n_verb, n_verb)
+            sim = dist.max(-1)[0].unsqueeze(-1) - dist
+            tgt_verbs = torch.cat([t['verb_labels'] for t in kwargs['targets']])
+            tvs = (tgt_verbs.unsqueeze(-1).repeat(1, 1, sim.shape[-1]) * sim).sum(dim=1)
+            if tgt_verbs.shape[0] > 0:
+                tvs = tvs / tvs.max(-1)[0].unsqueeze(-1)
+            tvs[tgt_verbs.bool()] = 0
+            tvs = tvs * (tvs > 0.3)
+            out["target_verb_sim"] = tvs
+            if self.aux_loss:
+                for aux in out["aux_outputs"]:
+                    aux["target_verb_sim"] = tvs
+        return out
+
+
+def build_parseda(backbone, args=None, text_encoder=None):
+    """Assemble the model the way models/detr.py:552-567 + models/transformer.py:1344 do for
+    --RLIP_ParSeDA_v2 (return_intermediate_dec=True, two_stage=False, use_dab=True)."""
+    args = default_args() if args is None else args
+    transformer = RLIP_ParSeDABDeformableTransformer_v2(
+        d_model=args.hidden_dim, nhead=args.nheads, num_encoder_layers=args.enc_layers,
+        num_decoder_layers=args.dec_layers, dim_feedforward=args.dim_feedforward, dropout=args.dropout,
+        activation="relu", return_intermediate_dec=True, num_feature_levels=args.num_feature_levels,
+        dec_n_points=args.dec_n_points, enc_n_points=args.enc_n_points, two_stage=False,
+        two_stage_num_proposals=args.num_queries, use_dab=True, text_encoder_type=args.text_encoder_type,
+        freeze_text_encoder=args.freeze_text_encoder, args=args, text_encoder=text_encoder)
+    return RLIP_ParSeDA(backbone, transformer, num_queries=args.num_queries,
+                        num_feature_levels=args.num_feature_levels, aux_loss=args.aux_loss,
+                        with_box_refine=args.with_box_refine, two_stage=False, use_dab=True,
+                        subject_class=args.subject_class, pseudo_verb=args.pseudo_verb, args=args)

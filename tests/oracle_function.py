@@ -1,0 +1,28 @@
+"""TEST INFRASTRUCTURE: an autograd Function with MSDeformAttnFunction's signature whose forward and
+backward are the CPU oracle (oracle/msda_oracle.c).  CPU tests substitute it for the HIP op
+(`rlipv2_amd.deform_attn.msda_function`) to check the HOST logic of the modules against
+reference-generated goldens without a GPU.  Never imported by the product package."""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from oracle import msda_oracle as O
+
+
+class OracleMSDeformAttnFunction(Function):
+    @staticmethod
+    def forward(ctx, value, shapes, starts, loc, aw, im2col_step):
+        dt = np.float64 if value.dtype == torch.float64 else np.float32
+        a = [value.detach().numpy().astype(dt), shapes.numpy(), starts.numpy(), loc.detach().numpy().astype(dt),
+             aw.detach().numpy().astype(dt)]
+        ctx.args = a
+        ctx.dtypes = (value.dtype, loc.dtype, aw.dtype)
+        return torch.from_numpy(O.forward(*a)).to(value.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a = ctx.args
+        gv, gl, ga = O.backward(*a, grad_out.contiguous().numpy().astype(a[0].dtype))
+        dv, dl, da = ctx.dtypes
+        return (torch.from_numpy(gv).to(dv), None, None, torch.from_numpy(gl).to(dl), torch.from_numpy(ga).to(da),
+                None)

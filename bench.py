@@ -9,12 +9,17 @@ BASELINE.json config 2 (RLIP_ParSeDA_v2 R50, 4 levels, 300 queries, bf16, batch 
 800x1333 images -> pyramid 100x167 / 50x84 / 25x42 / 13x21, 64 text tokens).
 
 Workloads (``--workload``)
-  msda_step  (default this round): every multi-scale-deformable-attention call of one train step
+  train_step (default): the full RLIP_ParSeDA_v2 R50 train step -- ResNet-50 (frozen BN) -> input
+             projections -> 6-layer ALIF-fused deformable encoder (3 VLFuse + 3 RoBERTa layers) -> 3-layer
+             DAB human-object decoder -> verb decoder -> heads -> SetCriterionHOI (Hungarian matching)
+             -> backward -> clip_grad_norm_(0.1) -> AdamW, bf16 autocast with float32 master weights,
+             RoBERTa-base-shaped text encoder with random weights in the step; data parallel over
+             images with RCCL gradient all-reduce overlapped with backward (rlipv2_amd/train.py).
+  msda_step: every multi-scale-deformable-attention call of one train step
              -- 6 encoder self-attention (Lq = S = 22223), 3 human-object decoder (Lq = 300) and
              3 verb decoder (Lq = 150) cross-attention calls, forward then backward, i.e. the
              12 + 12 launches SURVEY.md section 1 counts per step -- on synthetic model-like
-             sampling locations (tools/msda_inputs.py).  The dense blocks around them are not
-             in this workload; `config.workload` says so.
+             sampling locations (tools/msda_inputs.py), without the dense blocks around them.
 
 Multi-GPU: the path shards over images with no exchange inside the MSDA op, so
 every rank processes its own batch (weak scaling); ranks only meet in the timing barrier.
@@ -110,8 +115,8 @@ def run_step(calls, lib, stream, timed):
         c.backward(lib, stream, timed)
 
 
-def cpu_baseline(calls):
-    """Oracle (OpenMP C port) on one image of the batch through all 24 calls of a step."""
+def cpu_baseline(calls, scope="msda_step"):
+    """Oracle (OpenMP C port) on whole images through all 24 MSDA calls of a step."""
     import numpy as np
 
     from oracle import msda_oracle as O
@@ -133,7 +138,138 @@ def cpu_baseline(calls):
         images += 1
     return {"value": round(images / t_total, 4), "unit": "images/s", "cores": O.threads(True), "kind": "port",
             "sample": "%d image(s) through all 12 fwd + 12 bwd MSDA calls of one step, float32, "
-                      "oracle/msda_oracle.c built with OpenMP; %.1f s of CPU work" % (images, t_total)}
+                      "oracle/msda_oracle.c built with OpenMP; %.1f s of CPU work%s" % (
+                          images, t_total, "" if scope == "msda_step" else
+                          "; covers ONLY the MSDeformAttn calls of the train step (the oracle restates that op; the "
+                          "reference's dense blocks have no CPU port here), i.e. an upper bound on a CPU step rate")}
+
+
+class KernelTimer:
+    """HIP-event brackets around the MSDA entry points while the train step runs (same stream)."""
+
+    def __init__(self):
+        from rlipv2_amd import msda
+        self.msda = msda
+        self.records = []          # (direction, dims, dtype_code, start, end)
+        self.enabled = False
+        self._fwd, self._bwd = msda.ms_deform_attn_forward, msda.ms_deform_attn_backward
+        msda.ms_deform_attn_forward = self._wrap(self._fwd, "fwd")
+        msda.ms_deform_attn_backward = self._wrap(self._bwd, "bwd")
+
+    def _wrap(self, fn, direction):
+        def timed(value, shapes, starts, loc, aw, *rest):
+            if not self.enabled:
+                return fn(value, shapes, starts, loc, aw, *rest)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(value, shapes, starts, loc, aw, *rest)
+            b.record()
+            N, S, M, D = value.shape
+            dims = (N, S, M, D, shapes.shape[0], loc.shape[1], loc.shape[4])
+            code = _lib.MSDA_BF16 if value.dtype == torch.bfloat16 else (_lib.MSDA_F64 if value.dtype == torch.float64 else _lib.MSDA_F32)
+            self.records.append((direction, dims, code, a, b))
+            return out
+        return timed
+
+    def summary(self):
+        kern = {}
+        for direction, dims, code, a, b in self.records:
+            kind = "enc" if dims[5] == dims[1] else f"dec{dims[5]}"
+            k = kern.setdefault(f"{kind}_{direction}", {"ms": 0.0, "n": 0, "dims": dims, "code": code,
+                                                         "bwd": direction == "bwd",
+                                                         "bytes": _lib.algorithmic_bytes(code, direction == "bwd", *dims)})
+            k["ms"] += a.elapsed_time(b)
+            k["n"] += 1
+        return kern
+
+
+def run_train_step_bench(args, world, rank, local_rank, device):
+    from rlipv2_amd import parseda, train
+    margs = parseda.default_args(num_queries=args.queries)
+    torch.manual_seed(0 + rank)                                       # reference main.py:505
+    model, criterion = train.build_training(margs, device=device, with_text_encoder=True)
+    step_module = train.ParSeDATrainStep(model)
+    if world > 1:
+        step_module = torch.nn.parallel.DistributedDataParallel(
+            step_module, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
+            bucket_cap_mb=64)
+    optimizer = train.build_optimizer(model)
+    batch = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=8, device=device, seed=rank)
+    model.train()
+    timer = KernelTimer()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    for _ in range(args.warmup):
+        train.train_step(step_module, criterion, optimizer, batch, autocast_dtype=dtype)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train.train_step(step_module, criterion, optimizer, batch, autocast_dtype=dtype)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    return elapsed, timer.summary(), float(loss), n_params
+
+
+def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls):
+    dominant = max(kern, key=lambda n: kern[n]["ms"])
+    kd = kern[dominant]
+    mean_s = kd["ms"] / kd["n"] * 1e-3
+    achieved = kd["bytes"] / mean_s / 1e9
+    variant = lib.msda_variant_name(lib.msda_pick_variant(int(kd["bwd"]), kd["code"], *kd["dims"])).decode()
+    images = args.batch * world * args.steps
+    line = {
+        "metric": METRIC,
+        "value": round(images / elapsed, 3),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": workload_text,
+            "global_batch": args.batch * world,
+            "batch_per_gpu": args.batch,
+            "pyramid": PYRAMID_800x1333,
+            "parallelism": parallelism,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": f"msda_{variant}_{'backward' if kd['bwd'] else 'forward'} ({dominant}: N={kd['dims'][0]}, "
+                      f"Lq={kd['dims'][5]}, S={kd['dims'][1]})",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": kd["bytes"],
+            "mean_launch_us": round(mean_s * 1e6, 2),
+            "msda_share_of_step": round(sum(k["ms"] for k in kern.values()) * 1e-3 / elapsed, 4),
+            "all_kernels": {n: {"mean_us": round(k["ms"] / k["n"] * 1e3, 2), "launches": k["n"],
+                                "GBps": round(k["bytes"] / (k["ms"] / k["n"] * 1e-3) / 1e9, 1)}
+                            for n, k in sorted(kern.items())},
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -143,7 +279,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE config 2: 4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--workload", default="msda_step", choices=["msda_step"])
+    ap.add_argument("--workload", default="train_step", choices=["train_step", "msda_step"])
+    ap.add_argument("--queries", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -162,6 +299,19 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     lib = _lib.lib()
+    if args.workload == "train_step":
+        elapsed, kern, loss, n_params = run_train_step_bench(args, world, rank, local_rank, device)
+        if rank == 0:
+            emit(args, world, elapsed, kern, lib, workload_text=(
+                "train_step: RLIP_ParSeDA_v2 R50 4-scale %d-query train step (fwd phase A+B, SetCriterionHOI, bwd, "
+                "clip 0.1, AdamW), batch %d/GPU, 800x1333, 64 relation/object texts, RoBERTa-base-shaped text "
+                "encoder in the step, bf16 autocast with fp32 master weights; %.1f M trainable parameters; "
+                "final loss %.4f" % (args.queries, args.batch, n_params / 1e6, loss)),
+                 parallelism=f"dp{world} (RCCL gradient all-reduce, bucketed, overlapped with backward)",
+                 cpu_calls=lambda: build_msda_step(1, torch.float32, device, 0))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     calls = build_msda_step(args.batch, dtype, device, rank)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -186,62 +336,21 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        # per-kernel means from the HIP events recorded inside the timed region
         kern = {}
         for c in calls:
-            kind = "enc" if c.name.startswith("enc") else ("ho_dec" if c.name.startswith("ho") else "verb_dec")
+            kind = "enc" if c.name.startswith("enc") else ("dec300" if c.name.startswith("ho") else "dec150")
             for d in ("fwd", "bwd"):
                 ms = [a.elapsed_time(b) for a, b in c.ev[d]]
                 k = kern.setdefault(f"{kind}_{d}", {"ms": 0.0, "n": 0, "bytes": c.bytes_fwd if d == "fwd" else c.bytes_bwd,
                                                     "dims": c.dims, "code": c.code, "bwd": d == "bwd"})
                 k["ms"] += sum(ms)
                 k["n"] += len(ms)
-        dominant = max(kern, key=lambda n: kern[n]["ms"])
-        kd = kern[dominant]
-        mean_s = kd["ms"] / kd["n"] * 1e-3
-        achieved = kd["bytes"] / mean_s / 1e9
-        variant = lib.msda_variant_name(lib.msda_pick_variant(int(kd["bwd"]), kd["code"], *kd["dims"])).decode()
-        images = args.batch * world * args.steps
-        line = {
-            "metric": METRIC,
-            "value": round(images / elapsed, 3),
-            "unit": "images/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": "msda_step: the 12 fwd + 12 bwd MSDeformAttn launches of one RLIP_ParSeDA_v2 R50 "
-                            "train step (6 encoder Lq=S=22223, 3 ho-decoder Lq=300, 3 verb-decoder Lq=150), "
-                            "4-level 800x1333 pyramid, M8 D32 L4 P4; dense blocks not included",
-                "global_batch": args.batch * world,
-                "batch_per_gpu": args.batch,
-                "pyramid": PYRAMID_800x1333,
-                "parallelism": f"dp{world} (independent image shards, no collective in this workload)",
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": f"msda_{variant}_{'backward' if kd['bwd'] else 'forward'} (encoder shape, {dominant})",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
-                "algorithmic_bytes_per_launch": kd["bytes"],
-                "mean_launch_us": round(mean_s * 1e6, 2),
-                "all_kernels": {n: {"mean_us": round(k["ms"] / k["n"] * 1e3, 2),
-                                    "GBps": round(k["bytes"] / (k["ms"] / k["n"] * 1e-3) / 1e9, 1)}
-                                for n, k in sorted(kern.items())},
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(calls)
-        print(json.dumps(line), flush=True)
+        emit(args, world, elapsed, kern, lib, workload_text=(
+            "msda_step: the 12 fwd + 12 bwd MSDeformAttn launches of one RLIP_ParSeDA_v2 R50 train step "
+            "(6 encoder Lq=S=22223, 3 ho-decoder Lq=300, 3 verb-decoder Lq=150), 4-level 800x1333 pyramid, "
+            "M8 D32 L4 P4; dense blocks not included"),
+             parallelism=f"dp{world} (independent image shards, no collective in this workload)",
+             cpu_calls=lambda: calls)
     if world > 1:
         dist.destroy_process_group()
 

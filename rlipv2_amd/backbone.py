@@ -1,0 +1,127 @@
+"""ResNet-50 input producer with frozen BatchNorm, plus the (backbone, position-encoding) pair the
+model indexes as ``backbone[0]`` / ``backbone[1]``.
+
+Reference: models/DDETR_backbone.py (FrozenBatchNorm2d :27-59, BackboneBase :62-97 -- only layer2-4
+train, features C3/C4/C5 at strides 8/16/32 with nearest-interpolated masks, Joiner :135-160).  The
+reference builds the trunk from torchvision (absent here); this is a plain restatement of the
+ResNet-50 v1.5 topology with torchvision's parameter names (``body.layerK.B.convJ`` ...), so
+ImageNet / reference checkpoints load.  Host PyTorch (MIOpen convolutions): not a kernel target.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .blocks import NestedTensor, PositionEmbeddingSine
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters (buffers), eps inside the rsqrt."""
+
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self.eps = eps
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        state_dict.pop(prefix + 'num_batches_tracked', None)
+        super()._load_from_state_dict(state_dict, prefix, *args)
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        bias = self.bias - self.running_mean * scale
+        return x * scale.view(1, -1, 1, 1).to(x.dtype) + bias.view(1, -1, 1, 1).to(x.dtype)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = FrozenBatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)      # v1.5: stride on the 3x3
+        self.bn2 = FrozenBatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        return F.relu(self.bn3(self.conv3(out)) + idt)
+
+
+class ResNet50Body(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(64)
+        self.inplanes = 64
+        self.layer1 = self._stage(64, 3, 1)
+        self.layer2 = self._stage(128, 4, 2)
+        self.layer3 = self._stage(256, 6, 2)
+        self.layer4 = self._stage(512, 3, 2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _stage(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                 FrozenBatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        c2 = self.layer1(x)
+        c3 = self.layer2(c2)
+        c4 = self.layer3(c3)
+        c5 = self.layer4(c4)
+        return c3, c4, c5
+
+
+class Backbone(nn.Module):
+    def __init__(self, train_backbone=True):
+        super().__init__()
+        self.body = ResNet50Body()
+        for name, p in self.body.named_parameters():
+            if not train_backbone or ('layer2' not in name and 'layer3' not in name and 'layer4' not in name):
+                p.requires_grad_(False)
+        self.strides = [8, 16, 32]
+        self.num_channels = [512, 1024, 2048]
+
+    def forward(self, tensor_list: NestedTensor):
+        m = tensor_list.mask
+        assert m is not None
+        out = []
+        for x in self.body(tensor_list.tensors):
+            mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
+            out.append(NestedTensor(x, mask))
+        return out
+
+
+class Joiner(nn.Sequential):
+    """[0] = backbone, [1] = position encoding; returns (features, positions)."""
+
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+        self.strides = backbone.strides
+        self.num_channels = backbone.num_channels
+
+    def forward(self, tensor_list: NestedTensor):
+        feats = self[0](tensor_list)
+        return feats, [self[1](x).to(x.tensors.dtype) for x in feats]
+
+
+def build_r50_backbone(hidden_dim=256, train_backbone=True):
+    return Joiner(Backbone(train_backbone), PositionEmbeddingSine(hidden_dim // 2, normalize=True))

@@ -1,0 +1,143 @@
+"""The train step of RLIPv2-ParSeDA and its data-parallel wrapper (the protocol of the reference's
+engine.train_one_epoch, engine.py:45-201, and main.py:505-539).
+
+  step = phase A (backbone + ALIF encoder) -> phase B (decoders + heads) -> SetCriterionHOI ->
+         weighted loss -> backward -> clip_grad_norm_(0.1) -> AdamW (3 parameter groups by name:
+         rest / "backbone" / "text_encoder", main.py:523-539)
+
+Data parallelism: one process per GPU, full replica, image batch sharded, gradient
+all-reduce over RCCL (torch.distributed backend "nccl") bucketed and overlapped with backward by
+DistributedDataParallel.  Two departures from the reference, neither changes the gradients:
+  * both model phases run inside ONE wrapped forward, so the DDP hooks fire once per step (the
+    reference calls the DDP module twice per backward);
+  * the parameters that can never receive a gradient -- the box heads handed to the verb decoder,
+    whose outputs only feed detached reference points -- are frozen up front, a static
+    unused-parameter mask, instead of `find_unused_parameters=True` graph walks every step.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import criterion as crit_mod
+from .backbone import build_r50_backbone
+from .blocks import NestedTensor
+from .parseda import build_parseda, default_args
+
+
+class TextEncoderStub(nn.Module):
+    """RoBERTa-base shaped text encoder with random weights (no checkpoints offline), built from
+    the installed `transformers` package when available."""
+
+    def __init__(self):
+        super().__init__()
+        from transformers import RobertaConfig, RobertaModel
+        cfg = RobertaConfig(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                            intermediate_size=3072, hidden_act="gelu", hidden_dropout_prob=0.1,
+                            attention_probs_dropout_prob=0.1, max_position_embeddings=514, type_vocab_size=1,
+                            layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+        self.model = RobertaModel(cfg)
+
+    def forward(self, input_ids, attention_mask):
+        return self.model(input_ids=input_ids, attention_mask=attention_mask)
+
+
+class ParSeDATrainStep(nn.Module):
+    """Both phases of the model in one forward (what DDP wraps)."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, samples, text, targets):
+        memory_cache = self.model(samples, encode_and_save=True, text=text, targets=targets)
+        return self.model(samples, encode_and_save=False, memory_cache=memory_cache, text=text, targets=targets)
+
+
+def freeze_statically_unused(model):
+    """sub/obj_bbox_embed[n_pred:] only produce detached reference points in the verb decoder."""
+    n_pred = model.transformer.ho_decoder.num_layers
+    frozen = 0
+    for heads in (model.sub_bbox_embed, model.obj_bbox_embed):
+        for head in list(heads)[n_pred:]:
+            for p in head.parameters():
+                p.requires_grad_(False)
+                frozen += p.numel()
+    return frozen
+
+
+def build_training(args=None, device="cuda:0", with_text_encoder=True):
+    args = default_args() if args is None else args
+    backbone = build_r50_backbone(args.hidden_dim, train_backbone=True)
+    text_encoder = TextEncoderStub() if with_text_encoder else None
+    model = build_parseda(backbone, args, text_encoder=text_encoder).to(device)
+    freeze_statically_unused(model)
+    matcher = crit_mod.HungarianMatcherHOI(cost_obj_class=1, cost_verb_class=1, cost_bbox=2.5, cost_giou=1,
+                                           subject_class=args.subject_class)
+    criterion = crit_mod.SetCriterionHOI(matcher, crit_mod.build_weight_dict(args.dec_layers),
+                                         eos_coef=0.1, subject_class=args.subject_class, giou_verb_label=True,
+                                         pseudo_verb=args.pseudo_verb).to(device)
+    return model, criterion
+
+
+def build_optimizer(model, lr=1.41e-4, lr_backbone=1.41e-5, text_encoder_lr=1.41e-5, weight_decay=1e-4):
+    """AdamW, three groups by parameter name (reference main.py:523-539)."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    groups = [
+        {"params": [p for n, p in named if "backbone" not in n and "text_encoder" not in n]},
+        {"params": [p for n, p in named if "backbone" in n], "lr": lr_backbone},
+        {"params": [p for n, p in named if "text_encoder" in n], "lr": text_encoder_lr},
+    ]
+    try:
+        return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=True)
+    except (RuntimeError, TypeError):
+        return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+
+
+def synthetic_batch(batch, height=800, width=1333, n_obj=43, n_verb=21, triplets=8, token_len=5, device="cuda:0",
+                    seed=0):
+    """images ~ N(0,1) (post-normalisation), no padding; 43 object labels (last = "no
+    objects") + 21 relation labels = 64 texts as seeded token ids of length 5; 8 triplets per image."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    images = torch.randn(batch, 3, height, width, generator=g).to(device)
+    mask = torch.zeros(batch, height, width, dtype=torch.bool, device=device)
+    n_text = n_obj + n_verb
+    ids = torch.randint(3, 50000, (n_text, token_len), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    text = {"input_ids": ids.to(device), "attention_mask": torch.ones_like(ids).to(device),
+            "obj_pred_names_sums": torch.tensor([[n_obj, n_verb]])}
+    targets = []
+    for _ in range(batch):
+        c = torch.rand(triplets, 2, generator=g) * 0.6 + 0.2
+        wh = torch.rand(triplets, 2, generator=g) * 0.35 + 0.05
+        c2 = torch.rand(triplets, 2, generator=g) * 0.6 + 0.2
+        wh2 = torch.rand(triplets, 2, generator=g) * 0.35 + 0.05
+        verbs = torch.zeros(triplets, n_verb)
+        verbs[torch.arange(triplets), torch.randint(0, n_verb, (triplets,), generator=g)] = 1
+        verbs[torch.arange(0, triplets, 2), torch.randint(0, n_verb, (triplets // 2,), generator=g)] = 1
+        targets.append({"sub_labels": torch.randint(0, n_obj - 1, (triplets,), generator=g).to(device),
+                        "obj_labels": torch.randint(0, n_obj - 1, (triplets,), generator=g).to(device),
+                        "verb_labels": verbs.to(device),
+                        "sub_boxes": torch.cat([c, wh], 1).to(device), "obj_boxes": torch.cat([c2, wh2], 1).to(device)})
+    return NestedTensor(images, mask), text, targets
+
+
+def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_dtype=torch.bfloat16):
+    """One optimisation step; returns the (device) loss.  No host synchronisation except the
+    matcher's single device->host copy of the cost matrices."""
+    samples, text, targets = batch
+    with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
+        outputs = step_module(samples, text, targets)
+    outputs = {k: ([{kk: vv.float() for kk, vv in a.items()} for a in v] if k == "aux_outputs" else v.float())
+               for k, v in outputs.items()}
+    loss_dict = criterion(outputs, targets)
+    loss = criterion.weighted_sum(loss_dict)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if max_norm > 0:
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        torch.nn.utils.clip_grad_norm_(params, max_norm, foreach=True)
+    optimizer.step()
+    return loss.detach()

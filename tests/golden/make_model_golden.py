@@ -9,6 +9,7 @@ Goldens (tests/golden/model_*.npz), all in eval() mode and float3
   encoder                 RLIPv2_DeformableTransformerEncoder, 2 layers / 1 fusion, fusion_last_vis on and off
   decoder_ho / _verb      DABDeformableTransformerDecoderHOI ParSe=True / False, 2 layers, box refine
   mbf                     MultiBranchFusion
+  criterion               SetCriterionHOI + HungarianMatcherHOI loss dict and gradients for fixed predictions
   parseda                 full RLIP_ParSeDA (enc 4 / dec 2, nq 20, 12 texts, two images of different
                           size): all outputs + aux, and gradients w.r.t. the input features and a few
                           sentinel parameters
@@ -284,6 +285,76 @@ def gold_parseda():
     save("parseda", **rec)
 
 
+def criterion_case():
+    """Fixed predictions (main + 1 aux layer) and targets for the criterion golden."""
+    N, nq, n_obj, n_verb = 2, 10, 7, 5
+
+    def outs(seed):
+        g = torch.Generator().manual_seed(seed)
+        return {'pred_sub_logits': torch.randn(N, nq, n_obj, generator=g),
+                'pred_obj_logits': torch.randn(N, nq, n_obj, generator=g),
+                'pred_verb_logits': torch.randn(N, nq, n_verb, generator=g),
+                'pred_sub_boxes': torch.rand(N, nq, 4, generator=g) * 0.4 + 0.2,
+                'pred_obj_boxes': torch.rand(N, nq, 4, generator=g) * 0.4 + 0.2}
+    g = torch.Generator().manual_seed(5)
+    main, aux = outs(1), [outs(2)]
+    tvs = torch.rand(5, n_verb, generator=g) * 0.5
+    targets = []
+    for n, k in enumerate((3, 2)):
+        vl = torch.zeros(k, n_verb)
+        vl[torch.arange(k), torch.randint(0, n_verb, (k,), generator=g)] = 1
+        ob = torch.rand(k, 4, generator=g) * 0.3 + 0.2
+        if n == 1:
+            ob[1] = 0                                   # a relation without an object box
+        targets.append({'obj_labels': torch.randint(0, n_obj - 1, (k,), generator=g),
+                        'sub_labels': torch.randint(0, n_obj - 1, (k,), generator=g), 'verb_labels': vl,
+                        'sub_boxes': torch.rand(k, 4, generator=g) * 0.3 + 0.2, 'obj_boxes': ob})
+    tvs[torch.cat([t['verb_labels'] for t in targets]).bool()] = 0
+    for o in [main] + aux:
+        o['target_verb_sim'] = tvs
+    return main, aux, targets, (N, nq, n_obj, n_verb)
+
+
+def gold_criterion():
+    """SetCriterionHOI + HungarianMatcherHOI in the ParSeDA script configuration (models/hoi.py:3627,
+    models/matcher.py:95; weights models/detr.py:571-620 with set_cost_bbox 2.5 / bbox_loss_coef 2.5)."""
+    cwd = os.getcwd()
+    os.chdir(R.REF)                                     # the ctor loads datasets/priors/hico_verb_samples.npz
+    from models.hoi import SetCriterionHOI
+    from models.matcher import HungarianMatcherHOI
+    args = R.reference_args()
+    args.verb_tagger = False
+    main, aux, targets, (N, nq, n_obj, n_verb) = criterion_case()
+    for o in [main] + aux:
+        for k in o:
+            if k.startswith('pred_'):
+                o[k].requires_grad_(True)
+    out = dict(main)
+    out['aux_outputs'] = aux
+    matcher = HungarianMatcherHOI(cost_obj_class=1, cost_verb_class=1, cost_bbox=2.5, cost_giou=1, subject_class=True)
+    crit = SetCriterionHOI(n_obj - 1, nq, n_verb, matcher=matcher, weight_dict={}, eos_coef=0.1,
+                           losses=['obj_labels', 'verb_labels', 'sub_obj_boxes', 'obj_cardinality'],
+                           verb_loss_type='focal', obj_loss_type='cross_entropy', matching_symmetric=False,
+                           RLIP_ParSe=False, subject_class=True, use_no_verb_token=False, giou_verb_label=True,
+                           verb_curing=False, pseudo_verb=True, triplet_filtering=False, naive_obj_smooth=0,
+                           naive_verb_smooth=0, args=args)
+    ld = crit(out, [dict(t) for t in targets])
+    os.chdir(cwd)
+    w = {'loss_obj_ce': 1.0, 'loss_verb_ce': 1.0, 'loss_sub_bbox': 2.5, 'loss_obj_bbox': 2.5, 'loss_sub_giou': 1.0,
+         'loss_obj_giou': 1.0}
+    w.update({k + '_0': v for k, v in list(w.items())})
+    total = sum(ld[k] * w[k] for k in ld if k in w)
+    total.backward()
+    rec = {"total": total}
+    for li, o in enumerate([main] + aux):
+        for k in o:
+            if k.startswith('pred_'):
+                rec[f"g_L{li}_{k}"] = o[k].grad
+    for k, v in ld.items():
+        rec["loss_" + k] = v if torch.is_tensor(v) else torch.tensor(float(v))
+    save("criterion", **rec)
+
+
 def main():
     R.install()
     torch.manual_seed(0)
@@ -294,6 +365,7 @@ def main():
     gold_decoder()
     gold_mbf()
     gold_parseda()
+    gold_criterion()
 
 
 if __name__ == "__main__":

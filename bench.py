@@ -189,15 +189,17 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     torch.manual_seed(0 + rank)                                       # reference main.py:505
     model, criterion = train.build_training(margs, device=device, with_text_encoder=True)
     step_module = train.ParSeDATrainStep(model)
+    batch = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=8, device=device, seed=rank)
+    model.train()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else None
     if world > 1:
+        # static unused-parameter mask from a dry run, then DDP without per-step graph searches
+        train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
         step_module = torch.nn.parallel.DistributedDataParallel(
             step_module, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
             bucket_cap_mb=64)
     optimizer = train.build_optimizer(model)
-    batch = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=8, device=device, seed=rank)
-    model.train()
     timer = KernelTimer()
-    dtype = torch.bfloat16 if args.dtype == "bf16" else None
     for _ in range(args.warmup):
         train.train_step(step_module, criterion, optimizer, batch, autocast_dtype=dtype)
 

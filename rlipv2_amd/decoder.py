@@ -94,8 +94,8 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
             else:
                 ref_in = 0.5 * (sub_ref + obj_ref)[:, :, None] * ratios4
             if self.use_dab:
-                raw = self.ref_point_head(ref_in) if self.no_sine_embed else \
-                    self.ref_point_head(sine_embed_for_position(ref_in[:, :, 0, :]))
+                feat = ref_in if self.no_sine_embed else sine_embed_for_position(ref_in[:, :, 0, :])
+                raw = self.ref_point_head(feat.to(output.dtype))
                 query_pos = raw if lid == 0 else self.query_scale(output) * raw
             if self.high_dim_query_update and lid != 0:
                 query_pos = query_pos + self.high_dim_query_proj(output)

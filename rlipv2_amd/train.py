@@ -68,6 +68,27 @@ def freeze_statically_unused(model):
     return frozen
 
 
+def freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=None):
+    """Dry run (forward + backward, no optimiser step) and freeze every trainable parameter that
+    received no gradient: the static unused-parameter mask that lets DistributedDataParallel run
+    with find_unused_parameters=False (a bucket holding a parameter that never gets a gradient would
+    never be reduced).  Returns the frozen names.  Call BEFORE wrapping in DDP."""
+    samples, text, targets = batch
+    device_type = samples.tensors.device.type
+    with torch.autocast(device_type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+        outputs = step_module(samples, text, targets)
+    outputs = {k: ([{kk: vv.float() for kk, vv in a.items()} for a in v] if k == "aux_outputs" else v.float())
+               for k, v in outputs.items()}
+    criterion.weighted_sum(criterion(outputs, targets)).backward()
+    frozen = []
+    for n, p in step_module.named_parameters():
+        if p.requires_grad and p.grad is None:
+            p.requires_grad_(False)
+            frozen.append(n)
+        p.grad = None
+    return frozen
+
+
 def build_training(args=None, device="cuda:0", with_text_encoder=True):
     args = default_args() if args is None else args
     backbone = build_r50_backbone(args.hidden_dim, train_backbone=True)

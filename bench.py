@@ -188,17 +188,21 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     margs = parseda.default_args(num_queries=args.queries)
     torch.manual_seed(0 + rank)                                       # reference main.py:505
     model, criterion = train.build_training(margs, device=device, with_text_encoder=True)
-    step_module = train.ParSeDATrainStep(model)
     batch = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=8, device=device, seed=rank)
+    master = args.dtype == "bf16" and args.precision == "master"
+    if master:      # bf16 parameters / activations / gradients, float32 master weights in the optimiser
+        train.to_bf16(model)
+        batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    step_module = train.ParSeDATrainStep(model)
     model.train()
-    dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    dtype = torch.bfloat16 if (args.dtype == "bf16" and not master) else None
     if world > 1:
         # static unused-parameter mask from a dry run, then DDP without per-step graph searches
         train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
         step_module = torch.nn.parallel.DistributedDataParallel(
             step_module, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
             bucket_cap_mb=64)
-    optimizer = train.build_optimizer(model)
+    optimizer = train.MasterWeightAdamW(model) if master else train.build_optimizer(model)
     timer = KernelTimer()
     for _ in range(args.warmup):
         train.train_step(step_module, criterion, optimizer, batch, autocast_dtype=dtype)
@@ -283,6 +287,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="train_step", choices=["train_step", "msda_step"])
     ap.add_argument("--queries", type=int, default=300)
+    ap.add_argument("--precision", default="master", choices=["master", "autocast"],
+                    help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -307,8 +313,11 @@ def main():
             emit(args, world, elapsed, kern, lib, workload_text=(
                 "train_step: RLIP_ParSeDA_v2 R50 4-scale %d-query train step (fwd phase A+B, SetCriterionHOI, bwd, "
                 "clip 0.1, AdamW), batch %d/GPU, 800x1333, 64 relation/object texts, RoBERTa-base-shaped text "
-                "encoder in the step, bf16 autocast with fp32 master weights; %.1f M trainable parameters; "
-                "final loss %.4f" % (args.queries, args.batch, n_params / 1e6, loss)),
+                "encoder in the step, %s; %.1f M trainable parameters; "
+                "final loss %.4f" % (args.queries, args.batch,
+                                     ("bf16 parameters/activations/gradients with float32 master weights" if args.precision == "master"
+                                      else "bf16 autocast over float32 weights") if args.dtype == "bf16" else "float32",
+                                     n_params / 1e6, loss)),
                  parallelism=f"dp{world} (RCCL gradient all-reduce, bucketed, overlapped with backward)",
                  cpu_calls=lambda: build_msda_step(1, torch.float32, device, 0))
         if world > 1:

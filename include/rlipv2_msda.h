@@ -113,6 +113,19 @@ int msda_backward_ex(int variant, int dtype,
                      void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
                      void *stream);
 
+/* Fused "sampling geometry" of the MSDeformAttn module (reference models/ops/modules/ms_deform_attn.py:101-112:
+ * view + softmax over the L*P logits + offsets/(W,H) or offsets/P*wh*0.5 + reference point), L = 4, P = 4.
+ *   qproj [R, M*L*P*3] (qdtype MSDA_F32 or MSDA_BF16): M*L*P*2 offsets then M*L*P logits, R = N*Lq rows
+ *   ref   [R, L, refdim] float32, refdim 2 (points) or 4 (boxes)
+ *   -> sampling_loc [R, M, L, P, 2], attn_weight [R, M, L, P], float32.
+ * Backward: gradients of the projection row (qdtype) and, if g_ref != NULL, of the reference points
+ * (float32, zero-filled inside). */
+int msda_prepare_forward(int qdtype, const void *qproj, const float *ref, int refdim, const int64_t *spatial_shapes,
+                         int R, int M, int L, int P, float *sampling_loc, float *attn_weight, void *stream);
+int msda_prepare_backward(int qdtype, const void *qproj, const float *ref, int refdim, const int64_t *spatial_shapes,
+                          const float *attn_weight, const float *grad_sampling_loc, const float *grad_attn_weight,
+                          int R, int M, int L, int P, void *grad_qproj, float *grad_ref, void *stream);
+
 /* The reference's batch-chunking precondition (cuda/ms_deform_attn_cuda.cu:50-52). */
 int msda_check_im2col_step(int batch, int im2col_step);
 

@@ -21,6 +21,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "quad": VARIANT_QU
 EXPORTS = (
     "msda_forward", "msda_backward", "msda_forward_ex", "msda_backward_ex", "msda_check_im2col_step",
     "msda_algorithmic_bytes", "msda_strerror", "msda_abi_version", "msda_variant_name", "msda_pick_variant",
+    "msda_prepare_forward", "msda_prepare_backward",
 )
 
 _lib = None
@@ -53,6 +54,9 @@ def lib() -> ctypes.CDLL:
     L.msda_backward_ex.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp]
     for f in (L.msda_forward, L.msda_backward, L.msda_forward_ex, L.msda_backward_ex):
         f.restype = i
+    L.msda_prepare_forward.argtypes = [i, vp, vp, i, vp, i, i, i, i, vp, vp, vp]
+    L.msda_prepare_backward.argtypes = [i, vp, vp, i, vp, vp, vp, vp, i, i, i, i, vp, vp, vp]
+    L.msda_prepare_forward.restype = L.msda_prepare_backward.restype = i
     L.msda_check_im2col_step.argtypes = [i, i]
     L.msda_check_im2col_step.restype = i
     L.msda_algorithmic_bytes.argtypes = [i, i, *dims]

@@ -31,10 +31,22 @@ class FrozenBatchNorm2d(nn.Module):
         state_dict.pop(prefix + 'num_batches_tracked', None)
         super()._load_from_state_dict(state_dict, prefix, *args)
 
+    def _folded(self, dtype):
+        """(scale, bias) of the frozen affine map, computed in float32 once and cached per dtype
+        (the statistics are buffers that only change when a checkpoint is loaded)."""
+        key = (dtype, self.weight._version, self.bias._version, self.running_mean._version,
+               self.running_var._version, self.weight.device)
+        if getattr(self, "_fold_key", None) != key:
+            w, b = self.weight.float(), self.bias.float()
+            scale = w * (self.running_var.float() + self.eps).rsqrt()
+            bias = b - self.running_mean.float() * scale
+            self._fold = (scale.view(1, -1, 1, 1).to(dtype), bias.view(1, -1, 1, 1).to(dtype))
+            self._fold_key = key
+        return self._fold
+
     def forward(self, x):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        bias = self.bias - self.running_mean * scale
-        return x * scale.view(1, -1, 1, 1).to(x.dtype) + bias.view(1, -1, 1, 1).to(x.dtype)
+        scale, bias = self._folded(x.dtype)
+        return torch.addcmul(bias, x, scale)
 
 
 class Bottleneck(nn.Module):

@@ -19,6 +19,8 @@
 // rotates those registers through the quad, so level l is always broadcast from quad lane 0.
 // Per-level (H, W, start) are wave-uniform scalar loads from the device-resident int64
 // metadata, exactly the operands the reference passes (ms_deform_attn_cuda.cu:67-68).
+#include <cstdlib>
+
 #include "msda_device.h"
 #include "msda_internal.h"
 
@@ -98,7 +100,7 @@ template <typename VT, int WAVES, int FENCE>
 __global__ __launch_bounds__(kBlock, WAVES) void quad_forward_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ aw, int total_qm, int S, int M, int Lq,
-    VT *__restrict__ out)
+    VT *__restrict__ out, int dbg)
 {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     int qm = t >> 2;
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_forward_kernel(
     const int n = (qm / M) / Lq;
     const VT *vimg = value + (long)n * S * M * kD;
     const int head_chan = m * kD + sub * 8;
+    if (dbg & 1) M = 0;          // ablation: every gather hits the head's first rows (cache-resident)
     // quad lane j loads the 4 points of level j: (x,y) x 4 and 4 weights
     const float4 *loc4 = reinterpret_cast<const float4 *>(loc) + (long)qm * 8 + sub * 2;
     float4 la = loc4[0], lb = loc4[1];
@@ -242,16 +245,18 @@ bool quad_supports(const Problem &p)
 
 void launch_quad_forward(const Problem &p)
 {
+    const char *e = getenv("RLIPV2_MSDA_DEBUG");       // ablation switch, profiling only
+    const int dbg = e ? atoi(e) : 0;
     const int total_qm = p.N * p.Lq * p.M;
     const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
     if (p.dtype == MSDA_F32)
         hipLaunchKernelGGL((quad_forward_kernel<float, 6, 2>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           total_qm, p.S, p.M, p.Lq, (float *)p.out);
+                           total_qm, p.S, p.M, p.Lq, (float *)p.out, dbg);
     else
         hipLaunchKernelGGL((quad_forward_kernel<bf16_t, 6, 2>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           total_qm, p.S, p.M, p.Lq, (bf16_t *)p.out);
+                           total_qm, p.S, p.M, p.Lq, (bf16_t *)p.out, dbg);
 }
 
 void launch_quad_backward(const Problem &p)

@@ -21,6 +21,8 @@ from . import msda
 
 # the autograd op; a module attribute so that CPU unit tests can substitute a checker
 msda_function = msda.MSDeformAttnFunction
+# use the fused sampling-geometry kernel on the GPU (tests switch it off to compare both routes)
+fused_geometry = True
 
 
 def _is_power_of_2(n):
@@ -87,6 +89,17 @@ class MSDeformAttn(nn.Module):
         qproj = F.linear(query,
                          torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
                          torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+        if (qproj.is_cuda and fused_geometry and L == 4 and P == 4 and reference_points.shape[-1] in (2, 4)
+                and qproj.dtype in (torch.float32, torch.bfloat16)):
+            # one HIP kernel instead of view + softmax + divide + add (+ their backward passes)
+            locations, weights = msda.SamplingGeometryFunction.apply(qproj, reference_points, input_spatial_shapes,
+                                                                     M, L, P)
+            if value.dtype == torch.float64:
+                locations, weights = locations.double(), weights.double()
+            output = msda_function.apply(value, input_spatial_shapes, input_level_start_index, locations, weights,
+                                         self.im2col_step)
+            return self.output_proj(output)
+        # the module's own arithmetic (also what the CPU unit tests exercise)
         offsets = qproj[..., :n_off].reshape(N, Len_q, M, L, P, 2)
         logits = qproj[..., n_off:].reshape(N, Len_q, M, L * P)
         if logits.dtype in (torch.bfloat16, torch.float16):

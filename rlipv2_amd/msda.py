@@ -149,3 +149,52 @@ class MSDeformAttnFunction(Function):
         g_value, g_loc, g_aw = ms_deform_attn_backward(value, shapes, starts, loc, aw, grad_output.contiguous(),
                                                        ctx.im2col_step)
         return g_value, None, None, g_loc, g_aw, None
+
+
+class SamplingGeometryFunction(Function):
+    """qproj [N, Lq, M*L*P*3] (offsets then logits), reference_points [N, Lq, L, 2|4] ->
+    (sampling_locations [N, Lq, M, L, P, 2], attention_weights [N, Lq, M, L, P]), both float32 -- the
+    view / softmax / normalise / add chain of the reference module (ms_deform_attn.py:101-112) as one
+    HIP kernel each way (csrc/msda_prep.hip).  L = P = 4."""
+
+    @staticmethod
+    def forward(ctx, qproj, reference_points, spatial_shapes, M, L, P):
+        if not qproj.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        lib = _lib.lib()
+        N, Lq, _ = qproj.shape
+        qproj = qproj.contiguous()
+        ref = reference_points.float().contiguous()
+        loc = torch.empty((N, Lq, M, L, P, 2), dtype=torch.float32, device=qproj.device)
+        aw = torch.empty((N, Lq, M, L, P), dtype=torch.float32, device=qproj.device)
+        with torch.cuda.device(qproj.device):
+            st = lib.msda_prepare_forward(_DTYPES[qproj.dtype], qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
+                                          spatial_shapes.data_ptr(), N * Lq, M, L, P, loc.data_ptr(), aw.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream)
+        if st:
+            _raise(st)
+        ctx.save_for_backward(qproj, ref, spatial_shapes, aw)
+        ctx.dims = (M, L, P)
+        ctx.ref_dtype = reference_points.dtype
+        return loc, aw
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loc, g_aw):
+        qproj, ref, spatial_shapes, aw = ctx.saved_tensors
+        M, L, P = ctx.dims
+        lib = _lib.lib()
+        N, Lq, _ = qproj.shape
+        g_qproj = torch.empty_like(qproj)
+        need_ref = ctx.needs_input_grad[1]
+        g_ref = torch.empty_like(ref) if need_ref else None
+        with torch.cuda.device(qproj.device):
+            st = lib.msda_prepare_backward(_DTYPES[qproj.dtype], qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
+                                           spatial_shapes.data_ptr(), aw.data_ptr(),
+                                           g_loc.float().contiguous().data_ptr(), g_aw.float().contiguous().data_ptr(),
+                                           N * Lq, M, L, P, g_qproj.data_ptr(),
+                                           g_ref.data_ptr() if need_ref else None,
+                                           torch.cuda.current_stream().cuda_stream)
+        if st:
+            _raise(st)
+        return g_qproj, (g_ref.to(ctx.ref_dtype) if need_ref else None), None, None, None, None

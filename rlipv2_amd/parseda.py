@@ -166,7 +166,7 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
         # ---- phase B --------------------------------------------------------------------------------
         bs = img_memory.shape[0]
         d = self.d_model
-        anchors = query_embed[..., 2 * d:].sigmoid()
+        anchors = query_embed[..., 2 * d:].float().sigmoid()        # the box chain stays in float32
         nq = query_embed.shape[0]
         ref_sub, ref_obj = anchors[:nq // 2], anchors[nq // 2:]
         tgt = query_embed[..., :d].unsqueeze(0).expand(bs, -1, -1)
@@ -302,8 +302,8 @@ class RLIP_ParSeDA(nn.Module):
             ref_s, ref_o = init_reference if lvl == 0 else inter_references[lvl - 1]
             sub_box.append((self.sub_bbox_embed[lvl](hs_h[lvl]) + inverse_sigmoid(ref_s)).sigmoid())
             obj_box.append((self.obj_bbox_embed[lvl](hs_o[lvl]) + inverse_sigmoid(ref_o)).sigmoid())
-            text = F.normalize(text_dec[lvl].transpose(0, 1), p=2, dim=-1)
-            proj = self.projection_text(text / 2.0)
+            text = F.normalize(text_dec[lvl].transpose(0, 1).float(), p=2, dim=-1)       # float32 norm
+            proj = self.projection_text((text / 2.0).to(self.projection_text.weight.dtype))
             assert n_obj + n_verb == proj.shape[1]
             obj_text, verb_text = proj[:, :n_obj], proj[:, n_obj:n_obj + n_verb]
             obj_cls.append(torch.matmul(hs_o[lvl] + self.bias_obj_a, obj_text.transpose(1, 2)) + self.bias_c)

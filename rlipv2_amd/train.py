@@ -117,6 +117,58 @@ def build_optimizer(model, lr=1.41e-4, lr_backbone=1.41e-5, text_encoder_lr=1.41
         return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
 
 
+class MasterWeightAdamW:
+    """AdamW over float32 master copies of a model whose parameters live in bfloat16.
+
+    bf16 precision policy of the train step: parameters, activations and
+    gradients are bfloat16 (no per-op autocast casts, half the elementwise traffic, bf16 gradient
+    all-reduce); the optimiser state and the weights it updates are float32; after each step the
+    master weights are rounded back into the model.  Clipping (max-norm 0.1, engine.py:170-171) is
+    applied to the float32 copies of the gradients.  Parameter groups by name as in main.py:523-539."""
+
+    def __init__(self, model, lr=1.41e-4, lr_backbone=1.41e-5, text_encoder_lr=1.41e-5, weight_decay=1e-4):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
+        self.master = [p.detach().float().clone().requires_grad_(True) for p in self.params]
+        self.gbuf = [torch.zeros_like(m) for m in self.master]
+        for m, g in zip(self.master, self.gbuf):
+            m.grad = g
+        by = lambda pred: [m for (n, _), m in zip(named, self.master) if pred(n)]
+        groups = [{"params": by(lambda n: "backbone" not in n and "text_encoder" not in n)},
+                  {"params": by(lambda n: "backbone" in n), "lr": lr_backbone},
+                  {"params": by(lambda n: "text_encoder" in n), "lr": text_encoder_lr}]
+        groups = [g for g in groups if g["params"]]
+        try:
+            self.opt = torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=True)
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+        self.param_groups = self.opt.param_groups
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self, max_norm=0.1):
+        have = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if len(have) != len(self.params):                       # a parameter without gradient this step
+            for i in set(range(len(self.params))) - set(have):
+                self.gbuf[i].zero_()
+        torch._foreach_copy_([self.gbuf[i] for i in have], [self.params[i].grad for i in have])
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.master, max_norm, foreach=True)
+        self.opt.step()
+        torch._foreach_copy_(self.params, self.master)
+
+
+def to_bf16(model):
+    """Parameters and buffers to bfloat16; the backbone additionally to channels-last."""
+    model.to(torch.bfloat16)
+    if hasattr(model, "backbone"):
+        model.backbone.to(memory_format=torch.channels_last)
+    return model
+
+
 def synthetic_batch(batch, height=800, width=1333, n_obj=43, n_verb=21, triplets=8, token_len=5, device="cuda:0",
                     seed=0):
     """images ~ N(0,1) (post-normalisation), no padding; 43 object labels (last = "no
@@ -147,9 +199,10 @@ def synthetic_batch(batch, height=800, width=1333, n_obj=43, n_verb=21, triplets
 
 def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_dtype=torch.bfloat16):
     """One optimisation step; returns the (device) loss.  No host synchronisation except the
-    matcher's single device->host copy of the cost matrices."""
+    matcher's single device->host copy of the cost matrices.  `autocast_dtype=None` runs the model
+    in whatever dtype its parameters have (float32, or bfloat16 with MasterWeightAdamW)."""
     samples, text, targets = batch
-    with torch.autocast("cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
+    with torch.autocast(samples.tensors.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
         outputs = step_module(samples, text, targets)
     outputs = {k: ([{kk: vv.float() for kk, vv in a.items()} for a in v] if k == "aux_outputs" else v.float())
                for k, v in outputs.items()}
@@ -157,8 +210,11 @@ def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_
     loss = criterion.weighted_sum(loss_dict)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
-    if max_norm > 0:
-        params = [p for g in optimizer.param_groups for p in g["params"]]
-        torch.nn.utils.clip_grad_norm_(params, max_norm, foreach=True)
-    optimizer.step()
+    if isinstance(optimizer, MasterWeightAdamW):
+        optimizer.step(max_norm)
+    else:
+        if max_norm > 0:
+            params = [p for g in optimizer.param_groups for p in g["params"]]
+            torch.nn.utils.clip_grad_norm_(params, max_norm, foreach=True)
+        optimizer.step()
     return loss.detach()

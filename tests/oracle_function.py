@@ -13,8 +13,9 @@ class OracleMSDeformAttnFunction(Function):
     @staticmethod
     def forward(ctx, value, shapes, starts, loc, aw, im2col_step):
         dt = np.float64 if value.dtype == torch.float64 else np.float32
-        a = [value.detach().numpy().astype(dt), shapes.numpy(), starts.numpy(), loc.detach().numpy().astype(dt),
-             aw.detach().numpy().astype(dt)]
+        tdt = torch.float64 if value.dtype == torch.float64 else torch.float32       # bf16 is upcast (exactly)
+        a = [value.detach().to(tdt).numpy(), shapes.numpy(), starts.numpy(), loc.detach().to(tdt).numpy(),
+             aw.detach().to(tdt).numpy()]
         ctx.args = a
         ctx.dtypes = (value.dtype, loc.dtype, aw.dtype)
         return torch.from_numpy(O.forward(*a)).to(value.dtype)
@@ -22,7 +23,7 @@ class OracleMSDeformAttnFunction(Function):
     @staticmethod
     def backward(ctx, grad_out):
         a = ctx.args
-        gv, gl, ga = O.backward(*a, grad_out.contiguous().numpy().astype(a[0].dtype))
+        gv, gl, ga = O.backward(*a, grad_out.contiguous().to(torch.from_numpy(a[0]).dtype).numpy())
         dv, dl, da = ctx.dtypes
         return (torch.from_numpy(gv).to(dv), None, None, torch.from_numpy(gl).to(dl), torch.from_numpy(ga).to(da),
                 None)

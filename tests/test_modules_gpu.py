@@ -128,3 +128,33 @@ def test_full_parseda_bf16_is_close_to_f32_reference():
         assert err < band, (k, err, band)
     sum(out[k].float().sum() for k in C.KEYS).backward()
     assert all(torch.isfinite(t.grad.float()).all() for t, _ in feats)
+
+
+@pytest.mark.parametrize("nd", [2, 4])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_sampling_geometry_equals_module_arithmetic(nd, dtype):
+    """csrc/msda_prep.hip against the module's own PyTorch arithmetic (the reference's formula,
+    ms_deform_attn.py:101-112): outputs and the gradients of query, value input and reference points."""
+    g = dev(C.load(f"msdeformattn_{nd}d"))
+    m = deform_attn.MSDeformAttn(256, 4, 8, 4)
+    fill_closed_form(m)
+    with torch.no_grad():
+        m.sampling_offsets.weight.mul_(0.3)
+    m = m.to(DEV).to(dtype)
+    shapes, starts = [t.to(DEV) for t in C.level_meta()]
+    res = {}
+    for fused in (False, True):
+        deform_attn.fused_geometry = fused
+        try:
+            query = g["query"].to(dtype).clone().requires_grad_(True)
+            inp = g["inp"].to(dtype).clone().requires_grad_(True)
+            ref = g["ref"].float().clone().requires_grad_(True)
+            out = m(query, ref, inp, shapes, starts, g["mask"])
+            out.backward(g["go"].to(dtype))
+            res[fused] = [t.float() for t in (out, query.grad, inp.grad, ref.grad)]
+        finally:
+            deform_attn.fused_geometry = True
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-4       # bf16: the unfused route rounds offsets/normaliser to bf16
+    for name, a, b in zip(("out", "g_query", "g_inp", "g_ref"), res[True], res[False]):
+        err = (a - b).abs().max().item() / max(1e-6, b.abs().max().item())
+        assert err < tol, (name, err)

@@ -203,6 +203,20 @@ def run_train_step_bench(args, world, rank, local_rank, device):
             step_module, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
             bucket_cap_mb=64)
     optimizer = train.MasterWeightAdamW(model) if master else train.build_optimizer(model)
+    graphed = False
+    eager_step = step_module
+    if world == 1 and args.graph and dtype is None:
+        # HIP-graph the two model phases (forward graph + backward graph); the criterion's host-side
+        # assignment and the optimiser stay eager.  Not used under DDP (cannot be validated on one GPU).
+        try:
+            train.freeze_parameters_without_gradient(step_module, criterion, batch)
+            step_module = train.graph_step_module(step_module, model, batch)
+            graphed = True
+        except Exception as e:                                  # noqa: BLE001 -- fall back to eager, say so
+            import traceback
+            tb = "".join(traceback.format_exception(type(e), e, e.__traceback__)[-8:])
+            print(f"[bench] graph capture failed, running eager: {type(e).__name__}\n{tb}", file=sys.stderr)
+            torch.cuda.synchronize()
     timer = KernelTimer()
     for _ in range(args.warmup):
         train.train_step(step_module, criterion, optimizer, batch, autocast_dtype=dtype)
@@ -225,11 +239,20 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if graphed and rank == 0:
+        # kernels inside a replayed graph cannot be bracketed with events: probe them in two eager steps
+        # of the very same train step (same model, batch, optimiser), right after the timed region
+        timer.enabled = True
+        for _ in range(2):
+            train.train_step(eager_step, criterion, optimizer, batch, autocast_dtype=dtype)
+        torch.cuda.synchronize()
+        timer.enabled = False
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    return elapsed, timer.summary(), float(loss), n_params
+    return elapsed, timer.summary(), float(loss), n_params, graphed
 
 
-def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls):
+def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None):
+    probe_steps = args.steps if probe_steps is None else probe_steps
     dominant = max(kern, key=lambda n: kern[n]["ms"])
     kd = kern[dominant]
     mean_s = kd["ms"] / kd["n"] * 1e-3
@@ -267,7 +290,8 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls)
             "traffic": None,
             "algorithmic_bytes_per_launch": kd["bytes"],
             "mean_launch_us": round(mean_s * 1e6, 2),
-            "msda_share_of_step": round(sum(k["ms"] for k in kern.values()) * 1e-3 / elapsed, 4),
+            "timing": probe_note or "HIP events on the launch stream around every call inside the timed region",
+            "msda_ms_per_step": round(sum(k["ms"] for k in kern.values()) / max(1, probe_steps), 3),
             "all_kernels": {n: {"mean_us": round(k["ms"] / k["n"] * 1e3, 2), "launches": k["n"],
                                 "GBps": round(k["bytes"] / (k["ms"] / k["n"] * 1e-3) / 1e9, 1)}
                             for n, k in sorted(kern.items())},
@@ -287,6 +311,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="train_step", choices=["train_step", "msda_step"])
     ap.add_argument("--queries", type=int, default=300)
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="do not capture the model phases as HIP graphs (single-GPU runs capture by default)")
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -308,7 +334,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     lib = _lib.lib()
     if args.workload == "train_step":
-        elapsed, kern, loss, n_params = run_train_step_bench(args, world, rank, local_rank, device)
+        elapsed, kern, loss, n_params, graphed = run_train_step_bench(args, world, rank, local_rank, device)
         if rank == 0:
             emit(args, world, elapsed, kern, lib, workload_text=(
                 "train_step: RLIP_ParSeDA_v2 R50 4-scale %d-query train step (fwd phase A+B, SetCriterionHOI, bwd, "
@@ -318,8 +344,13 @@ def main():
                                      ("bf16 parameters/activations/gradients with float32 master weights" if args.precision == "master"
                                       else "bf16 autocast over float32 weights") if args.dtype == "bf16" else "float32",
                                      n_params / 1e6, loss)),
-                 parallelism=f"dp{world} (RCCL gradient all-reduce, bucketed, overlapped with backward)",
-                 cpu_calls=lambda: build_msda_step(1, torch.float32, device, 0))
+                 parallelism=f"dp{world} (RCCL gradient all-reduce, bucketed, overlapped with backward)"
+                             + ("; model forward/backward replayed as HIP graphs" if graphed else "; eager launches"),
+                 cpu_calls=lambda: build_msda_step(1, torch.float32, device, 0),
+                 probe_steps=2 if graphed else None,
+                 probe_note=("HIP events around every MSDA call in 2 eager steps of the same train step run right after "
+                             "the timed region (the timed steps replay HIP graphs, whose kernels cannot be bracketed)")
+                 if graphed else None)
         if world > 1:
             dist.destroy_process_group()
         return

@@ -134,8 +134,14 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
             mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
             lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
                                  for l, p in enumerate(pos_embeds)], 1)
-            spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=src_flatten.device)
-            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            # device-resident int64 metadata, built once per pyramid shape (a host->device copy per step
+            # would also be illegal inside a HIP-graph capture)
+            key = (tuple(shapes_list), str(src_flatten.device))
+            cache = self.__dict__.setdefault("_shape_cache", {})
+            if key not in cache:
+                sp = torch.as_tensor(shapes_list, dtype=torch.long, device=src_flatten.device)
+                cache[key] = (sp, torch.cat((sp.new_zeros((1,)), sp.prod(1).cumsum(0)[:-1])))
+            spatial_shapes, level_start_index = cache[key]
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
             text_attention_mask, text_memory, obj_pred_names_sums = self._encode_text(text, bs, src_flatten.device)

@@ -251,6 +251,16 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     return elapsed, timer.summary(), float(loss), n_params, graphed
 
 
+def pmc_traffic(kernel_key, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_msda.json; separate FETCH_SIZE / WRITE_SIZE runs of the same kernels, gfx950
+    correction applied there).  Only valid for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_msda.json")
+    if args.dtype != "bf16" or args.batch != 4 or not os.path.exists(path):
+        return None
+    return json.load(open(path))["traffic_bytes_per_launch"].get(kernel_key)
+
+
 def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None):
     probe_steps = args.steps if probe_steps is None else probe_steps
     dominant = max(kern, key=lambda n: kern[n]["ms"])
@@ -287,7 +297,7 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(dominant, args),
             "algorithmic_bytes_per_launch": kd["bytes"],
             "mean_launch_us": round(mean_s * 1e6, 2),
             "timing": probe_note or "HIP events on the launch stream around every call inside the timed region",

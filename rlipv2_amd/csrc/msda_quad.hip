@@ -31,58 +31,119 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kL = 4, kP = 4, kLP = 16, kD = 32;
 
-// Bilinear set-up of one sample for one lane.  Offsets are in elements relative to the image
-// base and already include the head and this lane's channel group.
-struct Corner4 {
-    int o1, o2, o3, o4;
-    float hh, hw, lh, lw;      // raw fractional weights
-    bool ok1, ok2, ok3, ok4;   // corner inside the level (and sample included)
-    float wgt;                 // attention weight, 0 when the sample is excluded
+// ---- sample geometry --------------------------------------------------------------------------------
+// Addressing is done with buffer loads: a 32-bit byte offset from the tensor base in a wave-uniform
+// resource descriptor (no 64-bit VALU address arithmetic), 24-bit integer multiplies, and the
+// hardware's range check -- a corner outside the level gets the offset kOob, which is beyond
+// num_records and therefore loads zeros.  So there is no clamping and no per-corner weight
+// masking: weight * 0 is the zero padding of the reference (ms_deform_im2col_cuda.cuh:58-78).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFFF00u;
+
+struct Corners {
+    unsigned o00, o01, o10, o11;    // byte offsets (or kOob) of (y0,x0) (y0,x1) (y1,x0) (y1,x1)
+    float hh, hw, lh, lw;           // bilinear fractions
+    bool v00, v01, v10, v11;        // corner inside the level
 };
 
-__device__ __forceinline__ Corner4 setup_sample(float x, float y, float w, int H, int W, int start, int M,
-                                                int head_chan /* m*D + sub*8 */)
+// (x, y) normalised -> corners of level (H, W, start).  `lane_byte` = image base + head/channel offset.
+// Pixel coordinates are clamped to [-2, size + 1] first: every out-of-range (or NaN / Inf) location
+// then has all its corners out of the level, with finite fractions.
+template <int ELEM>
+__device__ __forceinline__ Corners corners_of(float x, float y, int H, int W, int start, int row_bytes,
+                                               unsigned lane_byte)
 {
-    Corner4 c;
-    const float h_im = fmaf(y, (float)H, -0.5f);
-    const float w_im = fmaf(x, (float)W, -0.5f);
-    const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
-    const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;
-    const float hf = floorf(hs), wf = floorf(ws);
-    const int h_low = (int)hf, w_low = (int)wf;
-    c.lh = hs - hf; c.lw = ws - wf;
-    c.hh = 1.f - c.lh; c.hw = 1.f - c.lw;
-    const bool hl = h_low >= 0, hh_ok = h_low + 1 <= H - 1, wl = w_low >= 0, wh = w_low + 1 <= W - 1;
-    c.ok1 = inside && hl && wl;    c.ok2 = inside && hl && wh;
-    c.ok3 = inside && hh_ok && wl; c.ok4 = inside && hh_ok && wh;
-    c.wgt = inside ? w : 0.f;
-    const int rl = start + max(h_low, 0) * W, rh = start + min(h_low + 1, H - 1) * W;
-    const int cl = max(w_low, 0), ch = min(w_low + 1, W - 1);
-    const int row = M * kD;
-    c.o1 = (rl + cl) * row + head_chan; c.o2 = (rl + ch) * row + head_chan;
-    c.o3 = (rh + cl) * row + head_chan; c.o4 = (rh + ch) * row + head_chan;
+    Corners c;
+    const float Hf = (float)H, Wf = (float)W;
+    float h = fmaf(y, Hf, -0.5f), w = fmaf(x, Wf, -0.5f);
+    h = fminf(fmaxf(h, -2.f), Hf + 1.f);
+    w = fminf(fmaxf(w, -2.f), Wf + 1.f);
+    const float hf = floorf(h), wf = floorf(w);
+    c.lh = h - hf; c.lw = w - wf; c.hh = 1.f - c.lh; c.hw = 1.f - c.lw;
+    const int ih = (int)hf, iw = (int)wf;
+    const bool y0 = (unsigned)ih < (unsigned)H, y1 = (unsigned)(ih + 1) < (unsigned)H;
+    const bool x0 = (unsigned)iw < (unsigned)W, x1 = (unsigned)(iw + 1) < (unsigned)W;
+    c.v00 = y0 && x0; c.v01 = y0 && x1; c.v10 = y1 && x0; c.v11 = y1 && x1;
+    const int pix = start + __mul24(ih, W) + iw;                       // may be off-level: masked below
+    const unsigned o = (unsigned)__mul24(pix, row_bytes) + lane_byte;
+    const unsigned down = (unsigned)__mul24(W, row_bytes);
+    c.o00 = c.v00 ? o : kOob;
+    c.o01 = c.v01 ? o + row_bytes : kOob;
+    c.o10 = c.v10 ? o + down : kOob;
+    c.o11 = c.v11 ? o + down + row_bytes : kOob;
     return c;
+}
+
+// XCD-aware block order: hardware block b runs on XCD b % 8 (observed, MI355X_MICROARCH.md); give every
+// XCD one contiguous eighth of the (image, query) range so that its private L2 fetches only the value
+// rows that eighth samples.  Measured with the round-robin order: FETCH_SIZE 379 MB per batch-4 encoder
+// forward against 182 MB of algorithmic reads -- every XCD pulled the whole value tensor through its own L2.
+// Bijective for any grid size; placement only affects speed.
+__device__ __forceinline__ int xcd_block_id()
+{
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// 8 channels of one corner through the buffer descriptor
+template <typename VT> struct Corner8;
+template <> struct Corner8<float> {
+    struct raw { u32x4 a, b; };
+    static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, unsigned off)
+    {
+        raw v;
+        v.a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        v.b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 0);   // kOob + 16 is still out of range
+        return v;
+    }
+    static __device__ __forceinline__ void unpack(const raw &v, float (&f)[8])
+    {
+        f[0] = __uint_as_float(v.a.x); f[1] = __uint_as_float(v.a.y); f[2] = __uint_as_float(v.a.z);
+        f[3] = __uint_as_float(v.a.w); f[4] = __uint_as_float(v.b.x); f[5] = __uint_as_float(v.b.y);
+        f[6] = __uint_as_float(v.b.z); f[7] = __uint_as_float(v.b.w);
+    }
+};
+template <> struct Corner8<bf16_t> {
+    typedef u32x4 raw;
+    static __device__ __forceinline__ raw load(__amdgpu_buffer_rsrc_t r, unsigned off)
+    {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    }
+    static __device__ __forceinline__ void unpack(const raw &v, float (&f)[8])
+    {
+        f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+        f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+    }
+};
+
+template <typename VT>
+__device__ __forceinline__ void fma8(float w, const typename Corner8<VT>::raw &r, float (&acc)[8])
+{
+    float f[8];
+    Corner8<VT>::unpack(r, f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, f[k], acc[k]);
 }
 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-// One sample: 4 corner rows of this lane's 8 channels, folded into acc.
+// One sample: 4 corner rows of this lane's 8 channels, folded into acc.  The reference's sample-level
+// inclusion test (.cuh:285) is implied: a location outside (-1, size) has no corner inside the level.
 template <typename VT>
-__device__ __forceinline__ void fwd_sample(const VT *__restrict__ vimg, float x, float y, float w, int H, int W,
-                                           int start, int M, int head_chan, float (&acc)[8])
+__device__ __forceinline__ void fwd_sample(__amdgpu_buffer_rsrc_t vr, float x, float y, float w, int H, int W,
+                                           int start, int row_bytes, unsigned lane_byte, float (&acc)[8])
 {
-    const Corner4 c = setup_sample(x, y, w, H, W, start, M, head_chan);
-    const float a_h = c.hh * c.wgt, b_h = c.lh * c.wgt;
-    const float w1 = c.ok1 ? a_h * c.hw : 0.f, w2 = c.ok2 ? a_h * c.lw : 0.f;
-    const float w3 = c.ok3 ? b_h * c.hw : 0.f, w4 = c.ok4 ? b_h * c.lw : 0.f;
+    const Corners c = corners_of<sizeof(VT)>(x, y, H, W, start, row_bytes, lane_byte);
     // issue the four corner loads back to back, then fold them in arrival order
-    typename Vec8<VT>::raw r1 = Vec8<VT>::load_raw(vimg + c.o1), r2 = Vec8<VT>::load_raw(vimg + c.o2);
-    typename Vec8<VT>::raw r3 = Vec8<VT>::load_raw(vimg + c.o3), r4 = Vec8<VT>::load_raw(vimg + c.o4);
-    Vec8<VT>::fma(w1, r1, acc);
-    Vec8<VT>::fma(w2, r2, acc);
-    Vec8<VT>::fma(w3, r3, acc);
-    Vec8<VT>::fma(w4, r4, acc);
+    const typename Corner8<VT>::raw r00 = Corner8<VT>::load(vr, c.o00), r01 = Corner8<VT>::load(vr, c.o01);
+    const typename Corner8<VT>::raw r10 = Corner8<VT>::load(vr, c.o10), r11 = Corner8<VT>::load(vr, c.o11);
+    const float a = c.hh * w, b = c.lh * w;
+    fma8<VT>(a * c.hw, r00, acc);
+    fma8<VT>(a * c.lw, r01, acc);
+    fma8<VT>(b * c.hw, r10, acc);
+    fma8<VT>(b * c.lw, r11, acc);
 }
 
 // rotate the quad's per-lane sample data by one lane: lane j takes lane j+1's registers, so that
@@ -100,18 +161,20 @@ template <typename VT, int WAVES, int FENCE>
 __global__ __launch_bounds__(kBlock, WAVES) void quad_forward_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ aw, int total_qm, int S, int M, int Lq,
-    VT *__restrict__ out, int dbg)
+    unsigned value_bytes, VT *__restrict__ out, int dbg)
 {
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int t = xcd_block_id() * kBlock + threadIdx.x;
     int qm = t >> 2;
     const int sub = t & 3;
     const bool live = qm < total_qm;
     qm = live ? qm : total_qm - 1;   // keep whole quads converged for the DPP broadcasts
     const int m = qm % M;
     const int n = (qm / M) / Lq;
-    const VT *vimg = value + (long)n * S * M * kD;
-    const int head_chan = m * kD + sub * 8;
-    if (dbg & 1) M = 0;          // ablation: every gather hits the head's first rows (cache-resident)
+    int row_bytes = M * kD * (int)sizeof(VT);
+    const unsigned lane_byte = (unsigned)n * (unsigned)S * (unsigned)row_bytes
+                               + (unsigned)(m * kD + sub * 8) * (unsigned)sizeof(VT);
+    if (dbg & 1) row_bytes = 0;      // ablation: every gather hits the head's first rows (cache-resident)
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)value, 0, value_bytes, 0x00020000);
     // quad lane j loads the 4 points of level j: (x,y) x 4 and 4 weights
     const float4 *loc4 = reinterpret_cast<const float4 *>(loc) + (long)qm * 8 + sub * 2;
     float4 la = loc4[0], lb = loc4[1];
@@ -120,13 +183,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_forward_kernel(
 #pragma unroll 1
     for (int l = 0; l < kL; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
-        fwd_sample<VT>(vimg, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start, M, head_chan, acc);
+        fwd_sample<VT>(vr, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start, row_bytes, lane_byte, acc);
         if (FENCE == 1) __builtin_amdgcn_sched_barrier(0);
-        fwd_sample<VT>(vimg, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start, M, head_chan, acc);
+        fwd_sample<VT>(vr, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start, row_bytes, lane_byte, acc);
         if (FENCE <= 2) __builtin_amdgcn_sched_barrier(0);
-        fwd_sample<VT>(vimg, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, M, head_chan, acc);
+        fwd_sample<VT>(vr, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, row_bytes, lane_byte, acc);
         if (FENCE == 1) __builtin_amdgcn_sched_barrier(0);
-        fwd_sample<VT>(vimg, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, M, head_chan, acc);
+        fwd_sample<VT>(vr, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, row_bytes, lane_byte, acc);
         quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
     }
     if (live) Vec8<VT>::store(out + (long)qm * kD + sub * 8, acc);
@@ -152,32 +215,37 @@ __device__ __forceinline__ void scatter8(float *__restrict__ g, float w, const f
 // One sample of the backward pass.  Returns (d out / d attn_weight, d out / d x, d out / d y)
 // contracted with grad_out, identical in all four lanes of the quad.
 template <typename VT, bool SCATTER>
-__device__ __forceinline__ void bwd_sample(const VT *__restrict__ vimg, float *__restrict__ gimg, float x, float y,
-                                           float w, int H, int W, int start, int M, int head_chan, bool live,
-                                           const float (&tg)[8], float &g_a, float &g_w, float &g_h)
+__device__ __forceinline__ void bwd_sample(__amdgpu_buffer_rsrc_t vr, float *__restrict__ gbase, float x, float y,
+                                           float w, int H, int W, int start, int row_bytes, unsigned lane_byte,
+                                           bool live, const float (&tg)[8], float &g_a, float &g_w, float &g_h)
 {
-    const Corner4 c = setup_sample(x, y, w, H, W, start, M, head_chan);
-    float v1[8], v2[8], v3[8], v4[8];
-    Vec8<VT>::load(vimg + c.o1, v1);
-    Vec8<VT>::load(vimg + c.o2, v2);
-    Vec8<VT>::load(vimg + c.o3, v3);
-    Vec8<VT>::load(vimg + c.o4, v4);
-    // grad_value: w_k * attn * grad_out, 8 channels per corner per lane
-    const float a_h = c.hh * c.wgt, b_h = c.lh * c.wgt;
+    const Corners c = corners_of<sizeof(VT)>(x, y, H, W, start, row_bytes, lane_byte);
+    const typename Corner8<VT>::raw r00 = Corner8<VT>::load(vr, c.o00), r01 = Corner8<VT>::load(vr, c.o01);
+    const typename Corner8<VT>::raw r10 = Corner8<VT>::load(vr, c.o10), r11 = Corner8<VT>::load(vr, c.o11);
+    // the reference drops a sample whose pixel coordinate is not inside (-1, size) (.cuh:285); for the
+    // value that is implied by the corner range checks, for the location gradient at the exact
+    // boundary it is not, so the backward pass keeps the explicit test
+    const float h_im = fmaf(y, (float)H, -0.5f), w_im = fmaf(x, (float)W, -0.5f);
+    const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+    const float wgt = inside ? w : 0.f;
     if (SCATTER && live) {
-        if (c.ok1) scatter8(gimg + c.o1, a_h * c.hw, tg);
-        if (c.ok2) scatter8(gimg + c.o2, a_h * c.lw, tg);
-        if (c.ok3) scatter8(gimg + c.o3, b_h * c.hw, tg);
-        if (c.ok4) scatter8(gimg + c.o4, b_h * c.lw, tg);
+        // grad_value: w_k * attn * grad_out, 8 channels per corner per lane (reference-style direct scatter)
+        const float a = c.hh * wgt, b = c.lh * wgt;
+        const int esz = (int)sizeof(VT);
+        if (c.v00) scatter8(gbase + c.o00 / esz, a * c.hw, tg);
+        if (c.v01) scatter8(gbase + c.o01 / esz, a * c.lw, tg);
+        if (c.v10) scatter8(gbase + c.o10 / esz, b * c.hw, tg);
+        if (c.v11) scatter8(gbase + c.o11 / esz, b * c.lw, tg);
     }
-    // channel reductions: 8 channels in-lane, then across the quad with DPP
-    const float e1 = quad_sum(c.ok1 ? dot8(tg, v1) : 0.f);
-    const float e2 = quad_sum(c.ok2 ? dot8(tg, v2) : 0.f);
-    const float e3 = quad_sum(c.ok3 ? dot8(tg, v3) : 0.f);
-    const float e4 = quad_sum(c.ok4 ? dot8(tg, v4) : 0.f);
-    g_a = c.hh * (c.hw * e1 + c.lw * e2) + c.lh * (c.hw * e3 + c.lw * e4);
-    g_w = (float)W * c.wgt * (c.hh * (e2 - e1) + c.lh * (e4 - e3));
-    g_h = (float)H * c.wgt * (c.hw * (e3 - e1) + c.lw * (e4 - e2));
+    // channel reductions: 8 channels in-lane, then across the quad with DPP (out-of-level corners read zeros)
+    float f[8];
+    Corner8<VT>::unpack(r00, f); const float e1 = quad_sum(dot8(tg, f));
+    Corner8<VT>::unpack(r01, f); const float e2 = quad_sum(dot8(tg, f));
+    Corner8<VT>::unpack(r10, f); const float e3 = quad_sum(dot8(tg, f));
+    Corner8<VT>::unpack(r11, f); const float e4 = quad_sum(dot8(tg, f));
+    g_a = inside ? c.hh * (c.hw * e1 + c.lw * e2) + c.lh * (c.hw * e3 + c.lw * e4) : 0.f;
+    g_w = (float)W * wgt * (c.hh * (e2 - e1) + c.lh * (e4 - e3));
+    g_h = (float)H * wgt * (c.hw * (e3 - e1) + c.lw * (e4 - e2));
 }
 
 // SCATTER = false: only grad_sampling_loc / grad_attn_weight ("K1"; grad_value is then produced by
@@ -186,19 +254,20 @@ template <typename VT, int WAVES, bool SCATTER>
 __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ aw, const VT *__restrict__ grad_out, int total_qm,
-    int S, int M, int Lq, float *__restrict__ g_value, float *__restrict__ g_loc, float *__restrict__ g_aw)
+    int S, int M, int Lq, unsigned value_bytes, float *__restrict__ g_value, float *__restrict__ g_loc,
+    float *__restrict__ g_aw)
 {
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int t = xcd_block_id() * kBlock + threadIdx.x;
     int qm = t >> 2;
     const int sub = t & 3;
     const bool live = qm < total_qm;
     qm = live ? qm : total_qm - 1;
     const int m = qm % M;
     const int n = (qm / M) / Lq;
-    const long img = (long)n * S * M * kD;
-    const VT *vimg = value + img;
-    float *gimg = g_value + img;
-    const int head_chan = m * kD + sub * 8;
+    const int row_bytes = M * kD * (int)sizeof(VT);
+    const unsigned lane_byte = (unsigned)n * (unsigned)S * (unsigned)row_bytes
+                               + (unsigned)(m * kD + sub * 8) * (unsigned)sizeof(VT);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)value, 0, value_bytes, 0x00020000);
     const float4 *loc4 = reinterpret_cast<const float4 *>(loc) + (long)qm * 8 + sub * 2;
     float4 la = loc4[0], lb = loc4[1];
     float4 wa = reinterpret_cast<const float4 *>(aw)[(long)qm * 4 + sub];
@@ -209,17 +278,17 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_kernel(
     for (int l = 0; l < kL; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
         float4 ra, rb, rw;   // this level's results: (gx,gy) x 4 points, g_aw x 4 points
-        bwd_sample<VT, SCATTER>(vimg, gimg, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start, M,
-                       head_chan, live, tg, rw.x, ra.x, ra.y);
+        bwd_sample<VT, SCATTER>(vr, g_value, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start,
+                                row_bytes, lane_byte, live, tg, rw.x, ra.x, ra.y);
         __builtin_amdgcn_sched_barrier(0);
-        bwd_sample<VT, SCATTER>(vimg, gimg, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start, M,
-                       head_chan, live, tg, rw.y, ra.z, ra.w);
+        bwd_sample<VT, SCATTER>(vr, g_value, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start,
+                                row_bytes, lane_byte, live, tg, rw.y, ra.z, ra.w);
         __builtin_amdgcn_sched_barrier(0);
-        bwd_sample<VT, SCATTER>(vimg, gimg, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, M,
-                       head_chan, live, tg, rw.z, rb.x, rb.y);
+        bwd_sample<VT, SCATTER>(vr, g_value, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start,
+                                row_bytes, lane_byte, live, tg, rw.z, rb.x, rb.y);
         __builtin_amdgcn_sched_barrier(0);
-        bwd_sample<VT, SCATTER>(vimg, gimg, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, M,
-                       head_chan, live, tg, rw.w, rb.z, rb.w);
+        bwd_sample<VT, SCATTER>(vr, g_value, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start,
+                                row_bytes, lane_byte, live, tg, rw.w, rb.z, rb.w);
         if (sub == l) { gla = ra; glb = rb; ga = rw; }   // quad lane l owns level l's outputs
         quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
     }
@@ -233,8 +302,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_kernel(
 
 }  // namespace
 
+static unsigned value_bytes(const Problem &p)
+{
+    return (unsigned)((size_t)p.N * p.S * p.M * kD * (p.dtype == MSDA_F32 ? 4 : 2));
+}
+
 bool quad_supports(const Problem &p)
 {
+    // buffer addressing: the whole value tensor within 32-bit byte offsets, below the kOob sentinel
+    if ((size_t)p.N * p.S * p.M * kD * (p.dtype == MSDA_F32 ? 4 : 2) >= 0xFFFFFF00ull - 64) return false;
+    if ((long)p.S + 1 >= (1L << 23) || (long)p.M * kD * 4 >= (1L << 23)) return false;   // 24-bit multiplies
     if (p.dtype != MSDA_F32 && p.dtype != MSDA_BF16) return false;
     if (p.D != kD || p.L != kL || p.P != kP) return false;
     const long total_qm = (long)p.N * p.Lq * p.M;
@@ -252,11 +329,11 @@ void launch_quad_forward(const Problem &p)
     if (p.dtype == MSDA_F32)
         hipLaunchKernelGGL((quad_forward_kernel<float, 6, 2>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           total_qm, p.S, p.M, p.Lq, (float *)p.out, dbg);
+                           total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.out, dbg);
     else
-        hipLaunchKernelGGL((quad_forward_kernel<bf16_t, 6, 2>), dim3(grid), dim3(kBlock), 0, p.stream,
+        hipLaunchKernelGGL((quad_forward_kernel<bf16_t, 5, 2>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           total_qm, p.S, p.M, p.Lq, (bf16_t *)p.out, dbg);
+                           total_qm, p.S, p.M, p.Lq, value_bytes(p), (bf16_t *)p.out, dbg);
 }
 
 void launch_quad_backward(const Problem &p)
@@ -266,12 +343,12 @@ void launch_quad_backward(const Problem &p)
     if (p.dtype == MSDA_F32)
         hipLaunchKernelGGL((quad_backward_kernel<float, 3, true>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, (float *)p.g_value,
+                           (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_value,
                            (float *)p.g_loc, (float *)p.g_aw);
     else
         hipLaunchKernelGGL((quad_backward_kernel<bf16_t, 4, true>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, (float *)p.g_value,
+                           (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_value,
                            (float *)p.g_loc, (float *)p.g_aw);
 }
 
@@ -282,12 +359,12 @@ void launch_quad_backward_reduce(const Problem &p)
     if (p.dtype == MSDA_F32)
         hipLaunchKernelGGL((quad_backward_kernel<float, 4, false>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, (float *)p.g_value,
+                           (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_value,
                            (float *)p.g_loc, (float *)p.g_aw);
     else
         hipLaunchKernelGGL((quad_backward_kernel<bf16_t, 4, false>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, (float *)p.g_value,
+                           (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_value,
                            (float *)p.g_loc, (float *)p.g_aw);
 }
 

@@ -201,6 +201,16 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
         return hs_ho, hs_verb, text_dec, init_reference, inter_refs, hs_ho, hs_verb, None, None
 
 
+def _add_reference(delta, ref):
+    """box head output + inverse_sigmoid(reference): all 4 coordinates for a reference box, only (x, y)
+    for a 2-d reference point (reference hoi.py:2122-2138 / :3040-3056)."""
+    inv = inverse_sigmoid(ref)
+    if ref.shape[-1] == 4:
+        return delta + inv
+    assert ref.shape[-1] == 2
+    return torch.cat([delta[..., :2] + inv, delta[..., 2:].to(inv.dtype)], dim=-1)
+
+
 class RLIP_ParSeDA(nn.Module):
     def __init__(self, backbone, transformer, num_queries, num_feature_levels, aux_loss=True, with_box_refine=True,
                  two_stage=False, use_dab=True, num_patterns=0, random_refpoints_xy=False, subject_class=False,
@@ -266,6 +276,17 @@ class RLIP_ParSeDA(nn.Module):
         self.pseudo_verb = pseudo_verb
         self.pseudo_verb_mode = "online"
 
+    def _query_embeds(self):
+        return torch.cat((self.tgt_embed.weight, self.verb_tgt_embed.weight, self.refpoint_embed.weight), 1)
+
+    def _transformer_phase_b(self, mc):
+        return self.transformer(
+            masks=mc["masks"], query_embed=mc["ho_query_embed"], encode_and_save=False,
+            text_memory=mc["text_memory_resized"], img_memory=mc["img_memory"],
+            text_attention_mask=mc["text_attention_mask"], obj_pred_names_sums=mc["obj_pred_names_sums"],
+            spatial_shapes=mc["spatial_shapes"], level_start_index=mc["level_start_index"],
+            valid_ratios=mc["valid_ratios"])
+
     # ---- phase A: backbone + input projections + ALIF encoder -------------------------------------------
     def _encode(self, samples, text):
         features, pos = self.backbone(samples)
@@ -281,7 +302,7 @@ class RLIP_ParSeDA(nn.Module):
             pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
             srcs.append(src)
             masks.append(mask)
-        query_embeds = torch.cat((self.tgt_embed.weight, self.verb_tgt_embed.weight, self.refpoint_embed.weight), 1)
+        query_embeds = self._query_embeds()
         return self.transformer(srcs=srcs, masks=masks, pos_embeds=pos, query_embed=query_embeds, text=text,
                                 encode_and_save=True)
 
@@ -292,12 +313,7 @@ class RLIP_ParSeDA(nn.Module):
             return self._encode(samples, kwargs['text'])
 
         mc = memory_cache
-        hs_ho, hs_verb, text_dec, init_reference, inter_references, _, _, _, _ = self.transformer(
-            masks=mc["masks"], query_embed=mc["ho_query_embed"], encode_and_save=False,
-            text_memory=mc["text_memory_resized"], img_memory=mc["img_memory"],
-            text_attention_mask=mc["text_attention_mask"], obj_pred_names_sums=mc["obj_pred_names_sums"],
-            spatial_shapes=mc["spatial_shapes"], level_start_index=mc["level_start_index"],
-            valid_ratios=mc["valid_ratios"])
+        hs_ho, hs_verb, text_dec, init_reference, inter_references, _, _, _, _ = self._transformer_phase_b(mc)
         half = self.num_queries // 2
         hs_h, hs_o = hs_ho[:, :, :half], hs_ho[:, :, half:]
         sums = mc["obj_pred_names_sums"]
@@ -306,8 +322,8 @@ class RLIP_ParSeDA(nn.Module):
         sub_cls, obj_cls, verb_cls, sub_box, obj_box = [], [], [], [], []
         for lvl in range(hs_h.shape[0]):
             ref_s, ref_o = init_reference if lvl == 0 else inter_references[lvl - 1]
-            sub_box.append((self.sub_bbox_embed[lvl](hs_h[lvl]) + inverse_sigmoid(ref_s)).sigmoid())
-            obj_box.append((self.obj_bbox_embed[lvl](hs_o[lvl]) + inverse_sigmoid(ref_o)).sigmoid())
+            sub_box.append(_add_reference(self.sub_bbox_embed[lvl](hs_h[lvl]), ref_s).sigmoid())
+            obj_box.append(_add_reference(self.obj_bbox_embed[lvl](hs_o[lvl]), ref_o).sigmoid())
             text = F.normalize(text_dec[lvl].transpose(0, 1).float(), p=2, dim=-1)       # float32 norm
             proj = self.projection_text((text / 2.0).to(self.projection_text.weight.dtype))
             assert n_obj + n_verb == proj.shape[1]

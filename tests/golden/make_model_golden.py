@@ -9,6 +9,7 @@ Goldens (tests/golden/model_*.npz), all in eval() mode and float3
   encoder                 RLIPv2_DeformableTransformerEncoder, 2 layers / 1 fusion, fusion_last_vis on and off
   decoder_ho / _verb      DABDeformableTransformerDecoderHOI ParSe=True / False, 2 layers, box refine
   mbf                     MultiBranchFusion
+  parsed                  full RLIP_ParSeD v2 (config-1 family: non-DAB decoders, XGating), outputs + aux + gradients
   criterion               SetCriterionHOI + HungarianMatcherHOI loss dict and gradients for fixed predictions
   parseda                 full RLIP_ParSeDA (enc 4 / dec 2, nq 20, 12 texts, two images of different
                           size): all outputs + aux, and gradients w.r.t. the input features and a few
@@ -355,6 +356,69 @@ def gold_criterion():
     save("criterion", **rec)
 
 
+def gold_parsed():
+    """RLIP_ParSeD (v2), the non-DAB sibling used by BASELINE config 1 (models/hoi.py:2840,
+    models/ParSetransformer.py:404): XGating, learned query positions, 2-d reference points."""
+    from models.ParSetransformer import RLIP_ParSeDTransformer_v2
+    from models.hoi import RLIP_ParSeD
+    from util.misc import NestedTensor
+    args = R.reference_args(num_queries=20, enc_layers=4, dec_layers=2, dim_feedforward=512, pseudo_verb=False,
+                            gating_mechanism="XGating", RLIP_ParSeDA_v2=False, RLIP_ParSeD_v2=True, use_dab=False)
+    args.use_checkpoint_fusion = False
+    args.verb_tagger = False
+    tr = RLIP_ParSeDTransformer_v2(
+        d_model=256, nhead=8, num_encoder_layers=4, num_decoder_layers=2, dim_feedforward=512, dropout=0.0,
+        activation="relu", return_intermediate_dec=True, num_feature_levels=4, dec_n_points=4, enc_n_points=4,
+        two_stage=False, two_stage_num_proposals=20, args=args)
+    bb = R.StandInBackbone(num_channels=(32, 64, 128))
+    model = RLIP_ParSeD(bb, tr, num_queries=20, num_feature_levels=4, aux_loss=True, with_box_refine=True,
+                        two_stage=False, subject_class=True, pseudo_verb=False, args=args).eval()
+    R.fill_closed_form(model)
+    with torch.no_grad():
+        for mod in model.modules():
+            if mod.__class__.__name__ == "MSDeformAttn":
+                mod.sampling_offsets.weight.mul_(0.3)
+    N, H, W = 2, 64, 96
+    img_hw = [(64, 96), (56, 72)]
+    img_mask = torch.ones(N, H, W, dtype=torch.bool)
+    for n, (h, w) in enumerate(img_hw):
+        img_mask[n, :h, :w] = False
+    feats = []
+    for i, (c, s_) in enumerate(zip((32, 64, 128), (8, 16, 32))):
+        t = rng_tensor(160 + i, N, c, H // s_, W // s_).requires_grad_(True)
+        m = torch.nn.functional.interpolate(img_mask[None].float(), size=t.shape[-2:]).to(torch.bool)[0]
+        feats.append((t, m))
+    bb.features = feats
+    samples = NestedTensor(torch.zeros(N, 3, H, W), img_mask)
+    n_obj, n_verb = 7, 5
+    text_mem = torch.tanh(rng_tensor(170, n_obj + n_verb, 1, 768)).repeat(1, N, 1)
+    text_mask = ~(text_mem.sum(-1) > 0)
+    sums = torch.tensor([[n_obj, n_verb]])
+    mc = model(samples, encode_and_save=True, text=(text_mask, text_mem, sums), targets=None)
+    out = model(samples, encode_and_save=False, memory_cache=mc, text=(text_mask, text_mem, sums), targets=None)
+    keys = ["pred_sub_logits", "pred_obj_logits", "pred_verb_logits", "pred_sub_boxes", "pred_obj_boxes"]
+    loss = 0
+    rec = {}
+    for i, k in enumerate(keys):
+        gk = rng_tensor(180 + i, *out[k].shape)
+        loss = loss + (out[k] * gk).sum() + (out["aux_outputs"][0][k] * gk).sum() * 0.5
+        rec["g_" + k] = gk
+        rec[k] = out[k]
+        rec["aux0_" + k] = out["aux_outputs"][0][k]
+    loss.backward()
+    for i, (t, m) in enumerate(feats):
+        rec[f"feat{i}"] = t
+        rec[f"featmask{i}"] = m
+        rec[f"g_feat{i}"] = t.grad
+    rec["img_mask"], rec["text_mem"], rec["text_mask"] = img_mask, text_mem, text_mask
+    sd = dict(model.named_parameters(remove_duplicate=False))
+    for name in ("query_embed.weight", "transformer.reference_points_sub.weight", "transformer.verb_query_embed.weight",
+                 "transformer.ho_encoder.layers.0.linear1.weight"):
+        rec["gparam_" + name.replace(".", "__")] = sd[name].grad
+    rec["param_names"] = np.array(sorted(sd.keys()))
+    save("parsed", **rec)
+
+
 def main():
     R.install()
     torch.manual_seed(0)
@@ -366,6 +430,7 @@ def main():
     gold_mbf()
     gold_parseda()
     gold_criterion()
+    gold_parsed()
 
 
 if __name__ == "__main__":

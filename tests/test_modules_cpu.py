@@ -303,3 +303,83 @@ def test_criterion_and_matcher_match_reference():
         for k in o:
             if k.startswith("pred_"):
                 close(o[k].grad, g[f"g_L{li}_{k}"], 1e-4, 1e-6, f"grad L{li} {k}")
+
+
+def build_small_parsed():
+    from rlipv2_amd import parsed
+    args = parseda.default_args(num_queries=20, enc_layers=4, dec_layers=2, dim_feedforward=512, pseudo_verb=False,
+                                gating_mechanism="XGating")
+    bb = _FeatureBackbone((32, 64, 128))
+    model = parsed.build_parsed(bb, args).eval()
+    fill_closed_form(model)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, deform_attn.MSDeformAttn):
+                mod.sampling_offsets.weight.mul_(0.3)
+    return model, bb
+
+
+def run_small_parsed(model, bb, g, device="cpu"):
+    feats = [(g[f"feat{i}"].to(device).clone().requires_grad_(True), g[f"featmask{i}"].to(device)) for i in range(3)]
+    bb.features = feats
+    samples = blocks.NestedTensor(torch.zeros(2, 3, *g["img_mask"].shape[-2:], device=device), g["img_mask"].to(device))
+    text = (g["text_mask"].to(device), g["text_mem"].to(device), torch.tensor([[7, 5]]))
+    mc = model(samples, encode_and_save=True, text=text, targets=None)
+    return model(samples, encode_and_save=False, memory_cache=mc, text=text, targets=None), feats
+
+
+def test_full_parsed_v2_matches_reference():
+    """BASELINE config 1's model family (RLIP_ParSeD_v2): learned query positions, 2-d reference points
+    refined into boxes, XGating fusion."""
+    g = load("parsed")
+    model, bb = build_small_parsed()
+    out, feats = run_small_parsed(model, bb, g)
+    loss = 0
+    for k in KEYS:
+        box = "boxes" in k
+        close(out[k], g[k], 1e-3 if not box else 0.0, 1e-5 if not box else 1e-4, k)
+        close(out["aux_outputs"][0][k], g["aux0_" + k], 1e-3 if not box else 0.0, 1e-5 if not box else 1e-4, "aux " + k)
+        loss = loss + (out[k] * g["g_" + k]).sum() + (out["aux_outputs"][0][k] * g["g_" + k]).sum() * 0.5
+    loss.backward()
+    for i, (t, _) in enumerate(feats):
+        close(t.grad, g[f"g_feat{i}"], 1e-3, 1e-5, f"g_feat{i}")
+    params = dict(model.named_parameters(remove_duplicate=False))
+    for key in g:
+        if key.startswith("gparam_"):
+            close(params[key[len("gparam_"):].replace("__", ".")].grad, g[key], 1e-3, 1e-5, key)
+    with np.load(os.path.join(GOLD, "model_parsed.npz")) as z:
+        ref_names = {n for n in z["param_names"].tolist() if not n.startswith("transformer.text_encoder.")}
+    assert set(params.keys()) == ref_names, (sorted(set(params) - ref_names)[:8], sorted(ref_names - set(params))[:8])
+
+
+def test_baseline_config1_plumbing_on_cpu():
+    """BASELINE.json config 1: RLIP_ParSeD_v2 R50, two synthetic 640x640 images, end to end on the CPU
+    (forward phases, criterion, backward) with the checker standing in for the GPU op -- the reference's
+    "pure-PyTorch ms_deform_attn fallback" role.  Plumbing only: shapes, finiteness, gradients reach the
+    backbone, the ALIF fusion and the query table."""
+    from rlipv2_amd import criterion as MC
+    from rlipv2_amd import parsed, train
+    from rlipv2_amd.backbone import build_r50_backbone
+    torch.manual_seed(0)
+    args = parseda.default_args(num_queries=200, enc_layers=6, dec_layers=3, dim_feedforward=1024,
+                                gating_mechanism="XGating", pseudo_verb=False)
+    model = parsed.build_parsed(build_r50_backbone(256), args)
+    train.freeze_statically_unused(model)
+    samples, _, targets = train.synthetic_batch(2, 640, 640, n_obj=43, n_verb=21, triplets=4, device="cpu", seed=3)
+    mem = torch.tanh(torch.randn(64, 1, 768)).repeat(1, 2, 1)
+    text = (~(mem.sum(-1) > 0), mem, torch.tensor([[43, 21]]))
+    mc = model(samples, encode_and_save=True, text=text, targets=targets)
+    assert mc["img_memory"].shape == (2, 8500, 256)                      # 80^2 + 40^2 + 20^2 + 10^2 tokens
+    assert mc["spatial_shapes"].tolist() == [[80, 80], [40, 40], [20, 20], [10, 10]]
+    out = model(samples, encode_and_save=False, memory_cache=mc, text=text, targets=targets)
+    assert out["pred_obj_logits"].shape == (2, 100, 43) and out["pred_verb_logits"].shape == (2, 100, 21)
+    assert out["pred_sub_boxes"].shape == (2, 100, 4) and len(out["aux_outputs"]) == 2
+    crit = MC.SetCriterionHOI(MC.HungarianMatcherHOI(1, 1, 2.5, 1, subject_class=True), MC.build_weight_dict(3),
+                              pseudo_verb=False)
+    loss = crit.weighted_sum(crit(out, targets))
+    assert torch.isfinite(loss)
+    loss.backward()
+    for name in ("backbone.0.body.layer4.2.conv3.weight", "transformer.ho_encoder.VLFuse_layers.2.b_attn.attn.v_proj.weight",
+                 "query_embed.weight", "transformer.ho_encoder.layers.5.self_attn.sampling_offsets.weight"):
+        g = dict(model.named_parameters())[name].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, name

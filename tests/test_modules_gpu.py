@@ -158,3 +158,18 @@ def test_fused_sampling_geometry_equals_module_arithmetic(nd, dtype):
     for name, a, b in zip(("out", "g_query", "g_inp", "g_ref"), res[True], res[False]):
         err = (a - b).abs().max().item() / max(1e-6, b.abs().max().item())
         assert err < tol, (name, err)
+
+
+def test_full_parsed_v2_f32():
+    g = C.load("parsed")
+    model, bb = C.build_small_parsed()
+    model = model.to(DEV)
+    out, feats = C.run_small_parsed(model, bb, g, device=DEV)
+    loss = 0
+    for k in C.KEYS:
+        box = "boxes" in k
+        C.close(out[k].cpu(), g[k], 1e-3 if not box else 0.0, 1e-5 if not box else 1e-4, k)
+        loss = loss + (out[k] * g["g_" + k].to(DEV)).sum() + (out["aux_outputs"][0][k] * g["g_" + k].to(DEV)).sum() * 0.5
+    loss.backward()
+    for i, (t, _) in enumerate(feats):
+        C.close(t.grad.cpu(), g[f"g_feat{i}"], 1e-3, 1e-5, f"g_feat{i}")

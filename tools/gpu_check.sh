@@ -13,7 +13,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 echo "== microbench"
 timeout 900 python tools/msda_microbench.py --quick --out $OUT/microbench.json 2>&1 | tail -60 | tee $OUT/microbench.txt
 echo "== bench"
-timeout 900 python bench.py --steps 10 --warmup 2 2>&1 | tail -3 | tee $OUT/bench.json
+timeout 900 python bench.py --steps 10 --warmup 2 2>$OUT/bench.stderr | tail -1 | tee $OUT/bench.json
 echo "== rocprof"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.log 2>&1 )
 find $OUT/prof -name "*kernel_stats*" | head -3

@@ -118,10 +118,10 @@ class RLIP_ParSeDTransformer_v2(RLIP_ParSeDABDeformableTransformer_v2):
 
     def forward(self, srcs=None, masks=None, pos_embeds=None, query_embed=None, text=None, encode_and_save=True,
                 text_memory=None, img_memory=None, text_attention_mask=None, obj_pred_names_sums=None,
-                spatial_shapes=None, level_start_index=None, valid_ratios=None, **unused):
+                spatial_shapes=None, level_start_index=None, valid_ratios=None, encoded_text=None, **unused):
         if encode_and_save:
             mc = super().forward(srcs=srcs, masks=masks, pos_embeds=pos_embeds, query_embed=query_embed, text=text,
-                                 encode_and_save=True)
+                                 encode_and_save=True, encoded_text=encoded_text)
             mc["key_padding_mask"] = None
             mc["attn_mask"] = None
             return mc

@@ -125,7 +125,8 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
 
     def forward(self, srcs=None, masks=None, pos_embeds=None, query_embed=None, text=None, encode_and_save=True,
                 text_memory=None, img_memory=None, text_attention_mask=None, obj_pred_names_sums=None,
-                spatial_shapes=None, level_start_index=None, valid_ratios=None, spatial_shapes_list=None):
+                spatial_shapes=None, level_start_index=None, valid_ratios=None, spatial_shapes_list=None,
+                encoded_text=None):
         assert query_embed is not None
         if encode_and_save:
             shapes_list = [tuple(s.shape[-2:]) for s in srcs]
@@ -144,7 +145,9 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
             spatial_shapes, level_start_index = cache[key]
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
-            text_attention_mask, text_memory, obj_pred_names_sums = self._encode_text(text, bs, src_flatten.device)
+            if encoded_text is None:
+                encoded_text = self._encode_text(text, bs, src_flatten.device)
+            text_attention_mask, text_memory, obj_pred_names_sums = encoded_text
             img_memory, lang = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, lvl_pos,
                                             mask_flatten, lang_hidden=text_memory.transpose(0, 1),
                                             lang_masks=text_attention_mask.transpose(0, 1),
@@ -289,6 +292,19 @@ class RLIP_ParSeDA(nn.Module):
 
     # ---- phase A: backbone + input projections + ALIF encoder -------------------------------------------
     def _encode(self, samples, text):
+        # The label texts do not depend on the images: encode them on a second HIP stream while the
+        # backbone runs.  The text encoder is a chain of ~400 tiny kernels on [n_text, 5] tokens (4 ms of
+        # launch latency, ~0 compute) and the backbone is compute-bound, so the two overlap almost
+        # perfectly; autograd replays each backward on the stream of its forward, so the backward passes
+        # overlap the same way.
+        encoded_text = None
+        tr = self.transformer
+        if isinstance(text, dict) and samples.tensors.is_cuda and getattr(tr, "text_encoder", None) is not None:
+            cur = torch.cuda.current_stream()
+            side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=samples.tensors.device))
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                encoded_text = tr._encode_text(text, samples.tensors.shape[0], samples.tensors.device)
         features, pos = self.backbone(samples)
         srcs, masks = [], []
         for l, feat in enumerate(features):
@@ -303,8 +319,12 @@ class RLIP_ParSeDA(nn.Module):
             srcs.append(src)
             masks.append(mask)
         query_embeds = self._query_embeds()
+        if encoded_text is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            for t in encoded_text[:2]:
+                t.record_stream(torch.cuda.current_stream())
         return self.transformer(srcs=srcs, masks=masks, pos_embeds=pos, query_embed=query_embeds, text=text,
-                                encode_and_save=True)
+                                encode_and_save=True, encoded_text=encoded_text)
 
     def forward(self, samples, encode_and_save=True, memory_cache=None, **kwargs):
         if not isinstance(samples, NestedTensor):

@@ -48,6 +48,19 @@ def generalized_box_iou(a, b):
     return iou - (hull - union) / hull
 
 
+def paired_giou(a, b):
+    """GIoU of xyxy boxes a[i] with b[i] ([N,4] x [N,4] -> [N]): the diagonal of generalized_box_iou"""
+    inter = ((torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0)).prod(-1)
+    union = _area(a) + _area(b) - inter
+    hull = ((torch.max(a[:, 2:], b[:, 2:]) - torch.min(a[:, :2], b[:, :2])).clamp(min=0)).prod(-1)
+    return inter / union - (hull - union) / hull
+
+
+class LossDict(dict):
+    """loss dict of SetCriterionHOI.forward; `total` carries the weighted sum (see weighted_sum)."""
+    total = None
+
+
 class HungarianMatcherHOI(nn.Module):
     def __init__(self, cost_obj_class=1.0, cost_verb_class=1.0, cost_bbox=1.0, cost_giou=1.0, subject_class=False):
         super().__init__()
@@ -222,23 +235,17 @@ class SetCriterionHOI(nn.Module):
                 'loss_sub_giou': g_s.sum() / num_interactions,
                 'loss_obj_giou': (g_o * exist).sum() / (exist.sum() + 1e-4)}
 
-    def forward(self, outputs, targets):
+    def forward_per_layer(self, outputs, targets):
+        """The reference's control flow: one pass of every loss per decoder layer (kept as the readable
+        statement of the criterion and as a cross-check of `forward`, tests/test_modules_cpu.py)."""
         main = {k: v for k, v in outputs.items() if k != 'aux_outputs'}
         layers = [main] + list(outputs.get('aux_outputs', []))
         bs, nq = main['pred_obj_logits'].shape[:2]
         sizes = [len(t['obj_labels']) for t in targets]
-        # all layers' cost matrices -> ONE device->host copy -> scipy on the host
         costs = [self.matcher.costs(o, targets) for o in layers]
         stacked = torch.stack([c for c, _ in costs]).float().cpu()
         assignments = [self.matcher.assign(stacked[i], bs, nq, sizes) for i in range(len(layers))]
-
-        num = torch.as_tensor([sum(sizes)], dtype=torch.float, device=main['pred_obj_logits'].device)
-        world = 1
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(num)                               # keeps the loss scale of the reference
-            world = dist.get_world_size()
-        num_interactions = torch.clamp(num / world, min=1)[0]  # stays on the device: no .item() sync
-
+        num_interactions = self._num_interactions(sizes, main['pred_obj_logits'].device)
         losses = {}
         for li, (o, idx, (_, c_giou)) in enumerate(zip(layers, assignments, costs)):
             d = {}
@@ -249,5 +256,150 @@ class SetCriterionHOI(nn.Module):
             losses.update(d if li == 0 else {f'{k}_{li - 1}': v for k, v in d.items()})
         return losses
 
+    @staticmethod
+    def _num_interactions(sizes, device):
+        num = torch.as_tensor([sum(sizes)], dtype=torch.float, device=device)
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(num)                               # keeps the loss scale of the reference
+            world = dist.get_world_size()
+        return torch.clamp(num / world, min=1)[0]              # stays on the device: no .item() sync
+
+    def forward(self, outputs, targets):
+        """All decoder layers in one pass.  The K layers' predictions are stacked into [K*bs*nq, .] rows,
+        so the cost matrix, the label / verb / box losses and the cardinality error are each computed once
+        on a K-times larger tensor instead of K times (the per-layer loop is ~330 launch-bound kernels
+        forward and as many backward; this is ~110), with ONE device->host copy (costs) and ONE
+        host->device copy (matched indices) per step.  Every entry equals `forward_per_layer`."""
+        main = {k: v for k, v in outputs.items() if k != 'aux_outputs'}
+        layers = [main] + list(outputs.get('aux_outputs', []))
+        K = len(layers)
+        bs, nq = main['pred_obj_logits'].shape[:2]
+        dev = main['pred_obj_logits'].device
+        sizes = [len(t['obj_labels']) for t in targets]
+        T = sum(sizes)
+
+        def rows(key):                                         # [K*bs, nq, .], float32 (bf16 predictions upcast here)
+            return (torch.cat([o[key] for o in layers], 0) if K > 1 else main[key]).float()
+        pred = {k: rows(k) for k in ('pred_obj_logits', 'pred_verb_logits', 'pred_sub_boxes', 'pred_obj_boxes')}
+        if self.subject_class:
+            pred['pred_sub_logits'] = rows('pred_sub_logits')
+        C, c_giou = self.matcher.costs(pred, targets)           # [K*bs*nq, T]
+        C_host = C.float().cpu().view(K, bs, nq, T)
+        # Hungarian assignment on the host; rows of the stacked predictions / columns of the concatenated targets
+        flat_q, tgt_i, t0 = [], [], 0
+        starts = [0]
+        for n in sizes:
+            starts.append(starts[-1] + n)
+        for k in range(K):
+            for i in range(bs):
+                r, c = linear_sum_assignment(C_host[k, i, :, starts[i]:starts[i + 1]])
+                flat_q.append(torch.as_tensor(r, dtype=torch.int64) + (k * bs + i) * nq)
+                tgt_i.append(torch.as_tensor(c, dtype=torch.int64) + starts[i])
+        index = torch.stack([torch.cat(flat_q), torch.cat(tgt_i)]).to(dev, non_blocking=True)
+        flat_q, tgt_i = index[0], index[1]
+        n = flat_q.shape[0] // K                                # matched pairs per layer (the same for every layer)
+        num_interactions = self._num_interactions(sizes, dev)
+
+        t_obj = torch.cat([t['obj_labels'] for t in targets])
+        t_verb = torch.cat([t['verb_labels'] for t in targets])
+        t_sub_box = torch.cat([t['sub_boxes'] for t in targets])
+        t_obj_box = torch.cat([t['obj_boxes'] for t in targets])
+        out = {}
+
+        # --- object / subject labels: weighted cross-entropy per layer (hoi.py:3696) ---
+        def label_ce(logits, t_lab):
+            n_cls = logits.shape[-1]
+            logits = logits.reshape(K * bs * nq, n_cls)
+            weight = torch.ones(n_cls, device=dev, dtype=logits.dtype)
+            weight[-1] = self.eos_coef
+            matched = t_lab[tgt_i]
+            tgt = torch.full((K * bs * nq,), n_cls - 1, dtype=torch.int64, device=dev)
+            tgt[flat_q] = matched
+            nll = F.cross_entropy(logits, tgt, weight, reduction='none').view(K, -1).sum(1)
+            return nll / weight[tgt].view(K, -1).sum(1), logits, matched
+        ce, o_logits, m_o = label_ce(pred['pred_obj_logits'], t_obj)
+        if self.subject_class:
+            ce_s, s_logits, m_s = label_ce(pred['pred_sub_logits'], torch.cat([t['sub_labels'] for t in targets]))
+            ce = ce + ce_s
+        out['loss_obj_ce'] = ce
+
+        def class_error(logits, matched):
+            if n == 0:
+                return torch.zeros([], device=dev)
+            return 100 - (logits[flat_q[:n]].argmax(-1) == matched[:n]).float().mean() * 100
+        log = {'obj_class_error': class_error(o_logits, m_o)}
+        if self.subject_class:
+            log['sub_class_error'] = class_error(s_logits, m_s)
+
+        # --- verbs: (quality) focal loss on sigmoid probabilities (hoi.py:3925) ---
+        v_logits = pred['pred_verb_logits']
+        if self.use_no_verb_token:
+            v_logits = v_logits[:, :, :-1]
+        nv = v_logits.shape[-1]
+        v_logits = v_logits.reshape(K * bs * nq, nv)
+        lab = t_verb[tgt_i].to(v_logits.dtype)
+        if self.giou_verb_label:
+            quality = (1 - c_giou[flat_q, tgt_i]) / 2           # matcher cost is -GIoU; GIoU -> [0, 1]
+            if self.pseudo_verb:
+                sims = [o['target_verb_sim'] for o in layers]
+                if all(s_ is sims[0] for s_ in sims):
+                    lab = lab + sims[0][tgt_i].float()
+                else:
+                    lab = lab + torch.stack(sims)[torch.arange(K, device=dev).repeat_interleave(n), tgt_i].float()
+            lab = lab * quality.unsqueeze(-1)
+        gt = torch.zeros_like(v_logits)
+        gt[flat_q] = lab.to(v_logits.dtype)
+        p = torch.clamp(v_logits.sigmoid(), 1e-6, 1. - 1e-6)
+        if self.giou_verb_label:                                # soft_neg_loss, per layer
+            el = torch.pow(torch.abs(gt - p), 2) * ((1 - gt) * torch.log(1 - p) + gt * torch.log(p))
+            tot, num_pos = el.view(K, -1).sum(1), gt.gt(0).view(K, -1).sum(1).float()
+            out['loss_verb_ce'] = torch.where(num_pos == 0, -tot, -tot / num_pos.clamp(min=1))
+        else:                                                   # neg_loss, per layer
+            pos, neg = gt.eq(1).float(), gt.lt(1).float()
+            pl = (torch.log(p) * torch.pow(1 - p, 2) * pos).view(K, -1).sum(1)
+            nl = (torch.log(1 - p) * torch.pow(p, 2) * torch.pow(1 - gt, 4) * neg).view(K, -1).sum(1)
+            num_pos = pos.view(K, -1).sum(1)
+            out['loss_verb_ce'] = torch.where(num_pos == 0, -nl, -(pl + nl) / num_pos.clamp(min=1))
+
+        # --- boxes: L1 + GIoU of matched pairs (hoi.py:4162) ---
+        src_s = pred['pred_sub_boxes'].reshape(-1, 4)[flat_q]
+        src_o = pred['pred_obj_boxes'].reshape(-1, 4)[flat_q]
+        if n == 0:
+            z_s, z_o = src_s.sum().expand(K), src_o.sum().expand(K)
+            out.update(loss_sub_bbox=z_s, loss_obj_bbox=z_o, loss_sub_giou=z_s, loss_obj_giou=z_o)
+        else:
+            tgt_s, tgt_o = t_sub_box[tgt_i], t_obj_box[tgt_i]
+            exist = (tgt_o != 0).any(dim=1)
+            n_exist = exist.view(K, -1).sum(1) + 1e-4
+            out['loss_sub_bbox'] = (src_s - tgt_s).abs().view(K, -1).sum(1) / num_interactions
+            out['loss_obj_bbox'] = ((src_o - tgt_o).abs() * exist.unsqueeze(1)).view(K, -1).sum(1) / n_exist
+            g_s = 1 - paired_giou(box_cxcywh_to_xyxy(src_s), box_cxcywh_to_xyxy(tgt_s))
+            g_o = 1 - paired_giou(box_cxcywh_to_xyxy(src_o), box_cxcywh_to_xyxy(tgt_o))
+            out['loss_sub_giou'] = g_s.view(K, -1).sum(1) / num_interactions
+            out['loss_obj_giou'] = (g_o * exist).view(K, -1).sum(1) / n_exist
+
+        # --- cardinality error (hoi.py:3909), logging only ---
+        lengths = torch.as_tensor(sizes, device=dev, dtype=torch.float)
+        card = (o_logits.argmax(-1) != o_logits.shape[-1] - 1).view(K, bs, nq).sum(2).float()
+        out['obj_cardinality_error'] = (card - lengths).abs().mean(1)
+
+        losses = LossDict()
+        for li in range(K):
+            sfx = '' if li == 0 else f'_{li - 1}'
+            for k, v in out.items():
+                losses[k + sfx] = v[li]
+            if li == 0:
+                losses.update(log)
+        # the weighted total as one dot product instead of a chain of ~3*K tiny multiply-adds
+        kinds = [k for k in out if k in self.weight_dict]
+        w = torch.tensor([[self.weight_dict.get(k + ('' if li == 0 else f'_{li - 1}'), 0.0) for li in range(K)]
+                          for k in kinds], device=dev, dtype=out[kinds[0]].dtype)
+        losses.total = (torch.stack([out[k] for k in kinds]) * w).sum()
+        return losses
+
     def weighted_sum(self, loss_dict):
+        total = getattr(loss_dict, 'total', None)
+        if total is not None:
+            return total
         return sum(loss_dict[k] * self.weight_dict[k] for k in loss_dict if k in self.weight_dict)

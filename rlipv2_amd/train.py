@@ -138,8 +138,6 @@ def freeze_parameters_without_gradient(step_module, criterion, batch, autocast_d
     device_type = samples.tensors.device.type
     with torch.autocast(device_type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
         outputs = step_module(samples, text, targets)
-    outputs = {k: ([{kk: vv.float() for kk, vv in a.items()} for a in v] if k == "aux_outputs" else v.float())
-               for k, v in outputs.items()}
     criterion.weighted_sum(criterion(outputs, targets)).backward()
     frozen = []
     for n, p in step_module.named_parameters():
@@ -265,8 +263,6 @@ def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_
     samples, text, targets = batch
     with torch.autocast(samples.tensors.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
         outputs = step_module(samples, text, targets)
-    outputs = {k: ([{kk: vv.float() for kk, vv in a.items()} for a in v] if k == "aux_outputs" else v.float())
-               for k, v in outputs.items()}
     loss_dict = criterion(outputs, targets)
     loss = criterion.weighted_sum(loss_dict)
     optimizer.zero_grad(set_to_none=True)

@@ -383,3 +383,50 @@ def test_baseline_config1_plumbing_on_cpu():
                  "query_embed.weight", "transformer.ho_encoder.layers.5.self_attn.sampling_offsets.weight"):
         g = dict(model.named_parameters())[name].grad
         assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, name
+
+
+@pytest.mark.parametrize("sizes", [(2, 0, 4), (0, 0, 0), (3, 1, 2)])
+def test_batched_criterion_equals_per_layer_loop(sizes):
+    """SetCriterionHOI.forward (all decoder layers stacked, one pass) against forward_per_layer (the
+    reference's per-layer control flow): every entry, the weighted total and the gradients."""
+    from rlipv2_amd import criterion as MC
+    g = torch.Generator().manual_seed(5)
+    K, bs, nq, n_obj, n_verb = 3, len(sizes), 7, 6, 5
+
+    def layer():
+        return {"pred_obj_logits": torch.randn(bs, nq, n_obj + 1, generator=g),
+                "pred_sub_logits": torch.randn(bs, nq, n_obj + 1, generator=g),
+                "pred_verb_logits": torch.randn(bs, nq, n_verb, generator=g),
+                "pred_sub_boxes": torch.rand(bs, nq, 4, generator=g) * 0.4 + 0.3,
+                "pred_obj_boxes": torch.rand(bs, nq, 4, generator=g) * 0.4 + 0.3}
+    layers = [layer() for _ in range(K)]
+    sim = torch.rand(sum(sizes), n_verb, generator=g) * 0.3
+    targets = []
+    for n in sizes:
+        ob = torch.rand(n, 4, generator=g) * 0.4 + 0.3
+        if n > 1:
+            ob[0] = 0                                            # an interaction without object box
+        targets.append({"obj_labels": torch.randint(0, n_obj, (n,), generator=g),
+                        "sub_labels": torch.randint(0, n_obj, (n,), generator=g),
+                        "verb_labels": (torch.rand(n, n_verb, generator=g) > 0.6).float(),
+                        "sub_boxes": torch.rand(n, 4, generator=g) * 0.4 + 0.3, "obj_boxes": ob})
+    crit = MC.SetCriterionHOI(MC.HungarianMatcherHOI(1, 1, 2.5, 1, subject_class=True), MC.build_weight_dict(K))
+    results = []
+    for fn in (crit.forward, crit.forward_per_layer):
+        ls = [{k: v.clone().requires_grad_(True) for k, v in o.items()} for o in layers]
+        out = dict(ls[0]); out["target_verb_sim"] = sim
+        out["aux_outputs"] = [dict(o, target_verb_sim=sim) for o in ls[1:]]
+        ld = fn(out, targets)
+        total = crit.weighted_sum(ld)
+        total.backward()
+        results.append((ld, total, [o[k].grad for o in ls for k in sorted(o)]))
+    (a, ta, ga), (b, tb, gb) = results
+    assert set(a.keys()) == set(b.keys())
+    for k in a:
+        close(a[k].reshape(()), b[k].reshape(()), 1e-5, 1e-6, k)
+    close(ta.reshape(()), tb.reshape(()), 1e-5, 1e-6, "total")
+    for x, y in zip(ga, gb):
+        if x is None or y is None:
+            assert (x is None or not x.any()) and (y is None or not y.any())
+        else:
+            close(x, y, 1e-4, 1e-6, "grad")

@@ -1,0 +1,45 @@
+/* rlipv2_linear.h -- C ABI of the token-major Linear weight-gradient kernel (gfx950, bf16 MFMA).
+ *
+ * The encoder of RLIPv2-ParSeDA applies nn.Linear layers to the flattened multi-scale feature map,
+ * [N*S, C] with N*S = 88 892 rows at batch 4 x 800x1333 (reference: MSDeformAttn.value_proj /
+ * sampling_offsets / attention_weights / output_proj, models/ops/modules/ms_deform_attn.py:59-62,
+ * and DeformableTransformerEncoderLayer.linear1 / linear2, models/dab_deformable/
+ * deformable_transformer.py:571-576).  In the backward pass each of them needs
+ *
+ *      dW[M, K] = dY[T, M]^T . X[T, K]        db[M] = column sums of dY
+ *
+ * -- a GEMM whose reduction dimension is the 88 892 tokens and whose output is a small square.  The
+ * library GEMM handles that shape at 4-9 % of the HBM rate (measured, tools/gemm_shapes.py), and the
+ * bias gradient re-reads dY once more; this kernel streams dY and X once, split over the tokens.
+ *
+ * Plain pointers and sizes; nothing allocates, nothing synchronises; work is enqueued on `stream`.
+ */
+#ifndef RLIPV2_LINEAR_H
+#define RLIPV2_LINEAR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Bytes of scratch device memory linear_wgrad_bf16 needs for this problem (0 if the shape is not
+ * supported: M and K must be multiples of 128, T >= 1). */
+size_t linear_wgrad_workspace_bytes(int T, int M, int K);
+
+/* 1 if (T, M, K) runs on the MFMA kernel. */
+int linear_wgrad_supported(int T, int M, int K);
+
+/* dW = dY^T X and db = sum_t dY[t, :].
+ *   dy [T, M] bf16 row-major, x [T, K] bf16 row-major (16-byte aligned, contiguous),
+ *   dw [M, K] and db [M]: bf16 when out_f32 == 0, float32 otherwise; db may be NULL.
+ *   workspace: linear_wgrad_workspace_bytes(T, M, K) bytes of device memory.
+ * Accumulation is float32 throughout.  Returns 0, or an msda_status code (rlipv2_msda.h). */
+int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, int K, void *dw, void *db, int out_f32,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

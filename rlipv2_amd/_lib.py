@@ -22,6 +22,8 @@ EXPORTS = (
     "msda_forward", "msda_backward", "msda_forward_ex", "msda_backward_ex", "msda_check_im2col_step",
     "msda_algorithmic_bytes", "msda_strerror", "msda_abi_version", "msda_variant_name", "msda_pick_variant",
     "msda_prepare_forward", "msda_prepare_backward",
+    # include/rlipv2_linear.h
+    "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
 )
 
 _lib = None
@@ -68,6 +70,12 @@ def lib() -> ctypes.CDLL:
     L.msda_variant_name.restype = ctypes.c_char_p
     L.msda_pick_variant.argtypes = [i, i, *dims]
     L.msda_pick_variant.restype = i
+    L.linear_wgrad_workspace_bytes.argtypes = [i, i, i]
+    L.linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    L.linear_wgrad_supported.argtypes = [i, i, i]
+    L.linear_wgrad_supported.restype = i
+    L.linear_wgrad_bf16.argtypes = [vp, vp, i, i, i, vp, vp, i, vp, ctypes.c_size_t, vp]
+    L.linear_wgrad_bf16.restype = i
     _lib = L
     return L
 

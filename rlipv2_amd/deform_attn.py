@@ -4,8 +4,9 @@ models/dab_deformable/ops/modules/), with the sampling + aggregation done by the
 behind ``MSDeformAttnFunction``.
 
 Host-side differences (results identical): the two query projections (`sampling_offsets`,
-`attention_weights`) are issued as one GEMM over the concatenated weights, and the padding-mask
-fill is applied to the projected value without an extra copy.
+`attention_weights`) are issued as one GEMM over the concatenated weights, the padding-mask
+fill is applied to the projected value without an extra copy, and on the encoder's 88 892-token inputs
+the weight gradients of the projections run on the MFMA kernel of csrc/token_gemm.hip (linear.py).
 """
 from __future__ import annotations
 
@@ -18,6 +19,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from . import msda
+from .linear import token_linear
 
 # the autograd op; a module attribute so that CPU unit tests can substitute a checker
 msda_function = msda.MSDeformAttnFunction
@@ -80,15 +82,15 @@ class MSDeformAttn(nn.Module):
         # (the reference asserts sum(H*W) == Len_in on the device, a host sync per call
         #  (ms_deform_attn.py:96); the HIP library validates shapes without one)
 
-        value = self.value_proj(input_flatten)
+        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, Len_in, M, self.d_model // M)
 
         n_off = M * L * P * 2
-        qproj = F.linear(query,
-                         torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
-                         torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+        qproj = token_linear(query,
+                             torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
+                             torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
         if (qproj.is_cuda and fused_geometry and L == 4 and P == 4 and reference_points.shape[-1] in (2, 4)
                 and qproj.dtype in (torch.float32, torch.bfloat16)):
             # one HIP kernel instead of view + softmax + divide + add (+ their backward passes)
@@ -98,7 +100,7 @@ class MSDeformAttn(nn.Module):
                 locations, weights = locations.double(), weights.double()
             output = msda_function.apply(value, input_spatial_shapes, input_level_start_index, locations, weights,
                                          self.im2col_step)
-            return self.output_proj(output)
+            return token_linear(output, self.output_proj.weight, self.output_proj.bias)
         # the module's own arithmetic (also what the CPU unit tests exercise)
         offsets = qproj[..., :n_off].reshape(N, Len_q, M, L, P, 2)
         logits = qproj[..., n_off:].reshape(N, Len_q, M, L * P)

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .deform_attn import MSDeformAttn
+from .linear import token_linear
 
 
 def _clones(module, n):
@@ -48,7 +49,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
         q = src if pos is None else src + pos
         src = self.norm1(src + self.dropout1(
             self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)))
-        ffn = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        hidden = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
+        ffn = token_linear(hidden, self.linear2.weight, self.linear2.bias)
         return self.norm2(src + self.dropout3(ffn))
 
 

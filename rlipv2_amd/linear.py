@@ -1,0 +1,92 @@
+"""Linear layers applied to the flattened multi-scale feature map ([N, S, C] with N*S = 88 892 tokens at
+batch 4): forward and input gradient stay library GEMMs, the weight + bias gradient -- a GEMM that
+reduces over the tokens into a small [out, in] square, which the library runs at a few percent of the
+HBM rate -- is the hand-written MFMA kernel of csrc/token_gemm.hip (C ABI: include/rlipv2_linear.h).
+
+Used by MSDeformAttn (value_proj, the fused sampling_offsets + attention_weights projection, output_proj;
+reference models/ops/modules/ms_deform_attn.py:59-62) and by the encoder layer's FFN (linear1 / linear2,
+reference models/dab_deformable/deformable_transformer.py:571-576).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+# rows below this go to the library (its weight-gradient GEMM is fine when the reduction is short)
+MIN_ROWS = 8192
+enabled = True
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 26), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    if not (enabled and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
+        return False
+    rows = x.numel() // x.shape[-1]
+    return rows >= MIN_ROWS and bool(_lib.lib().linear_wgrad_supported(rows, weight.shape[0], weight.shape[1]))
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True, out_dtype=torch.bfloat16):
+    """dW [M, K] = dy[T, M]^T x[T, K] and db [M] = dy.sum(0) (bf16 inputs, float32 accumulation)."""
+    if not (dy.is_cuda and x.is_cuda):
+        raise RuntimeError("Not implemented on the CPU")
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
+        raise RuntimeError("linear_wgrad: bfloat16 operands expected")
+    dy = dy.reshape(-1, dy.shape[-1]).contiguous()
+    x = x.reshape(-1, x.shape[-1]).contiguous()
+    T, M = dy.shape
+    K = x.shape[1]
+    if x.shape[0] != T:
+        raise RuntimeError("linear_wgrad: dy and x disagree on the number of rows")
+    L = _lib.lib()
+    nbytes = L.linear_wgrad_workspace_bytes(T, M, K)
+    if nbytes == 0:
+        raise RuntimeError(f"linear_wgrad: unsupported shape T={T} M={M} K={K} (M, K must be multiples of 128)")
+    ws = _workspace(dy.device, nbytes)
+    f32 = out_dtype == torch.float32
+    dw = torch.empty(M, K, dtype=out_dtype, device=dy.device)
+    db = torch.empty(M, dtype=out_dtype, device=dy.device) if with_bias else None
+    st = L.linear_wgrad_bf16(dy.data_ptr(), x.data_ptr(), T, M, K, dw.data_ptr(),
+                             db.data_ptr() if with_bias else None, int(f32), ws.data_ptr(), ws.numel(),
+                             torch.cuda.current_stream(dy.device).cuda_stream)
+    if st:
+        raise RuntimeError("linear_wgrad: " + _lib.strerror(st))
+    return dw, db
+
+
+class TokenLinearFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dy.matmul(weight) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = linear_wgrad(dy, x, with_bias=ctx.has_bias, out_dtype=weight.dtype)
+        return dx, dw, db
+
+
+def token_linear(x, weight, bias=None):
+    """F.linear with the MFMA weight-gradient kernel behind it when the shape qualifies."""
+    if supported(x, weight) and torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
+        return TokenLinearFunction.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

@@ -14,9 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "rlipv2_msda.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(msda_[a-z0-9_]+)\s*\(", text)
+    names = []
+    for header in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b((?:msda|linear)_[a-z0-9_]+)\s*\(", text)
     return sorted(set(names))
 
 
@@ -25,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     declared = _declared_functions()
     assert set(declared) == set(_lib.EXPORTS), (declared, _lib.EXPORTS)
     for name in declared:
-        assert hasattr(L, name), f"{name} declared in include/rlipv2_msda.h but not exported"
+        assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
 
 
 def test_abi_version_and_strerror():
@@ -109,3 +111,25 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_linear_wgrad_plan_and_cpu_behaviour():
+    from rlipv2_amd import linear
+    L = _lib.lib()
+    # supported: out/in features multiples of 128; the workspace holds one float32 partial per token chunk
+    assert L.linear_wgrad_supported(88892, 256, 256) == 1
+    assert L.linear_wgrad_supported(88892, 1024, 256) == 1
+    assert L.linear_wgrad_supported(88892, 384, 256) == 1
+    assert L.linear_wgrad_supported(88892, 100, 256) == 0
+    assert L.linear_wgrad_supported(0, 256, 256) == 0
+    assert L.linear_wgrad_workspace_bytes(88892, 100, 256) == 0
+    nbytes = L.linear_wgrad_workspace_bytes(88892, 256, 256)
+    assert nbytes % ((256 * 256 + 256) * 4) == 0 and 0 < nbytes <= 64 << 20
+    assert L.linear_wgrad_workspace_bytes(1, 128, 128) == (128 * 128 + 128) * 4
+    # CPU tensors never reach the kernel: token_linear is the library call there, linear_wgrad refuses
+    x = torch.randn(3, 5, 128, requires_grad=True)
+    w = torch.randn(128, 128, requires_grad=True)
+    assert not linear.supported(x, w)
+    torch.testing.assert_close(linear.token_linear(x, w, None), torch.nn.functional.linear(x, w))
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        linear.linear_wgrad(torch.zeros(4, 128), torch.zeros(4, 128))

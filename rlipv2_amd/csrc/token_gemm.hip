@@ -4,22 +4,30 @@
 // Shape: T = 88 892 tokens, M, K in {256, 384, 1024}.  Arithmetic intensity M*K/(M+K) flop/byte = 128..205,
 // below the MI355X ridge (2.5 PFLOP/s / 8 TB/s = 312), so the bound is HBM: dY and X are streamed once.
 //
-// Layout of one workgroup (256 threads = 4 waves, 2x2 waves of 64x64 outputs = one 128x128 tile of dW):
-//   * a chunk of consecutive tokens [r0, r1) is walked 32 rows at a time; each thread carries 2 x 16 bytes
-//     of the dY tile and 2 x 16 bytes of the X tile in registers (issued one step ahead), and stores them
-//     row-major into LDS with a 320-byte row pitch;
-//   * both MFMA operands need 8 consecutive-k (= token) values of one column per lane, i.e. the transpose
-//     of what memory holds; gfx950's ds_read_b64_tr_b16 delivers exactly that: a 16-lane group reads a
-//     [4 tokens][16 columns] block and every lane receives one column.  Since dY and X are read with the
-//     same lane->token map, the k order inside an MFMA is consistent by construction.  The 320-byte pitch
-//     puts the 4 rows x 2 column blocks of a 32-lane half on 64 distinct banks;
+// One workgroup (256 threads = 4 waves, 2x2 waves of 64x64 outputs = one 128x128 tile of dW) walks a chunk
+// of consecutive tokens 32 rows at a time:
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers and no ds_write pass (a
+//     ds_write_b128 costs 13 LDS-path cycles per wave; the register-staged first version of this kernel
+//     spent more time storing tiles than the MFMAs spent consuming them).  One DMA instruction fills one
+//     1 KB "row group" = 4 token rows x 128 columns; three LDS stages, DMAs issued two steps ahead and
+//     waited for with a counted vmcnt, one raw s_barrier per step;
+//   * both MFMA operands need 8 consecutive-k (= token) values of one column per lane, the transpose of
+//     what memory holds; ds_read_b64_tr_b16 delivers that: a 16-lane group reads a [4 tokens][16 columns]
+//     block and every lane receives one column.  dY and X are read with the same lane->token map, so the
+//     k order inside an MFMA is consistent by construction;
+//   * the DMA's LDS side is lane-linear, so the bank skew is applied on the SOURCE side: 16-byte piece c of
+//     row r of a group is stored at slot 16 r + (c ^ 4 r); the 4 rows x 4 pieces a 32-lane half reads with
+//     one transpose-read then cover all 64 banks exactly once;
 //   * v_mfma_f32_32x32x16_bf16, 2x2 per wave per 16 tokens, 64 accumulator VGPRs;
-//   * the per-chunk 128x128 partial goes to the workspace with plain stores (fp32 atomics to a shared dW
-//     measured 3x slower than stores + one pass of `reduce_partials`, profiles/r01_ubench_global_atomics.txt);
-//   * bias gradient: the threads of the tile_k == 0 workgroups add up the dY registers they stage anyway.
+//   * the per-chunk 128x128 partial goes to the workspace with plain stores and `reduce_partials` sums the
+//     chunks (fp32 atomics to one shared dW measured 3x slower, profiles/r01_ubench_global_atomics.txt);
+//     the same pass adds the T % 32 tail rows, so the main loop has no partial step;
+//   * bias gradient: the tile_k == 0 workgroups also add up the dY tile they have in LDS anyway.
 // Workgroups that share a chunk are placed on the same XCD (they re-read the chunk through that XCD's L2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/rlipv2_linear.h"
 #include "../../include/rlipv2_msda.h"
@@ -29,31 +37,83 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void global_void;
 
 constexpr int BM = 128, BN = 128, BK = 32, THREADS = 256;
-constexpr int ROW_BYTES = 320;                 // 128 bf16 + 64 bytes of skew
-constexpr int TILE_BYTES = BK * ROW_BYTES;     // one operand, one stage
+constexpr int GROUP_BYTES = 1024;               // 4 token rows x 128 columns, one DMA instruction
+constexpr int TILE_BYTES = BK / 4 * GROUP_BYTES;  // one operand, one stage: 8 KB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // 40 960
+constexpr int STAGES = 3;
+constexpr int LDS_BYTES = STAGES * STAGE_BYTES;  // 48 KB
 constexpr int NUM_XCD = 8;
+constexpr int WAVES_PER_SIMD = 3;               // workgroups per CU (4 waves each, one per SIMD)
 
 __device__ __forceinline__ float bf16_to_float(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 
-__device__ __forceinline__ bf16x8 read_fragment(const char *lane_base)
+// LDS reads are inline asm on purpose: hipcc's waitcnt pass makes every LDS read it can see wait for ALL
+// outstanding LDS-DMA (vmcnt(0)), which would serialise the three-stage pipeline; the reads below are
+// ordered against the DMAs by the counted vmcnt + barrier in the main loop instead.
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr_read(unsigned addr)
 {
-    union { s16x4 h[2]; bf16x8 v; } u;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lane_base));
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lane_base + 4 * ROW_BYTES));
-    return u.v;
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
 }
 
-__global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const uint16_t *__restrict__ dy,
-                                                           const uint16_t *__restrict__ x, int T, int M, int K,
-                                                           int rows_per_chunk, int chunks, float *__restrict__ partial,
-                                                           float *__restrict__ bias_partial)
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+// the 8 transpose-reads of one 16-token k-step: A fragments 0/1 and B fragments 0/1, rows 0-3 | 4-7 of
+// the lane's 8 tokens (two consecutive row groups)
+struct StepFragments { s16x4 r[8]; };
+
+template <int OFF>
+__device__ __forceinline__ void read_step(StepFragments &s, unsigned a0, unsigned a1, unsigned b0, unsigned b1)
+{
+    s.r[0] = lds_tr_read<OFF>(a0);
+    s.r[1] = lds_tr_read<OFF + GROUP_BYTES>(a0);
+    s.r[2] = lds_tr_read<OFF>(a1);
+    s.r[3] = lds_tr_read<OFF + GROUP_BYTES>(a1);
+    s.r[4] = lds_tr_read<OFF + TILE_BYTES>(b0);
+    s.r[5] = lds_tr_read<OFF + TILE_BYTES + GROUP_BYTES>(b0);
+    s.r[6] = lds_tr_read<OFF + TILE_BYTES>(b1);
+    s.r[7] = lds_tr_read<OFF + TILE_BYTES + GROUP_BYTES>(b1);
+}
+
+__device__ __forceinline__ void wait_step(StepFragments &s)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(s.r[0]), "+v"(s.r[1]), "+v"(s.r[2]), "+v"(s.r[3]), "+v"(s.r[4]), "+v"(s.r[5]), "+v"(s.r[6]),
+                   "+v"(s.r[7]));
+}
+
+__device__ __forceinline__ void mfma_step(const StepFragments &s, f32x16 (&acc)[2][2])
+{
+    union { s16x4 h[2]; bf16x8 v; } a[2], b[2];
+    a[0].h[0] = s.r[0]; a[0].h[1] = s.r[1]; a[1].h[0] = s.r[2]; a[1].h[1] = s.r[3];
+    b[0].h[0] = s.r[4]; b[0].h[1] = s.r[5]; b[1].h[0] = s.r[6]; b[1].h[1] = s.r[7];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+}
+
+template <int dbg>
+__global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
+    const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x, int M, int K, int steps_total,
+    int steps_per_chunk, int chunks, float *__restrict__ partial, float *__restrict__ bias_partial)
+{
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tiles_k = K / BN, tiles = (M / BM) * tiles_k;
     const int total = chunks * tiles;
     // physical workgroup b runs on XCD b % 8: give every XCD a contiguous range of logical ids so that
@@ -63,21 +123,31 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const uint16_t *__res
     if (logical >= total) return;
     const int chunk = logical / tiles, tile = logical % tiles;
     const int tm = tile / tiles_k, tk = tile % tiles_k;
-    const int r0 = chunk * rows_per_chunk;
-    const int r1 = min(T, r0 + rows_per_chunk);
+    const int s0 = chunk * steps_per_chunk;
+    const int nsteps = min(steps_total, s0 + steps_per_chunk) - s0;      // >= 1 by construction of the plan
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // staging role: 16 threads per 256-byte tile row, rows srow and srow + 16
-    const int srow = tid >> 4, spiece = tid & 15;
-    const uint16_t *a_src = dy + (size_t)tm * BM + spiece * 8;
-    const uint16_t *b_src = x + (size_t)tk * BN + spiece * 8;
-    const int st_off = srow * ROW_BYTES + spiece * 16;
-    // fragment role: 16-lane group g reads rows (lane>>5)*8 + (p>>2) (+4), columns 16*(g&1) + 4*(p&3)
-    const int p = lane & 15, g = lane >> 4;
-    const int frag_off = ((lane >> 5) * 8 + (p >> 2)) * ROW_BYTES + (16 * (g & 1) + 4 * (p & 3)) * 2;
-    const char *a_frag = smem + frag_off + wm * 128;
-    const char *b_frag = smem + TILE_BYTES + frag_off + wn * 128;
+
+    // DMA role: wave w fills row groups w and w + 4 of both operand tiles.  Lane l carries the piece that
+    // belongs at LDS slot l of the group: row l >> 4, 16-byte piece (l & 15) ^ 4 (l >> 4).
+    const int drow = lane >> 4, dpiece = (lane & 15) ^ (4 * (lane >> 4));
+    const uint16_t *a_src = dy + ((size_t)s0 * BK + 4 * wave + drow) * M + (size_t)tm * BM + dpiece * 8;
+    const uint16_t *b_src = x + ((size_t)s0 * BK + 4 * wave + drow) * K + (size_t)tk * BN + dpiece * 8;
+    const size_t a_step = (size_t)BK * M, b_step = (size_t)BK * K;          // elements per 32-token step
+    const size_t a_half = (size_t)16 * M, b_half = (size_t)16 * K;          // row group w + 4 is 16 rows on
+
+    // fragment role: lane (p = l & 15, g = l >> 4) reads row r = p >> 2 of row group 2 (l >> 5) (+1), the
+    // 8 bytes at columns wave_col + 32 f + 16 (g & 1) + 4 (p & 3): piece index c, stored at slot c ^ 4 r
+    const int p = lane & 15, g = lane >> 4, r = p >> 2;
+    auto frag_addr = [&](int wave_piece, int f) {
+        const int c = wave_piece + 4 * f + 2 * (g & 1) + ((p & 3) >> 1);
+        return (lane >> 5) * 2 * GROUP_BYTES + r * 256 + ((c ^ (4 * r)) * 16) + (p & 1) * 8;
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned a0 = lds0 + frag_addr(wm * 8, 0), a1 = lds0 + frag_addr(wm * 8, 1);
+    const unsigned b0 = lds0 + frag_addr(wn * 8, 0), b1 = lds0 + frag_addr(wn * 8, 1);
+    const unsigned bias_addr = lds0 + wave * GROUP_BYTES + lane * 16;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -85,37 +155,53 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const uint16_t *__res
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     float bsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
     const bool want_bias = (tk == 0) && bias_partial != nullptr;
 
-    uint4 ra[2], rb[2];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = k0 + srow + 16 * i;
-            if (row < r1) {
-                ra[i] = *reinterpret_cast<const uint4 *>(a_src + (size_t)row * M);
-                rb[i] = *reinterpret_cast<const uint4 *>(b_src + (size_t)row * K);
-            } else {
-                ra[i] = make_uint4(0, 0, 0, 0);
-                rb[i] = make_uint4(0, 0, 0, 0);
-            }
-        }
+    // Always four DMAs per wave per call, so the vmcnt arithmetic below is exact; steps past the end of
+    // the chunk re-load its last step into a stage nobody reads again.
+    auto issue = [&](int step, int stage) {
+        const int st = min(step, nsteps - 1);
+        const uint16_t *a = a_src + (size_t)st * a_step;
+        const uint16_t *b = b_src + (size_t)st * b_step;
+        char *dst = smem + stage * STAGE_BYTES + wave * GROUP_BYTES;
+        __builtin_amdgcn_global_load_lds((global_void *)a, (lds_void *)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((global_void *)(a + a_half), (lds_void *)(dst + 4 * GROUP_BYTES), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((global_void *)b, (lds_void *)(dst + TILE_BYTES), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((global_void *)(b + b_half), (lds_void *)(dst + TILE_BYTES + 4 * GROUP_BYTES), 16, 0, 0);
     };
-    auto lstore = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            char *d = smem + stage * STAGE_BYTES + st_off + i * 16 * ROW_BYTES;
-            *reinterpret_cast<uint4 *>(d) = ra[i];
-            *reinterpret_cast<uint4 *>(d + TILE_BYTES) = rb[i];
+    auto compute = [&](auto stage_c) {
+        constexpr int SB = decltype(stage_c)::value * STAGE_BYTES;
+        StepFragments f0, f1;
+        if (dbg & 2) {
+            for (int q = 0; q < 8; ++q) { f0.r[q] = s16x4{1, 2, 3, 4}; f1.r[q] = s16x4{1, 2, 3, 4}; }
+            mfma_step(f0, acc);
+            mfma_step(f1, acc);
+        } else if (dbg & 4) {
+            read_step<SB>(f0, a0, a1, b0, b1);
+            wait_step(f0);
+            read_step<SB + 4 * GROUP_BYTES>(f1, a0, a1, b0, b1);
+            wait_step(f1);
+            for (int q = 0; q < 8; ++q) acc[0][0][q] += (float)(f0.r[q][0] ^ f1.r[q][1]);
+        } else {
+        read_step<SB>(f0, a0, a1, b0, b1);
+        wait_step(f0);
+        read_step<SB + 4 * GROUP_BYTES>(f1, a0, a1, b0, b1);      // in flight behind the first four MFMAs
+        mfma_step(f0, acc);
+        wait_step(f1);
+        mfma_step(f1, acc);
         }
         if (want_bias) {
+            // thread t re-reads slot t & 63 of row groups (t >> 6) and (t >> 6) + 4 of the dY tile: always
+            // the same 8 columns (piece (t & 15) ^ 4 ((t >> 4) & 3)), one row of each group
+            u32x4 v[2] = {lds_read_b128<SB>(bias_addr), lds_read_b128<SB + 4 * GROUP_BYTES>(bias_addr)};
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint32_t w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t w[4] = {v[h][0], v[h][1], v[h][2], v[h][3]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     bsum[2 * j] += bf16_to_float(w[j] & 0xffffu);
@@ -124,51 +210,49 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const uint16_t *__res
             }
         }
     };
+    // iteration i: this wave's DMAs of step i have landed once at most the 4 of step i+1 are outstanding;
+    // after the barrier everybody's have, and everybody is done reading step i-1's stage, which is where
+    // step i+2 goes.
+    auto body = [&](int i, auto stage_c) {
+        constexpr int stage = decltype(stage_c)::value;
+        if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!(dbg & 1)) issue(i + 2, (stage + 2) % STAGES);
+        compute(stage_c);
+    };
 
-    if (r0 < r1) {
-        gload(r0);
-        lstore(0);
+    issue(0, 0);
+    issue(1, 1);
+    for (int i = 0;;) {
+        body(i, std::integral_constant<int, 0>{});
+        if (++i >= nsteps) break;
+        body(i, std::integral_constant<int, 1>{});
+        if (++i >= nsteps) break;
+        body(i, std::integral_constant<int, 2>{});
+        if (++i >= nsteps) break;
     }
-    __syncthreads();
-    int stage = 0;
-    for (int k0 = r0; k0 < r1; k0 += BK, stage ^= 1) {
-        const bool more = k0 + BK < r1;
-        if (more) gload(k0 + BK);
-        const int sb = stage * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                af[f] = read_fragment(a_frag + sb + ks * 16 * ROW_BYTES + f * 64);
-                bfr[f] = read_fragment(b_frag + sb + ks * 16 * ROW_BYTES + f * 64);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) lstore(stage ^ 1);
-        __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two surplus DMAs still target our LDS
+    __builtin_amdgcn_s_barrier();
 
-    // partial[chunk][m][k]: accumulator register r of lane l is row 8*(r/4) + 4*(l/32) + r%4, column l%32
+    // partial[chunk][m][k]: accumulator register q of lane l is row 8*(q/4) + 4*(l/32) + q%4, column l%32
     float *out = partial + ((size_t)chunk * M + (size_t)tm * BM + wm * 64) * K + (size_t)tk * BN + wn * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-                out[(size_t)row * K + j * 32 + (lane & 31)] = acc[i][j][r];
+            for (int q = 0; q < 16; ++q) {
+                const int row = i * 32 + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3);
+                out[(size_t)row * K + j * 32 + (lane & 31)] = acc[i][j][q];
             }
 
-    if (want_bias) {
-        float *red = reinterpret_cast<float *>(smem);          // [16 row groups][128 columns]
+    if (want_bias) {                                           // (all waves are past their last LDS read)
+        float *red = reinterpret_cast<float *>(smem);          // [16 threads per column piece][128 columns]
+        const int piece = (tid & 15) ^ (4 * ((tid >> 4) & 3));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[srow * BM + spiece * 8 + j] = bsum[j];
+        for (int j = 0; j < 8; ++j) red[(tid >> 4) * BM + piece * 8 + j] = bsum[j];
         __syncthreads();
         if (tid < BM) {
             float s = 0.f;
@@ -179,17 +263,46 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_kernel(const uint16_t *__res
     }
 }
 
-// out[e] = sum_c partial[c][e]; four elements per thread; bf16 (round-to-nearest-even) or f32 output
-template <bool F32>
+// out[e] = sum_c partial[c][e] + the contribution of the tail rows [tail0, T) the main kernel left out.
+// A workgroup owns 16 consecutive float4s (256 bytes per chunk) and splits the chunks (and the tail rows)
+// over 16 thread groups, so every thread has only chunks/16 independent loads in flight and the grid is
+// n/64 workgroups (a thread-per-element loop over 128 chunks was latency-bound at ~30 us).
+// BIAS: n = M and the tail term is dy[t][e..e+3]; otherwise e = m*K + k and it is dy[t][m] * x[t][k..k+3].
+template <bool F32, bool BIAS>
 __global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__ partial, int chunks, size_t n,
-                                                       void *__restrict__ out)
+                                                       const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                       int tail0, int T, int M, int K, void *__restrict__ out)
 {
-    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= n) return;
+    __shared__ float4 red[16][16];
+    const int q = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const size_t e = ((size_t)blockIdx.x * 16 + q) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int c = 0; c < chunks; ++c) {
-        const float4 v = *reinterpret_cast<const float4 *>(partial + (size_t)c * n + e);
+    if (e < n) {
+#pragma unroll 4
+        for (int c = cg; c < chunks; c += 16) {
+            const float4 v = *reinterpret_cast<const float4 *>(partial + (size_t)c * n + e);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int m = BIAS ? (int)e : (int)(e / K), k = BIAS ? 0 : (int)(e % K);
+        for (int t = tail0 + cg; t < T; t += 16) {
+            if (BIAS) {
+                const uint2 d = *reinterpret_cast<const uint2 *>(dy + (size_t)t * M + m);
+                s.x += bf16_to_float(d.x & 0xffffu); s.y += bf16_to_float(d.x >> 16);
+                s.z += bf16_to_float(d.y & 0xffffu); s.w += bf16_to_float(d.y >> 16);
+            } else {
+                const float d = bf16_to_float(dy[(size_t)t * M + m]);
+                const uint2 xv = *reinterpret_cast<const uint2 *>(x + (size_t)t * K + k);
+                s.x += d * bf16_to_float(xv.x & 0xffffu); s.y += d * bf16_to_float(xv.x >> 16);
+                s.z += d * bf16_to_float(xv.y & 0xffffu); s.w += d * bf16_to_float(xv.y >> 16);
+            }
+        }
+    }
+    red[cg][q] = s;
+    __syncthreads();
+    if (cg != 0 || e >= n) return;
+#pragma unroll
+    for (int g2 = 1; g2 < 16; ++g2) {
+        const float4 v = red[g2][q];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     if (F32) {
@@ -207,23 +320,23 @@ __global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__
     }
 }
 
-struct Plan { int chunks, rows_per_chunk, tiles; size_t partial_floats, bias_floats; };
+struct Plan { int chunks, steps_per_chunk, steps_total, tiles; size_t partial_floats, bias_floats; };
 
 bool make_plan(int T, int M, int K, Plan &pl)
 {
     if (T < 1 || M < BM || K < BN || M % BM || K % BN) return false;
     pl.tiles = (M / BM) * (K / BN);
-    // two workgroups per CU (512 in flight); a chunk is a whole number of 32-token steps
-    static int target = [] { const char *e = getenv("RLIPV2_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    pl.steps_total = T / BK;                                   // whole 32-token steps; the rest is the tail
+    // WAVES_PER_SIMD workgroups per CU in flight
+    static int target = [] { const char *e = getenv("RLIPV2_WGRAD_BLOCKS"); return e ? atoi(e) : 256 * WAVES_PER_SIMD; }();
     int chunks = (target + pl.tiles - 1) / pl.tiles;
-    const int steps = (T + BK - 1) / BK;
-    if (chunks > steps) chunks = steps;
+    if (chunks > pl.steps_total) chunks = pl.steps_total;
     if (chunks < 1) chunks = 1;
-    const int steps_per_chunk = (steps + chunks - 1) / chunks;
-    pl.rows_per_chunk = steps_per_chunk * BK;
-    pl.chunks = (T + pl.rows_per_chunk - 1) / pl.rows_per_chunk;
-    pl.partial_floats = (size_t)pl.chunks * M * K;
-    pl.bias_floats = (size_t)pl.chunks * M;
+    pl.steps_per_chunk = pl.steps_total ? (pl.steps_total + chunks - 1) / chunks : 0;
+    pl.chunks = pl.steps_total ? (pl.steps_total + pl.steps_per_chunk - 1) / pl.steps_per_chunk : 0;
+    // at least one slot so that the workspace is never empty
+    pl.partial_floats = (size_t)(pl.chunks ? pl.chunks : 1) * M * K;
+    pl.bias_floats = (size_t)(pl.chunks ? pl.chunks : 1) * M;
     return true;
 }
 
@@ -253,22 +366,35 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
          reinterpret_cast<uintptr_t>(workspace)) & 15u)
         return MSDA_ERR_ALIGNMENT;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const uint16_t *dy16 = static_cast<const uint16_t *>(dy), *x16 = static_cast<const uint16_t *>(x);
     float *partial = static_cast<float *>(workspace);
-    float *bias_partial = db ? partial + pl.partial_floats : nullptr;
-    const int total = pl.chunks * pl.tiles;
-    const int grid = ((total + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(THREADS), LDS_BYTES, stream,
-                       static_cast<const uint16_t *>(dy), static_cast<const uint16_t *>(x), T, M, K,
-                       pl.rows_per_chunk, pl.chunks, partial, bias_partial);
+    float *bias_partial = partial + pl.partial_floats;
+    if (pl.chunks > 0) {
+        const int total = pl.chunks * pl.tiles;
+        const int grid = ((total + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+        static int dbg = getenv("RLIPV2_WGRAD_DBG") ? atoi(getenv("RLIPV2_WGRAD_DBG")) : 0;
+#define LAUNCH(D) hipLaunchKernelGGL(wgrad_kernel<D>, dim3(grid), dim3(THREADS), LDS_BYTES, stream, dy16, x16, M, K, \
+                                     pl.steps_total, pl.steps_per_chunk, pl.chunks, partial, db ? bias_partial : nullptr)
+        switch (dbg) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        case 4: LAUNCH(4); break;
+        case 5: LAUNCH(5); break;
+        case 7: LAUNCH(7); break;
+        default: LAUNCH(0); break;
+        }
+#undef LAUNCH
+    }
     const size_t n = (size_t)M * K;
+    const int tail0 = pl.steps_total * BK;
+    const dim3 gw((n / 4 + 15) / 16), gb(((size_t)M / 4 + 15) / 16), blk(256);
     if (out_f32) {
-        hipLaunchKernelGGL(reduce_partials<true>, dim3((n / 4 + 255) / 256), dim3(256), 0, stream, partial, pl.chunks, n, dw);
-        if (db) hipLaunchKernelGGL(reduce_partials<true>, dim3(((size_t)M / 4 + 255) / 256), dim3(256), 0, stream,
-                                   bias_partial, pl.chunks, (size_t)M, db);
+        hipLaunchKernelGGL((reduce_partials<true, false>), gw, blk, 0, stream, partial, pl.chunks, n, dy16, x16, tail0, T, M, K, dw);
+        if (db) hipLaunchKernelGGL((reduce_partials<true, true>), gb, blk, 0, stream, bias_partial, pl.chunks, (size_t)M, dy16, x16, tail0, T, M, K, db);
     } else {
-        hipLaunchKernelGGL(reduce_partials<false>, dim3((n / 4 + 255) / 256), dim3(256), 0, stream, partial, pl.chunks, n, dw);
-        if (db) hipLaunchKernelGGL(reduce_partials<false>, dim3(((size_t)M / 4 + 255) / 256), dim3(256), 0, stream,
-                                   bias_partial, pl.chunks, (size_t)M, db);
+        hipLaunchKernelGGL((reduce_partials<false, false>), gw, blk, 0, stream, partial, pl.chunks, n, dy16, x16, tail0, T, M, K, dw);
+        if (db) hipLaunchKernelGGL((reduce_partials<false, true>), gb, blk, 0, stream, bias_partial, pl.chunks, (size_t)M, dy16, x16, tail0, T, M, K, db);
     }
     return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
 }

@@ -7,15 +7,19 @@ T = int(os.environ.get("T", 4 * 22223))
 
 
 def t_us(fn, n=20):
+    """GPU time per call, replayed from a HIP graph so that host-side launch cost does not count"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay(); torch.cuda.synchronize()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(n):
-        fn()
-    e.record(); torch.cuda.synchronize()
+    s.record(); g.replay(); e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
+
 
 
 for M, K in [(256, 256), (384, 256), (1024, 256), (256, 1024), (2048, 256), (256, 2048)]:

@@ -24,6 +24,9 @@ EXPORTS = (
     "msda_prepare_forward", "msda_prepare_backward",
     # include/rlipv2_linear.h
     "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
+    # include/rlipv2_norm.h
+    "add_layernorm_supported", "add_layernorm_workspace_bytes", "add_layernorm_forward_bf16",
+    "add_layernorm_backward_bf16",
 )
 
 _lib = None
@@ -76,6 +79,15 @@ def lib() -> ctypes.CDLL:
     L.linear_wgrad_supported.restype = i
     L.linear_wgrad_bf16.argtypes = [vp, vp, i, i, i, vp, vp, i, vp, ctypes.c_size_t, vp]
     L.linear_wgrad_bf16.restype = i
+    lg, f32 = ctypes.c_long, ctypes.c_float
+    L.add_layernorm_supported.argtypes = [lg, i]
+    L.add_layernorm_supported.restype = i
+    L.add_layernorm_workspace_bytes.argtypes = [lg, i]
+    L.add_layernorm_workspace_bytes.restype = ctypes.c_size_t
+    L.add_layernorm_forward_bf16.argtypes = [vp, vp, vp, vp, lg, i, f32, vp, vp, vp, vp]
+    L.add_layernorm_forward_bf16.restype = i
+    L.add_layernorm_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, lg, i, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.add_layernorm_backward_bf16.restype = i
     _lib = L
     return L
 

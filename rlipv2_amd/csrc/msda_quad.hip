@@ -29,7 +29,7 @@ namespace msda {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kL = 4, kP = 4, kLP = 16, kD = 32;
+constexpr int kL = 4, kP = 4, kD = 32;
 
 // ---- sample geometry --------------------------------------------------------------------------------
 // Addressing is done with buffer loads: a 32-bit byte offset from the tensor base in a wave-uniform

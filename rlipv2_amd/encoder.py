@@ -14,6 +14,7 @@ from torch import nn
 
 from .deform_attn import MSDeformAttn
 from .linear import token_linear
+from .norm import add_layer_norm
 
 
 def _clones(module, n):
@@ -47,11 +48,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         q = src if pos is None else src + pos
-        src = self.norm1(src + self.dropout1(
-            self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)))
+        attn = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        src = add_layer_norm(src, self.dropout1(attn), self.norm1)
         hidden = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
         ffn = token_linear(hidden, self.linear2.weight, self.linear2.bias)
-        return self.norm2(src + self.dropout3(ffn))
+        return add_layer_norm(src, self.dropout3(ffn), self.norm2)
 
 
 def encoder_reference_points(spatial_shapes_list, valid_ratios, device):

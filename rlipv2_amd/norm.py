@@ -1,0 +1,91 @@
+"""Fused residual add + LayerNorm for the encoder's [N, S, 256] token tensors (csrc/add_layernorm.hip,
+C ABI include/rlipv2_norm.h): `norm(src + branch)` of the post-norm encoder layer (reference
+models/dab_deformable/deformable_transformer.py:1261-1300) as one HBM pass per direction.
+
+Smaller or differently shaped inputs (decoder queries, text tokens, float32 autocast runs) keep PyTorch's
+add + layer_norm; there the tensors are a few hundred rows and launch latency, not bandwidth, is the cost.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+MIN_ROWS = 4096
+enabled = True
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def supported(a, b, weight, bias) -> bool:
+    if not (enabled and a.is_cuda and a.dtype == torch.bfloat16 and weight is not None and bias is not None
+            and weight.dtype == torch.bfloat16 and bias.dtype == torch.bfloat16):
+        return False
+    if b is not None and (b.shape != a.shape or b.dtype != a.dtype):
+        return False
+    rows = a.numel() // a.shape[-1]
+    return rows >= MIN_ROWS and bool(_lib.lib().add_layernorm_supported(rows, a.shape[-1]))
+
+
+def _check(st, what):
+    if st:
+        raise RuntimeError(f"{what}: " + _lib.strerror(st))
+
+
+class AddLayerNormFunction(torch.autograd.Function):
+    """y = LayerNorm(a + b); the gradient of a and of b is the same tensor."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, eps):
+        if not a.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        a = a.contiguous()
+        b = None if b is None else b.contiguous()
+        C = a.shape[-1]
+        rows = a.numel() // C
+        y = torch.empty_like(a)
+        mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+        L = _lib.lib()
+        _check(L.add_layernorm_forward_bf16(a.data_ptr(), None if b is None else b.data_ptr(), weight.data_ptr(),
+                                            bias.data_ptr(), rows, C, float(eps), y.data_ptr(), mean.data_ptr(),
+                                            rstd.data_ptr(), torch.cuda.current_stream(a.device).cuda_stream),
+               "add_layernorm_forward")
+        ctx.save_for_backward(a, b, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        a, b, weight, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = a.shape[-1]
+        rows = a.numel() // C
+        L = _lib.lib()
+        dx = torch.empty_like(a)
+        dgamma = torch.empty_like(weight)
+        dbeta = torch.empty_like(weight)
+        ws = _workspace(a.device, L.add_layernorm_workspace_bytes(rows, C))
+        _check(L.add_layernorm_backward_bf16(dy.data_ptr(), a.data_ptr(), None if b is None else b.data_ptr(),
+                                             weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C,
+                                             dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                                             ws.numel(), torch.cuda.current_stream(a.device).cuda_stream),
+               "add_layernorm_backward")
+        return dx, (dx if b is not None else None), dgamma, dbeta, None
+
+
+def add_layer_norm(a, b, norm: torch.nn.LayerNorm):
+    """norm(a + b) (b may be None) with the module's weight / bias / eps."""
+    if supported(a, b, norm.weight, norm.bias) and len(norm.normalized_shape) == 1:
+        return AddLayerNormFunction.apply(a, b, norm.weight, norm.bias, norm.eps)
+    return norm(a if b is None else a + b)

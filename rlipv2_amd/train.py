@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import criterion as crit_mod
+from .linear import swap_linears
 from .backbone import build_r50_backbone
 from .blocks import NestedTensor
 from .parseda import build_parseda, default_args
@@ -154,6 +155,7 @@ def build_training(args=None, device="cuda:0", with_text_encoder=True):
     text_encoder = TextEncoderStub() if with_text_encoder else None
     model = build_parseda(backbone, args, text_encoder=text_encoder).to(device)
     freeze_statically_unused(model)
+    swap_linears(model)
     matcher = crit_mod.HungarianMatcherHOI(cost_obj_class=1, cost_verb_class=1, cost_bbox=2.5, cost_giou=1,
                                            subject_class=args.subject_class)
     criterion = crit_mod.SetCriterionHOI(matcher, crit_mod.build_weight_dict(args.dec_layers),

@@ -80,3 +80,27 @@ def test_token_linear_gradients_match_library_linear():
     # the weight gradient is closer to the float32 result than bf16 rounding of it allows the library to be
     ref = dy.float().flatten(0, 1).t() @ x.float().flatten(0, 1)
     assert (outs[0][2].float() - ref).abs().max() <= 2.0 ** -8 * ref.abs().max() + 1e-3
+
+
+@gpu
+def test_small_linear_and_module_swap():
+    """FastLinear (class swap of nn.Linear) keeps parameters / state_dict and reproduces nn.Linear's output and
+    gradients on a decoder-sized input (bias gradient as a ones-row GEMM instead of a column reduction)."""
+    from rlipv2_amd import linear
+    torch.manual_seed(0)
+    for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2e-2)):
+        ref = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 64)).cuda().to(dtype)
+        fast = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 64)).cuda().to(dtype)
+        fast.load_state_dict(ref.state_dict())
+        assert linear.swap_linears(fast) == 2 and isinstance(fast[0], linear.FastLinear)
+        assert list(fast.state_dict().keys()) == list(ref.state_dict().keys())
+        x = torch.randn(4, 150, 256, device="cuda", dtype=dtype)
+        dy = torch.randn(4, 150, 64, device="cuda", dtype=dtype)
+        res = []
+        for net in (fast, ref):
+            xx = x.clone().requires_grad_(True)
+            y = net(xx)
+            y.backward(dy)
+            res.append([y.detach(), xx.grad] + [p.grad for p in net.parameters()])
+        for a, b in zip(*res):
+            torch.testing.assert_close(a.float(), b.float(), rtol=tol, atol=tol * float(b.float().abs().max()))

@@ -1,0 +1,78 @@
+"""GPU parity of the fused residual-add + LayerNorm kernels (csrc/add_layernorm.hip) against a float32
+PyTorch reference of the same op (floating-point kernel: torch fp32 is the checker).
+
+Tolerances: outputs are bf16 -> one rounding (2^-8 relative) of a float32-exact result; statistics are
+float32 (compared at 1e-5); parameter gradients are sums over all rows in float32, rounded once to bf16."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+gpu = pytest.mark.gpu
+
+
+def _inputs(rows, seed, with_b=True):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(rows, 256, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    b = (torch.randn(rows, 256, generator=g) * 0.7).to(torch.bfloat16) if with_b else None
+    w = (1 + 0.2 * torch.randn(256, generator=g)).to(torch.bfloat16)
+    bias = (0.1 * torch.randn(256, generator=g)).to(torch.bfloat16)
+    dy = torch.randn(rows, 256, generator=g).to(torch.bfloat16)
+    return a, b, w, bias, dy
+
+
+def _reference(a, b, w, bias, dy, eps):
+    x = (a.double() + (0 if b is None else b.double())).requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    y = F.layer_norm(x, (256,), wd, bd, eps)
+    y.backward(dy.double())
+    return y.detach(), x.grad, wd.grad, bd.grad, x.detach().mean(-1), x.detach().var(-1, unbiased=False)
+
+
+@gpu
+@pytest.mark.parametrize("rows", [1, 7, 8, 9, 4099, 88892])
+@pytest.mark.parametrize("with_b", [True, False])
+def test_add_layernorm_forward_backward(rows, with_b):
+    from rlipv2_amd import norm
+    eps = 1e-5
+    a, b, w, bias, dy = _inputs(rows, rows + int(with_b), with_b)
+    ref_y, ref_dx, ref_dw, ref_db, ref_mean, ref_var = _reference(a, b, w, bias, dy, eps)
+    ac = a.cuda().requires_grad_(True)
+    bc = b.cuda().requires_grad_(True) if with_b else None
+    wc, biasc = w.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
+    y = norm.AddLayerNormFunction.apply(ac, bc, wc, biasc, eps)
+    y.backward(dy.cuda())
+    tol = 2.0 ** -8
+    assert y.dtype == torch.bfloat16
+    assert ((y.double().cpu() - ref_y).abs() <= tol * ref_y.abs() + 1e-6).all()
+    assert ((ac.grad.double().cpu() - ref_dx).abs() <= tol * ref_dx.abs() + 2e-3 * ref_dx.abs().max()).all()
+    if with_b:
+        assert torch.equal(bc.grad, ac.grad)
+    scale_w = (dy.double().abs() * ((a.double() + (0 if b is None else b.double()) - ref_mean[:, None])
+                                    / (ref_var[:, None] + eps).sqrt()).abs()).sum(0)
+    assert ((wc.grad.double().cpu() - ref_dw).abs() <= tol * ref_dw.abs() + 1e-5 * scale_w + 1e-6).all()
+    assert ((biasc.grad.double().cpu() - ref_db).abs() <= tol * ref_db.abs() + 1e-5 * dy.double().abs().sum(0) + 1e-6).all()
+
+
+@gpu
+def test_add_layer_norm_module_route_and_fallback():
+    """encoder-sized bf16 input takes the fused kernel; a small or float32 input takes PyTorch's ops; both
+    agree with the plain module."""
+    from rlipv2_amd import norm
+    ln = torch.nn.LayerNorm(256).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.2, 0.2)
+    g = torch.Generator().manual_seed(1)
+    big_a = torch.randn(2, 5000, 256, generator=g).to(torch.bfloat16).cuda()
+    big_b = torch.randn(2, 5000, 256, generator=g).to(torch.bfloat16).cuda()
+    assert norm.supported(big_a, big_b, ln.weight, ln.bias)
+    fused = norm.add_layer_norm(big_a, big_b, ln)
+    plain = ln((big_a.float() + big_b.float()).to(torch.bfloat16))
+    torch.testing.assert_close(fused.float(), plain.float(), rtol=2e-2, atol=3e-2)
+    small = big_a[:, :10]
+    assert not norm.supported(small, None, ln.weight, ln.bias)
+    torch.testing.assert_close(norm.add_layer_norm(small, None, ln), ln(small))
+    ln32 = torch.nn.LayerNorm(256).cuda()
+    assert not norm.supported(big_a.float(), None, ln32.weight, ln32.bias)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        norm.AddLayerNormFunction.apply(torch.zeros(8, 256), None, torch.ones(256), torch.zeros(256), 1e-5)

@@ -53,6 +53,19 @@ print(f"wall {wall:.2f} ms/step; GPU busy (sum of kernels) {sum(cat.values()):.2
       f"launches {sum(calls.values()):.0f}/step")
 for c, t in cat.most_common():
     print(f"  {c:12s} {t:8.2f} ms/step {calls[c]:7.0f} launches")
+small = collections.Counter(); smalln = collections.Counter(); big = collections.Counter(); bign = collections.Counter()
+for e in prof.events():
+    if e.device_type.name != 'CUDA' and str(e.device_type) != 'DeviceType.CUDA':
+        continue
+    t = e.device_time if hasattr(e, 'device_time') else e.cuda_time
+    c = classify(e.name)
+    if t < 8:
+        small[c] += t / steps / 1e3; smalln[c] += 1 / steps
+    else:
+        big[c] += t / steps / 1e3; bign[c] += 1 / steps
+print("kernels shorter than 8 us (latency-bound) vs longer, per category:")
+for c in cat:
+    print(f"  {c:12s} short {small[c]:6.2f} ms ({smalln[c]:5.0f}x)   long {big[c]:6.2f} ms ({bign[c]:5.0f}x)")
 print("top kernels:")
 for n, t in per.most_common(int(os.environ.get("TOP", "45"))):
     print(f"  {t:7.2f} ms {pc[n]:6.0f}x  {n[:150]}")

@@ -1,0 +1,41 @@
+"""GPU-side timeline of the graphed train step: HIP events at the phase boundaries (no extra syncs) and the
+host clock at the same points, averaged over a few steps.  Shows where the GPU waits for the host."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rlipv2_amd import parseda, train
+from rlipv2_amd.train import MasterWeightAdamW
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+margs = parseda.default_args(num_queries=300)
+model, criterion = train.build_training(margs, device="cuda:0", with_text_encoder=True)
+batch = train.synthetic_batch(4, 800, 1333, device="cuda:0")
+train.to_bf16(model)
+batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+step_module = train.ParSeDATrainStep(model)
+opt = MasterWeightAdamW(model)
+model.train()
+graphed = train.graph_step_module(step_module, model, batch)
+names = ["forward graph", "criterion fwd (D2H + LSA + losses)", "backward (criterion eager + model graph)", "optimizer"]
+acc_gpu = [0.0] * 4; acc_host = [0.0] * 4
+for it in range(steps + 3):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    hs = []
+    samples, text, targets = batch
+    ev[0].record(); hs.append(time.perf_counter())
+    outputs = graphed(samples, text, targets)
+    ev[1].record(); hs.append(time.perf_counter())
+    loss = criterion.weighted_sum(criterion(outputs, targets))
+    ev[2].record(); hs.append(time.perf_counter())
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    ev[3].record(); hs.append(time.perf_counter())
+    opt.step(0.1)
+    ev[4].record(); hs.append(time.perf_counter())
+    torch.cuda.synchronize()
+    if it >= 3:
+        for k in range(4):
+            acc_gpu[k] += ev[k].elapsed_time(ev[k + 1]) / steps
+            acc_host[k] += (hs[k + 1] - hs[k]) * 1e3 / steps
+print(f"{'phase':44s} {'GPU timeline ms':>16s} {'host issue ms':>14s}")
+for k in range(4):
+    print(f"{names[k]:44s} {acc_gpu[k]:16.2f} {acc_host[k]:14.2f}")
+print(f"{'sum':44s} {sum(acc_gpu):16.2f} {sum(acc_host):14.2f}")

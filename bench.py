@@ -202,7 +202,7 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         step_module = torch.nn.parallel.DistributedDataParallel(
             step_module, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
             bucket_cap_mb=64)
-    optimizer = train.MasterWeightAdamW(model) if master else train.build_optimizer(model)
+    optimizer = train.FusedMasterAdamW(model) if master else train.build_optimizer(model)
     graphed = False
     eager_step = step_module
     if world == 1 and args.graph and dtype is None:

@@ -27,6 +27,8 @@ EXPORTS = (
     # include/rlipv2_norm.h
     "add_layernorm_supported", "add_layernorm_workspace_bytes", "add_layernorm_forward_bf16",
     "add_layernorm_backward_bf16",
+    # include/rlipv2_optim.h
+    "adamw_abi_sizes", "adamw_grad_sqnorm_bf16", "adamw_step_bf16",
 )
 
 _lib = None
@@ -88,6 +90,13 @@ def lib() -> ctypes.CDLL:
     L.add_layernorm_forward_bf16.restype = i
     L.add_layernorm_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, lg, i, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.add_layernorm_backward_bf16.restype = i
+    ip = ctypes.POINTER(ctypes.c_int)
+    L.adamw_abi_sizes.argtypes = [ip, ip, ip, ip]
+    L.adamw_abi_sizes.restype = i
+    L.adamw_grad_sqnorm_bf16.argtypes = [vp, vp, i, vp, vp]
+    L.adamw_grad_sqnorm_bf16.restype = i
+    L.adamw_step_bf16.argtypes = [vp, vp, i, vp, f32, vp, i, vp]
+    L.adamw_step_bf16.restype = i
     _lib = L
     return L
 

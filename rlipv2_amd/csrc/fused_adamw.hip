@@ -1,0 +1,164 @@
+// fused_adamw.hip -- gradient-norm + clip + AdamW + bf16 parameter write-back in two launches
+// (include/rlipv2_optim.h).  HBM-bound: 2 B/param for the norm, 2 + 12 read + 12 + 2 written for the step.
+//
+// One workgroup (256 threads) per ADAMW_CHUNK = 16 384 elements of one tensor; 8 elements per thread per
+// iteration (one 16-byte bf16 load, two 16-byte loads per float32 stream) when the tensor's pointers are
+// 16-byte aligned, scalar otherwise and for the tail.  The clip coefficient is recomputed by every thread
+// from the device-resident squared norm, so there is no host round trip between the two launches.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rlipv2_msda.h"
+#include "../../include/rlipv2_optim.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct Groups { adamw_group g[ADAMW_MAX_GROUPS]; };
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float bf16_one(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+__device__ __forceinline__ uint32_t to_bf16(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__global__ __launch_bounds__(THREADS) void sqnorm_kernel(const adamw_tensor *__restrict__ tensors,
+                                                         const adamw_chunk *__restrict__ chunks, float *__restrict__ out)
+{
+    const adamw_chunk ck = chunks[blockIdx.x];
+    const adamw_tensor t = tensors[ck.tensor];
+    const int64_t begin = (int64_t)ck.index * ADAMW_CHUNK;
+    const int n = (int)min<int64_t>(ADAMW_CHUNK, t.numel - begin);
+    const uint16_t *g = static_cast<const uint16_t *>(t.grad) + begin;
+    float s = 0.f;
+    int done = 0;
+    if (aligned16(g)) {
+        const int n8 = n & ~7;
+        for (int i = threadIdx.x * 8; i < n8; i += THREADS * 8) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(g + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf16_lo(w[j]), b = bf16_hi(w[j]);
+                s += a * a + b * b;
+            }
+        }
+        done = n8;
+    }
+    for (int i = done + threadIdx.x; i < n; i += THREADS) {
+        const float a = bf16_one(g[i]);
+        s += a * a;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    __shared__ float part[THREADS / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+__device__ __forceinline__ void update_one(float g, float &p, float &m, float &v, const adamw_group &h, float clip,
+                                           float step_size)
+{
+    g *= clip;
+    p *= h.decay;
+    m = h.beta1 * m + h.one_minus_beta1 * g;
+    v = h.beta2 * v + h.one_minus_beta2 * g * g;
+    const float denom = sqrtf(v) / h.bias_correction2_sqrt + h.eps;
+    p -= step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(THREADS) void step_kernel(const adamw_tensor *__restrict__ tensors,
+                                                       const adamw_chunk *__restrict__ chunks,
+                                                       const float *__restrict__ sqnorm, float max_norm, Groups groups)
+{
+    const adamw_chunk ck = chunks[blockIdx.x];
+    const adamw_tensor t = tensors[ck.tensor];
+    const adamw_group h = groups.g[t.group];
+    const int64_t begin = (int64_t)ck.index * ADAMW_CHUNK;
+    const int n = (int)min<int64_t>(ADAMW_CHUNK, t.numel - begin);
+    const uint16_t *g = static_cast<const uint16_t *>(t.grad) + begin;
+    uint16_t *pb = static_cast<uint16_t *>(t.param) + begin;
+    float *p = t.master + begin, *m = t.exp_avg + begin, *v = t.exp_avg_sq + begin;
+    float clip = 1.f;
+    if (max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(*sqnorm) + 1e-6f));
+    const float step_size = h.step_size;
+    int done = 0;
+    if (aligned16(g) && aligned16(pb) && aligned16(p) && aligned16(m) && aligned16(v)) {
+        const int n8 = n & ~7;
+        for (int i = threadIdx.x * 8; i < n8; i += THREADS * 8) {
+            const uint4 gv = *reinterpret_cast<const uint4 *>(g + i);
+            float4 p0 = *reinterpret_cast<const float4 *>(p + i), p1 = *reinterpret_cast<const float4 *>(p + i + 4);
+            float4 m0 = *reinterpret_cast<const float4 *>(m + i), m1 = *reinterpret_cast<const float4 *>(m + i + 4);
+            float4 v0 = *reinterpret_cast<const float4 *>(v + i), v1 = *reinterpret_cast<const float4 *>(v + i + 4);
+            update_one(bf16_lo(gv.x), p0.x, m0.x, v0.x, h, clip, step_size);
+            update_one(bf16_hi(gv.x), p0.y, m0.y, v0.y, h, clip, step_size);
+            update_one(bf16_lo(gv.y), p0.z, m0.z, v0.z, h, clip, step_size);
+            update_one(bf16_hi(gv.y), p0.w, m0.w, v0.w, h, clip, step_size);
+            update_one(bf16_lo(gv.z), p1.x, m1.x, v1.x, h, clip, step_size);
+            update_one(bf16_hi(gv.z), p1.y, m1.y, v1.y, h, clip, step_size);
+            update_one(bf16_lo(gv.w), p1.z, m1.z, v1.z, h, clip, step_size);
+            update_one(bf16_hi(gv.w), p1.w, m1.w, v1.w, h, clip, step_size);
+            *reinterpret_cast<float4 *>(p + i) = p0; *reinterpret_cast<float4 *>(p + i + 4) = p1;
+            *reinterpret_cast<float4 *>(m + i) = m0; *reinterpret_cast<float4 *>(m + i + 4) = m1;
+            *reinterpret_cast<float4 *>(v + i) = v0; *reinterpret_cast<float4 *>(v + i + 4) = v1;
+            uint4 o;
+            o.x = to_bf16(p0.x) | (to_bf16(p0.y) << 16);
+            o.y = to_bf16(p0.z) | (to_bf16(p0.w) << 16);
+            o.z = to_bf16(p1.x) | (to_bf16(p1.y) << 16);
+            o.w = to_bf16(p1.z) | (to_bf16(p1.w) << 16);
+            *reinterpret_cast<uint4 *>(pb + i) = o;
+        }
+        done = n8;
+    }
+    for (int i = done + threadIdx.x; i < n; i += THREADS) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        update_one(bf16_one(g[i]), pp, mm, vv, h, clip, step_size);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        pb[i] = (uint16_t)to_bf16(pp);
+    }
+}
+
+}  // namespace
+
+extern "C" int adamw_abi_sizes(int *tensor_bytes, int *chunk_bytes, int *group_bytes, int *chunk_elements)
+{
+    if (tensor_bytes) *tensor_bytes = (int)sizeof(adamw_tensor);
+    if (chunk_bytes) *chunk_bytes = (int)sizeof(adamw_chunk);
+    if (group_bytes) *group_bytes = (int)sizeof(adamw_group);
+    if (chunk_elements) *chunk_elements = ADAMW_CHUNK;
+    return 0;
+}
+
+extern "C" int adamw_grad_sqnorm_bf16(const adamw_tensor *tensors, const adamw_chunk *chunks, int n_chunks,
+                                      float *sqnorm, void *stream_)
+{
+    if (!tensors || !chunks || !sqnorm) return MSDA_ERR_NULL_POINTER;
+    if (n_chunks < 0) return MSDA_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (hipMemsetAsync(sqnorm, 0, sizeof(float), stream) != hipSuccess) return MSDA_ERR_LAUNCH;
+    if (n_chunks > 0) hipLaunchKernelGGL(sqnorm_kernel, dim3(n_chunks), dim3(THREADS), 0, stream, tensors, chunks, sqnorm);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}
+
+extern "C" int adamw_step_bf16(const adamw_tensor *tensors, const adamw_chunk *chunks, int n_chunks,
+                               const float *sqnorm, float max_norm, const adamw_group *groups, int n_groups,
+                               void *stream_)
+{
+    if (!tensors || !chunks || !groups || (max_norm > 0.f && !sqnorm)) return MSDA_ERR_NULL_POINTER;
+    if (n_chunks < 0 || n_groups < 1 || n_groups > ADAMW_MAX_GROUPS) return MSDA_ERR_BAD_SHAPE;
+    Groups g = {};
+    for (int i = 0; i < n_groups; ++i) g.g[i] = groups[i];
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_chunks > 0)
+        hipLaunchKernelGGL(step_kernel, dim3(n_chunks), dim3(THREADS), 0, stream, tensors, chunks, sqnorm, max_norm, g);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}

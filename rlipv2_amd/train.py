@@ -23,6 +23,7 @@ from torch import nn
 
 from . import criterion as crit_mod
 from .linear import swap_linears
+from .optim import FusedMasterAdamW
 from .backbone import build_r50_backbone
 from .blocks import NestedTensor
 from .parseda import build_parseda, default_args
@@ -269,7 +270,7 @@ def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_
     loss = criterion.weighted_sum(loss_dict)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
-    if isinstance(optimizer, MasterWeightAdamW):
+    if isinstance(optimizer, (MasterWeightAdamW, FusedMasterAdamW)):
         optimizer.step(max_norm)
     else:
         if max_norm > 0:

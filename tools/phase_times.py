@@ -10,7 +10,7 @@ model, criterion = train.build_training(margs, device="cuda:0", with_text_encode
 train.to_bf16(model)
 batch = train.synthetic_batch(4, 800, 1333, device="cuda:0")
 batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-opt = train.MasterWeightAdamW(model)
+opt = train.FusedMasterAdamW(model)
 model.train()
 samples, text, targets = batch
 marks = {}

@@ -11,7 +11,7 @@ batch = train.synthetic_batch(4, 800, 1333, device="cuda:0")
 train.to_bf16(model)
 batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 step_module = train.ParSeDATrainStep(model)
-opt = train.MasterWeightAdamW(model)
+opt = train.FusedMasterAdamW(model)
 model.train()
 for _ in range(3):
     train.train_step(step_module, criterion, opt, batch, autocast_dtype=None)

@@ -11,7 +11,7 @@ if master:
     train.to_bf16(model)
     batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 step_module = train.ParSeDATrainStep(model)
-opt = train.MasterWeightAdamW(model) if master else train.build_optimizer(model)
+opt = train.FusedMasterAdamW(model) if master else train.build_optimizer(model)
 model.train()
 for _ in range(steps):
     train.train_step(step_module, criterion, opt, batch, autocast_dtype=None if master else torch.bfloat16)

@@ -3,7 +3,7 @@ host clock at the same points, averaged over a few steps.  Shows where the GPU w
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlipv2_amd import parseda, train
-from rlipv2_amd.train import MasterWeightAdamW
+from rlipv2_amd.train import FusedMasterAdamW as MasterWeightAdamW
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 margs = parseda.default_args(num_queries=300)
 model, criterion = train.build_training(margs, device="cuda:0", with_text_encoder=True)

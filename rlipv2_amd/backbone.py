@@ -5,7 +5,9 @@ Reference: models/DDETR_backbone.py (FrozenBatchNorm2d :27-59, BackboneBase :62-
 train, features C3/C4/C5 at strides 8/16/32 with nearest-interpolated masks, Joiner :135-160).  The
 reference builds the trunk from torchvision (absent here); this is a plain restatement of the
 ResNet-50 v1.5 topology with torchvision's parameter names (``body.layerK.B.convJ`` ...), so
-ImageNet / reference checkpoints load.  Host PyTorch (MIOpen convolutions): not a kernel target.
+ImageNet / reference checkpoints load.  3x3 / strided convolutions are MIOpen's; the 1x1 stride-1
+convolutions of the bf16 channels-last path run as token-major GEMMs with BatchNorm and ReLU folded in
+(`pointwise_conv_bn`).
 """
 from __future__ import annotations
 
@@ -14,6 +16,10 @@ import torch.nn.functional as F
 from torch import nn
 
 from .blocks import NestedTensor, PositionEmbeddingSine
+from .linear import token_linear
+
+# 1x1 convolutions of channels-last bf16 feature maps as token-major GEMMs (tests switch it off to compare)
+pointwise_as_gemm = True
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -48,6 +54,24 @@ class FrozenBatchNorm2d(nn.Module):
         scale, bias = self._folded(x.dtype)
         return torch.addcmul(bias, x, scale)
 
+    def folded_vectors(self, dtype):
+        """(scale [C], bias [C]) of the frozen affine map"""
+        scale, bias = self._folded(dtype)
+        return scale.view(-1), bias.view(-1)
+
+
+def pointwise_conv_bn(x, conv, bn, relu):
+    """1x1 stride-1 convolution + frozen BatchNorm (+ ReLU) of a channels-last bf16 tensor as ONE GEMM over
+    the N*H*W pixels: the BN scale is folded into the weight rows (a [Cout, Cin] multiply, differentiable
+    w.r.t. the weight), the BN shift is the GEMM bias and the ReLU its epilogue, so the separate BN and
+    activation passes over the feature map disappear and the weight gradient runs on the token-major MFMA
+    kernel (linear.py) instead of MIOpen's split-K path with its float32 workspace zero/cast kernels."""
+    N, C, H, W = x.shape
+    scale, bias = bn.folded_vectors(x.dtype)
+    w = conv.weight.reshape(conv.out_channels, C) * scale[:, None]
+    y = token_linear(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w, bias, relu=relu)
+    return y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
+
 
 class Bottleneck(nn.Module):
     expansion = 4
@@ -64,6 +88,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
+        if pointwise_as_gemm and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+            out = pointwise_conv_bn(x, self.conv1, self.bn1, relu=True)
+            out = F.relu(self.bn2(self.conv2(out)))
+            if out.is_contiguous(memory_format=torch.channels_last):
+                return F.relu(pointwise_conv_bn(out, self.conv3, self.bn3, relu=False) + idt)
+            return F.relu(self.bn3(self.conv3(out)) + idt)
         out = F.relu(self.bn1(self.conv1(x)))
         out = F.relu(self.bn2(self.conv2(out)))
         return F.relu(self.bn3(self.conv3(out)) + idt)

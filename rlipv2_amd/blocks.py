@@ -18,6 +18,8 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from .linear import token_linear
+
 
 def inverse_sigmoid(x: Tensor, eps: float = 1e-5) -> Tensor:
     x = x.clamp(min=0, max=1)
@@ -35,7 +37,7 @@ class MLP(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         for layer in self.layers[:-1]:
-            x = F.relu(layer(x))
+            x = token_linear(x, layer.weight, layer.bias, relu=True)
         return self.layers[-1](x)
 
 

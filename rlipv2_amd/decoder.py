@@ -6,11 +6,13 @@ and DABDeformableTransformerDecoderHOI (:1404-1552).  Parameter names match the 
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .blocks import MLP, inverse_sigmoid, sine_embed_for_position
 from .deform_attn import MSDeformAttn
 from .encoder import _activation, _clones
+from .linear import token_linear
 
 
 class DeformableTransformerDecoderLayer(nn.Module):
@@ -44,7 +46,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
         ca = self.cross_attn(tgt if query_pos is None else tgt + query_pos, reference_points, src,
                              src_spatial_shapes, level_start_index, src_padding_mask)
         tgt = self.norm1(tgt + self.dropout1(ca))
-        ffn = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        if self.activation is F.relu:
+            hidden = token_linear(tgt, self.linear1.weight, self.linear1.bias, relu=True)
+        else:
+            hidden = self.activation(self.linear1(tgt))
+        ffn = self.linear2(self.dropout3(hidden))
         return self.norm3(tgt + self.dropout4(ffn))
 
 

@@ -50,7 +50,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
         q = src if pos is None else src + pos
         attn = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = add_layer_norm(src, self.dropout1(attn), self.norm1)
-        hidden = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
+        if self.activation is F.relu:
+            hidden = self.dropout2(token_linear(src, self.linear1.weight, self.linear1.bias, relu=True))
+        else:
+            hidden = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
         ffn = token_linear(hidden, self.linear2.weight, self.linear2.bias)
         return add_layer_norm(src, self.dropout3(ffn), self.norm2)
 

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import _lib
 
 # rows below this go to the library (its weight-gradient GEMM is fine when the reduction is short)
-MIN_ROWS = 8192
+MIN_ROWS = 4096
 enabled = True
 
 _workspaces = {}
@@ -67,22 +67,34 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True, out_
     return dw, db
 
 
+def _linear_forward(x, weight, bias, relu):
+    if relu and bias is not None:
+        # bias + ReLU in the GEMM epilogue (hipBLASLt): no separate activation pass over the output
+        y = torch._addmm_activation(bias, x.reshape(-1, x.shape[-1]), weight.t())
+        return y.view(*x.shape[:-1], weight.shape[0])
+    y = F.linear(x, weight, bias)
+    return F.relu(y) if relu else y
+
+
 class TokenLinearFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+    def forward(ctx, x, weight, bias, relu=False):
+        y = _linear_forward(x, weight, bias, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            dy = torch.ops.aten.threshold_backward(dy, y, 0)
         dx = dy.matmul(weight) if ctx.needs_input_grad[0] else None
         dw = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = linear_wgrad(dy, x, with_bias=ctx.has_bias, out_dtype=weight.dtype)
-        return dx, dw, db
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, db = linear_wgrad(dy, x, with_bias=ctx.needs_input_grad[2], out_dtype=weight.dtype)
+        return dx, dw, db, None
 
 
 _ones = {}
@@ -103,30 +115,38 @@ class SmallLinearFunction(torch.autograd.Function):
     more small GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        return F.linear(x, weight, bias)
+    def forward(ctx, x, weight, bias, relu=False):
+        y = _linear_forward(x, weight, bias, relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            dy = torch.ops.aten.threshold_backward(dy, y, 0)
         dy2 = dy.reshape(-1, dy.shape[-1])
         dx = dy.matmul(weight) if ctx.needs_input_grad[0] else None
         dw = dy2.t().mm(x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
         db = _ones_row(dy2.shape[0], dy2).mm(dy2).view(-1) if ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def token_linear(x, weight, bias=None):
-    """F.linear with the MFMA weight-gradient kernel behind it when the shape qualifies."""
+def token_linear(x, weight, bias=None, relu=False):
+    """relu?(F.linear(x, weight, bias)) with the MFMA weight-gradient kernel behind it when the shape
+    qualifies; `relu=True` puts the activation into the GEMM epilogue."""
     if torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
         if supported(x, weight):
-            return TokenLinearFunction.apply(x, weight, bias)
-        if (enabled and x.is_cuda and bias is not None and bias.requires_grad and x.dtype == weight.dtype
-                and x.dtype in (torch.bfloat16, torch.float32)):
-            return SmallLinearFunction.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+            return TokenLinearFunction.apply(x, weight, bias, relu)
+        if (enabled and x.is_cuda and bias is not None and x.dtype == weight.dtype
+                and x.dtype in (torch.bfloat16, torch.float32) and (bias.requires_grad or relu)):
+            return SmallLinearFunction.apply(x, weight, bias, relu)
+    if x.is_cuda:
+        return _linear_forward(x, weight, bias, relu)
+    y = F.linear(x, weight, bias)
+    return F.relu(y) if relu else y
 
 
 class FastLinear(torch.nn.Linear):

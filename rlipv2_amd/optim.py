@@ -13,6 +13,11 @@ import torch
 from . import _lib
 
 
+def _same_layout(a, b):
+    """same element order in memory (strides of size-1 dimensions are arbitrary and ignored)"""
+    return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
 class _Group(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in ("beta1", "beta2", "one_minus_beta1", "one_minus_beta2", "eps", "decay",
                                               "step_size", "bias_correction2_sqrt")]
@@ -52,7 +57,7 @@ class FusedMasterAdamW:
         assert (sizes[0].value, sizes[1].value, sizes[2].value) == (56, 8, ctypes.sizeof(_Group)), "ABI mismatch"
         self.chunk = sizes[3].value
         self._tables = {}        # tuple of gradient pointers -> (tensor table, chunk table, n_chunks)
-        self._keep = []
+        self._relayout = {}
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -64,9 +69,14 @@ class FusedMasterAdamW:
             g = p.grad
             if g is None:
                 continue                                   # torch.optim skips parameters without gradient
-            if g.dtype != torch.bfloat16 or g.stride() != p.stride():
-                g = torch.empty_like(p).copy_(g)
-                self._keep.append(g)
+            if g.dtype != torch.bfloat16 or not _same_layout(g, p):
+                # e.g. a convolution weight kept channels-last whose gradient arrives contiguous: re-lay it
+                # out into a persistent buffer (stable address -> the pointer table stays cached)
+                buf = self._relayout.get(i)
+                if buf is None:
+                    buf = self._relayout[i] = torch.empty_like(p)
+                g = buf.copy_(g)
+                self.grad_copies = getattr(self, "grad_copies", 0) + 1
             idx.append(i)
             grads.append(g)
         return idx, grads
@@ -85,6 +95,7 @@ class FusedMasterAdamW:
             chunks += [(r, c) for c in range((n + self.chunk - 1) // self.chunk)]
         t_dev = torch.from_numpy(rows).to(self.device)
         c_dev = torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 2)).to(self.device)
+        self.table_builds = getattr(self, "table_builds", 0) + 1
         if len(self._tables) > 8:
             self._tables.clear()
         self._tables[key] = (t_dev, c_dev, len(chunks))
@@ -92,7 +103,6 @@ class FusedMasterAdamW:
 
     @torch.no_grad()
     def step(self, max_norm=0.1):
-        self._keep.clear()
         idx, grads = self._grads()
         if not idx:
             return

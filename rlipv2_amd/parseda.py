@@ -17,6 +17,8 @@ Text: the reference tokenises label strings on the CPU and runs RoBERTa-base eve
 """
 from __future__ import annotations
 
+import os
+
 import math
 from types import SimpleNamespace
 
@@ -31,6 +33,10 @@ from .blocks import (MLP, FeatureResizer, MultiBranchFusion, NestedTensor, inver
 from .decoder import DABDeformableTransformerDecoderHOI, DeformableTransformerDecoderLayer
 from .deform_attn import MSDeformAttn
 from .encoder import DeformableTransformerEncoderLayer, RLIPv2_DeformableTransformerEncoder, _clones
+
+
+# encode the label texts on a second HIP stream, concurrently with the backbone (RLIP_ParSeDA._encode)
+overlap_text_encoder = os.environ.get("RLIPV2_NO_TEXT_OVERLAP", "0") != "1"
 
 
 def default_args(**overrides):
@@ -299,7 +305,8 @@ class RLIP_ParSeDA(nn.Module):
         # overlap the same way.
         encoded_text = None
         tr = self.transformer
-        if isinstance(text, dict) and samples.tensors.is_cuda and getattr(tr, "text_encoder", None) is not None:
+        if (isinstance(text, dict) and samples.tensors.is_cuda and getattr(tr, "text_encoder", None) is not None
+                and overlap_text_encoder):
             cur = torch.cuda.current_stream()
             side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=samples.tensors.device))
             side.wait_stream(cur)

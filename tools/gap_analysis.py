@@ -6,13 +6,8 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-# step boundaries: the fused AdamW kernels (a burst at the end of every step)
-opt = [r[1] for r in rows if "FusedOptimizer" in r[2]]
-bounds = [opt[0]]
-for t_prev, t in zip(opt, opt[1:]):
-    if t - t_prev > 10e6:
-        bounds.append(t_prev)          # end of the previous burst
-bounds.append(opt[-1])
+# step boundaries: the fused AdamW kernel (csrc/fused_adamw.hip) ends every step
+bounds = [r[1] for r in rows if "step_kernel" in r[2]]
 ends = sorted(set(bounds))
 print("step durations (ms):", " ".join(f"{(b2 - b1) / 1e6:.1f}" for b1, b2 in zip(ends, ends[1:])))
 pick = int(sys.argv[2]) if len(sys.argv) > 2 else 4          # analyse the step ending at ends[-pick]
@@ -48,6 +43,23 @@ for g, a, b in gaps:
 print("idle time by preceding kernel:")
 for n, t in by.most_common(18):
     print(f"  {t / 1e6:7.2f} ms {cnt[n]:6d}x  avg {t / cnt[n] / 1e3:6.1f} us  {n}")
+pairs = collections.Counter(); pcnt = collections.Counter()
+for g, a, b in gaps:
+    if g >= 12000:
+        k = (a[:58], b[:58]); pairs[k] += g; pcnt[k] += 1
+print("gaps >= 12 us by (previous kernel -> next kernel):")
+for (a, b), t in pairs.most_common(25):
+    print(f"  {t / 1e6:6.2f} ms {pcnt[(a, b)]:4d}x  {a}  ->  {b}")
+# position of the idle time inside the step (tenths of the step)
+pos = [0.0] * 10
+for (s0, e0, _), (s1, _, _) in zip(win, win[1:]):
+    pass
+cur = win[0][1]
+for s_, e_, _ in win[1:]:
+    if s_ > cur:
+        pos[min(9, int(10 * (cur - t0) / (t1 - t0)))] += (s_ - cur) / 1e6
+    cur = max(cur, e_)
+print("idle ms per tenth of the step:", " ".join(f"{x:.1f}" for x in pos))
 print("longest gaps:")
 for g, a, b in sorted(gaps, reverse=True)[:12]:
     print(f"  {g / 1e3:8.1f} us  after {a[:60]}  before {b[:60]}")

@@ -44,8 +44,45 @@ def run(record):
             marks.setdefault(n1, []).append(e0.elapsed_time(e1))
 for i in range(6):
     run(i >= 2)
+
+# kernel launches and GPU-busy time per phase: one profiler session per phase of one more eager step
+from torch.profiler import profile, ProfilerActivity
+counts = {}
+class Phase:
+    def __init__(self, name): self.name = name
+    def __enter__(self):
+        torch.cuda.synchronize(); self.p = profile(activities=[ProfilerActivity.CUDA]); self.p.__enter__(); return self
+    def __exit__(self, *a):
+        torch.cuda.synchronize(); self.p.__exit__(*a)
+        ev_ = [e for e in self.p.events() if str(e.device_type).endswith("CUDA")]
+        counts[self.name] = (len(ev_), sum((e.device_time if hasattr(e, "device_time") else e.cuda_time) for e in ev_) / 1e3)
+import torch.nn.functional as F
+with Phase("backbone"):
+    features, pos = model.backbone(samples)
+with Phase("input_proj+pos"):
+    srcs, masks = [], []
+    for l, feat in enumerate(features):
+        src, mask = feat.decompose(); srcs.append(model.input_proj[l](src)); masks.append(mask)
+    src = model.input_proj[3](features[-1].tensors)
+    mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
+    pos.append(model.backbone[1](NestedTensor(src, mask)).to(src.dtype)); srcs.append(src); masks.append(mask)
+tr = model.transformer
+with Phase("text_encoder"):
+    pooled = tr.text_encoder(input_ids=text["input_ids"], attention_mask=text["attention_mask"]).pooler_output
+with Phase("transformer phase A (incl. 2nd text enc)"):
+    mc = tr(srcs=srcs, masks=masks, pos_embeds=pos, query_embed=model._query_embeds(), text=text, encode_and_save=True)
+with Phase("phase B decoders+heads"):
+    out = model(samples, encode_and_save=False, memory_cache=mc, text=text, targets=targets)
+with Phase("criterion"):
+    loss = criterion.weighted_sum(criterion(out, targets))
+opt.zero_grad()
+with Phase("backward"):
+    (loss + 0 * pooled.float().sum()).backward()
+with Phase("clip+optimizer"):
+    opt.step(0.1)
 tot = 0
 for k, v in marks.items():
     m = sum(v) / len(v); tot += m
-    print(f"{k:45s} {m:8.2f} ms")
+    c = counts.get(k, (0, 0.0))
+    print(f"{k:45s} {m:8.2f} ms eager wall   {c[0]:5d} launches  {c[1]:7.2f} ms GPU busy")
 print(f"{'sum':45s} {tot:8.2f} ms")

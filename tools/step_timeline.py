@@ -27,6 +27,7 @@ for it in range(steps + 3):
     ev[2].record(); hs.append(time.perf_counter())
     opt.zero_grad(set_to_none=True)
     loss.backward()
+    graphed.backward()
     ev[3].record(); hs.append(time.perf_counter())
     opt.step(0.1)
     ev[4].record(); hs.append(time.perf_counter())
@@ -39,3 +40,5 @@ print(f"{'phase':44s} {'GPU timeline ms':>16s} {'host issue ms':>14s}")
 for k in range(4):
     print(f"{names[k]:44s} {acc_gpu[k]:16.2f} {acc_host[k]:14.2f}")
 print(f"{'sum':44s} {sum(acc_gpu):16.2f} {sum(acc_host):14.2f}")
+print("optimizer table builds:", getattr(opt, "table_builds", 0), " gradient re-layout copies:", getattr(opt, "grad_copies", 0),
+      " steps:", opt.t)

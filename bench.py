@@ -196,27 +196,38 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     step_module = train.ParSeDATrainStep(model)
     model.train()
     dtype = torch.bfloat16 if (args.dtype == "bf16" and not master) else None
-    if world > 1:
-        # static unused-parameter mask from a dry run, then DDP without per-step graph searches
-        train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
-        step_module = torch.nn.parallel.DistributedDataParallel(
-            step_module, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
-            bucket_cap_mb=64)
-    optimizer = train.FusedMasterAdamW(model) if master else train.build_optimizer(model)
     graphed = False
+    synchronizer = None
     eager_step = step_module
-    if world == 1 and args.graph and dtype is None:
+    force_dp = os.environ.get("RLIPV2_FORCE_DP") == "1" and dist.is_initialized()   # 1-rank plumbing check
+    if world > 1 or force_dp:
+        train.broadcast_parameters(model, 0)
+        # static unused-parameter mask from a dry run (identical on every rank), instead of per-step graph
+        # searches (find_unused_parameters=True in the reference, main.py:517)
+        train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
+    if args.graph and dtype is None:
         # HIP-graph the two model phases (forward graph + backward graph); the criterion's host-side
-        # assignment and the optimiser stay eager.  Not used under DDP (cannot be validated on one GPU).
+        # assignment and the optimiser stay eager.  Data-parallel runs average the gradients with one flat
+        # RCCL all-reduce after the backward replay (train.GradientSynchronizer).
         try:
-            train.freeze_parameters_without_gradient(step_module, criterion, batch)
-            step_module = train.graph_step_module(step_module, model, batch)
+            if world == 1 and not force_dp:
+                train.freeze_parameters_without_gradient(step_module, criterion, batch)
+            else:
+                synchronizer = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
+            step_module = train.graph_step_module(step_module, model, batch, synchronizer)
             graphed = True
         except Exception as e:                                  # noqa: BLE001 -- fall back to eager, say so
             import traceback
             tb = "".join(traceback.format_exception(type(e), e, e.__traceback__)[-8:])
             print(f"[bench] graph capture failed, running eager: {type(e).__name__}\n{tb}", file=sys.stderr)
             torch.cuda.synchronize()
+            step_module = eager_step
+    if (world > 1 or force_dp) and not graphed:
+        step_module = torch.nn.parallel.DistributedDataParallel(
+            eager_step, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
+            bucket_cap_mb=64)
+        eager_step = step_module
+    optimizer = train.FusedMasterAdamW(model) if master else train.build_optimizer(model)
     timer = KernelTimer()
     for _ in range(args.warmup):
         train.train_step(step_module, criterion, optimizer, batch, autocast_dtype=dtype)
@@ -239,7 +250,7 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if graphed and rank == 0:
+    if graphed:                          # every rank: the criterion holds a collective
         # kernels inside a replayed graph cannot be bracketed with events: probe them in two eager steps
         # of the very same train step (same model, batch, optimiser), right after the timed region
         timer.enabled = True
@@ -337,7 +348,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    if world > 1:
+    if world > 1 or (os.environ.get("RLIPV2_FORCE_DP") == "1" and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
@@ -354,8 +365,9 @@ def main():
                                      ("bf16 parameters/activations/gradients with float32 master weights" if args.precision == "master"
                                       else "bf16 autocast over float32 weights") if args.dtype == "bf16" else "float32",
                                      n_params / 1e6, loss)),
-                 parallelism=f"dp{world} (RCCL gradient all-reduce, bucketed, overlapped with backward)"
-                             + ("; model forward/backward replayed as HIP graphs" if graphed else "; eager launches"),
+                 parallelism=(f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
+                              "model forward/backward replayed as HIP graphs" if graphed else
+                              f"dp{world} (DDP: bucketed RCCL gradient all-reduce overlapped with backward); eager launches"),
                  cpu_calls=lambda: build_msda_step(1, torch.float32, device, 0),
                  probe_steps=2 if graphed else None,
                  probe_note=("HIP events around every MSDA call in 2 eager steps of the same train step run right after "

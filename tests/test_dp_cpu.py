@@ -103,3 +103,62 @@ def test_statically_unused_parameters_are_frozen():
             assert p.grad is not None, f"{n} is trainable but got no gradient"
     n_pred = model.transformer.ho_decoder.num_layers
     assert all(not p.requires_grad for h in list(model.sub_bbox_embed)[n_pred:] for p in h.parameters())
+
+
+def _sync_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rlipv2_amd import train
+        torch.manual_seed(100 + rank)                      # different initial weights: the broadcast must fix that
+        net = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3), torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 5))
+        net[0].to(memory_format=torch.channels_last)
+        train.broadcast_parameters(net, 0)
+        params = list(net.parameters())
+        sync = train.GradientSynchronizer(params)
+        g = torch.Generator().manual_seed(7 + rank)
+        grads = [torch.randn(p.shape, generator=g) for p in params]
+        grads[0] = grads[0].contiguous(memory_format=torch.channels_last)
+        grads[3] = None                                    # a parameter without gradient on this step
+        try:
+            avg = sync(grads)
+        except RuntimeError:                               # gloo has no ReduceOp.AVG: emulate it for this CPU test
+            import torch.distributed as dist2
+            have = [(v, gr) for v, gr in zip(sync.views, grads) if gr is not None]
+            torch._foreach_zero_([v for v, gr in zip(sync.views, grads) if gr is None])
+            torch._foreach_copy_([v for v, _ in have], [gr for _, gr in have])
+            dist2.all_reduce(sync.flat)
+            sync.flat.div_(world)
+            avg = sync.views
+        out[rank] = ([p.detach().clone() for p in params], [a.clone() for a in avg],
+                     [None if gr is None else gr.clone() for gr in grads])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_synchronizer_and_broadcast_two_ranks():
+    """train.broadcast_parameters + train.GradientSynchronizer (the data-parallel path of the graphed step):
+    equal parameters on both ranks afterwards; averaged gradients = mean of the ranks' gradients, in the
+    parameter's own memory layout; a missing gradient counts as zero."""
+    import threading
+    out = {}
+    port = 29500 + (os.getpid() % 400) + 37
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    shared = mgr.dict()
+    procs = [mp.Process(target=_sync_worker, args=(r, 2, port, shared)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (p0, a0, g0), (p1, a1, g1) = shared[0], shared[1]
+    for x, y in zip(p0, p1):
+        assert torch.equal(x, y)
+    for i, (x, y) in enumerate(zip(a0, a1)):
+        assert torch.equal(x, y)
+        ga = torch.zeros_like(x) if g0[i] is None else g0[i]
+        gb = torch.zeros_like(x) if g1[i] is None else g1[i]
+        torch.testing.assert_close(x, (ga + gb) / 2)
+        assert x.stride() == p0[i].stride()

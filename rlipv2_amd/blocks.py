@@ -107,12 +107,17 @@ class FeatureResizer(nn.Module):
 
 
 class NestedTensor:
-    def __init__(self, tensors: Tensor, mask: Optional[Tensor]):
+    """`no_padding` is a host-side hint (set by whoever built the batch) that the mask is all False: the
+    model then skips the value masking inside MSDeformAttn (identical results, no device round trip)."""
+
+    def __init__(self, tensors: Tensor, mask: Optional[Tensor], no_padding: bool = False):
         self.tensors = tensors
         self.mask = mask
+        self.no_padding = no_padding
 
     def to(self, device):
-        return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
+        return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device),
+                            self.no_padding)
 
     def decompose(self):
         return self.tensors, self.mask
@@ -134,7 +139,7 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor]) -> NestedTensor:
     for img, pad, m in zip(tensor_list, batch, mask):
         pad[:, : img.shape[1], : img.shape[2]].copy_(img)
         m[: img.shape[1], : img.shape[2]] = False
-    return NestedTensor(batch, mask)
+    return NestedTensor(batch, mask, no_padding=all(t.shape[1] == h and t.shape[2] == w for t in tensor_list))
 
 
 class PositionEmbeddingSine(nn.Module):

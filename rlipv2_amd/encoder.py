@@ -90,7 +90,7 @@ class RLIPv2_DeformableTransformerEncoder(nn.Module):
         self.lang_aux_loss = lang_aux_loss
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
-                lang_hidden=None, lang_masks=None, spatial_shapes_list=None):
+                lang_hidden=None, lang_masks=None, spatial_shapes_list=None, skip_value_mask=False):
         if spatial_shapes_list is None:                      # reference behaviour: read them back
             spatial_shapes_list = [(int(h), int(w)) for h, w in spatial_shapes.tolist()]
         last_start = sum(h * w for h, w in spatial_shapes_list[:-1])
@@ -115,7 +115,8 @@ class RLIPv2_DeformableTransformerEncoder(nn.Module):
                 output = torch.cat([output[:, :last_start], part], 1) if self.fusion_last_vis else part
                 hidden = self.roberta_layers[k](hidden_states=hidden, attention_mask=lang_mask)
                 collected.append(hidden)
-            output = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+            output = layer(output, pos, reference_points, spatial_shapes, level_start_index,
+                           None if skip_value_mask else padding_mask)
         if self.lang_aux_loss:
             lang = torch.stack(collected if self.fusion_interval == 2 else collected[::2], dim=0)
         else:

@@ -132,7 +132,7 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
     def forward(self, srcs=None, masks=None, pos_embeds=None, query_embed=None, text=None, encode_and_save=True,
                 text_memory=None, img_memory=None, text_attention_mask=None, obj_pred_names_sums=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, spatial_shapes_list=None,
-                encoded_text=None):
+                encoded_text=None, no_padding=False):
         assert query_embed is not None
         if encode_and_save:
             shapes_list = [tuple(s.shape[-2:]) for s in srcs]
@@ -157,7 +157,7 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
             img_memory, lang = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, lvl_pos,
                                             mask_flatten, lang_hidden=text_memory.transpose(0, 1),
                                             lang_masks=text_attention_mask.transpose(0, 1),
-                                            spatial_shapes_list=shapes_list)
+                                            spatial_shapes_list=shapes_list, skip_value_mask=no_padding)
             # [N, n_text, 768] or, with lang_aux_loss, [n_fusions, N, n_text, 768] -> text-major + resize
             text_memory_resized = self.resizer(lang.transpose(0, 1) if lang.dim() == 3 else lang.transpose(1, 2))
             return {
@@ -167,7 +167,8 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
                 "text_memory_resized": text_memory_resized,
                 "text_memory": text_memory_resized,
                 "img_memory": img_memory,
-                "masks": mask_flatten,
+                # (only consumed as MSDeformAttn's value mask in the decoders: an all-False mask is dropped)
+                "masks": None if no_padding else mask_flatten,
                 "text_attention_mask": text_attention_mask,
                 "pos_embed": lvl_pos,
                 "ho_query_embed": query_embed,
@@ -331,7 +332,8 @@ class RLIP_ParSeDA(nn.Module):
             for t in encoded_text[:2]:
                 t.record_stream(torch.cuda.current_stream())
         return self.transformer(srcs=srcs, masks=masks, pos_embeds=pos, query_embed=query_embeds, text=text,
-                                encode_and_save=True, encoded_text=encoded_text)
+                                encode_and_save=True, encoded_text=encoded_text,
+                                no_padding=bool(getattr(samples, "no_padding", False)))
 
     def forward(self, samples, encode_and_save=True, memory_cache=None, **kwargs):
         if not isinstance(samples, NestedTensor):

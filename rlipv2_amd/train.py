@@ -78,10 +78,11 @@ class GraphedTrainForward(nn.Module):
         self.sums = obj_pred_names_sums
         self.n_layers = n_layers
         self.pseudo_verb = pseudo_verb
+        self.no_padding = False
 
     def forward(self, images, mask, input_ids, attention_mask, verb_labels):
         text = {"input_ids": input_ids, "attention_mask": attention_mask, "obj_pred_names_sums": self.sums}
-        out = self.step(NestedTensor(images, mask), text, [{"verb_labels": verb_labels}])
+        out = self.step(NestedTensor(images, mask, self.no_padding), text, [{"verb_labels": verb_labels}])
         flat = [out[k] for k in OUT_KEYS]
         for aux in out.get("aux_outputs", []):
             flat += [aux[k] for k in OUT_KEYS]
@@ -124,6 +125,7 @@ class GraphedStep:
         self.synchronizer = synchronizer
         self.wrapper = GraphedTrainForward(step_module, text["obj_pred_names_sums"],
                                            model.transformer.ho_decoder.num_layers, model.pseudo_verb)
+        self.wrapper.no_padding = bool(getattr(samples, "no_padding", False))      # baked into the capture
         self.params = [p for p in step_module.parameters() if p.requires_grad]
         verbs = torch.cat([t["verb_labels"] for t in targets])
         self.static_in = [samples.tensors, samples.mask, text["input_ids"], text["attention_mask"], verbs]
@@ -152,6 +154,8 @@ class GraphedStep:
         self.leaves = None
 
     def __call__(self, samples, text, targets):
+        if bool(getattr(samples, "no_padding", False)) != self.wrapper.no_padding:
+            raise RuntimeError("GraphedStep was captured for a batch with a different padding hint; capture again")
         verbs = torch.cat([t["verb_labels"] for t in targets])
         for dst, src in zip(self.static_in, (samples.tensors, samples.mask, text["input_ids"], text["attention_mask"], verbs)):
             if dst.data_ptr() != src.data_ptr():
@@ -382,7 +386,7 @@ def synthetic_batch(batch, height=800, width=1333, n_obj=43, n_verb=21, triplets
                         "obj_labels": torch.randint(0, n_obj - 1, (triplets,), generator=g).to(device),
                         "verb_labels": verbs.to(device),
                         "sub_boxes": torch.cat([c, wh], 1).to(device), "obj_boxes": torch.cat([c2, wh2], 1).to(device)})
-    return NestedTensor(images, mask), text, targets
+    return NestedTensor(images, mask, no_padding=True), text, targets
 
 
 def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_dtype=torch.bfloat16):

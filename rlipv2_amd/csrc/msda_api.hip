@@ -36,7 +36,12 @@ int pick(bool backward, const Problem &p)
     // kernel's own scatter (strided 4-byte global atomics, 64 sectors per instruction) measured
     // 34 ms at the encoder shape against 4.6 ms for the generic kernel's 128-byte rows and 1.1 ms
     // for the sorted scatter, so it is never picked automatically.
-    if (window_supports(p, backward)) return MSDA_VARIANT_WINDOW;
+    if (backward && window_supports(p, true)) return MSDA_VARIANT_WINDOW;
+    // forward: the window-staged tile kernel wins for float32 rows (201 vs 259 us at the encoder shape: half
+    // the LDS-resident pixels per byte of texture traffic saved); for bf16 the direct-gather kernel is faster
+    // (164 vs 215 us: both are VALU-bound on the 32 unpack + 32 FMA per sample, and the tile kernel adds its
+    // bounding-box / staging phases), see DESIGN.md section 4
+    if (!backward && p.dtype == MSDA_F32 && window_supports(p, false)) return MSDA_VARIANT_WINDOW;
     if (!backward && quad_supports(p)) return MSDA_VARIANT_QUAD;
     return MSDA_VARIANT_GENERIC;
 }

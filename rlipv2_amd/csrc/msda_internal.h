@@ -34,6 +34,7 @@ bool quad_supports(const Problem &p);
 void launch_quad_forward(const Problem &p);
 void launch_quad_backward(const Problem &p);
 void launch_quad_backward_reduce(const Problem &p);   // grad_loc / grad_aw only (no grad_value)
+void launch_tile_forward(const Problem &p);           // window-staged forward (Lq == S)
 
 bool window_supports(const Problem &p, bool backward);
 void launch_window_forward(const Problem &p);

@@ -196,6 +196,220 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_forward_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, window-staged ("tile" kernel; encoder self-attention, where the queries are the pixels)
+// ------------------------------------------------------------------------------------------
+// The direct-gather kernel above is bound by the texture-address path: every wave load touches 16 distinct
+// 64-byte segments and the 16 samples x 4 corners of a (query, head) re-read the same neighbourhood -- 2.9 GB
+// of gathers per batch-4 encoder call against 45 MB of value.  Here a workgroup owns one head and a 16 x TH
+// tile of spatially adjacent queries, and for each sampled level
+//   1. the bounding box of every in-level corner its queries touch is found with LDS integer min/max,
+//   2. that window of the head's value rows is copied into LDS ONCE (LDS-DMA, lane-linear image:
+//      pixel-major, 64/128 bytes per pixel),
+//   3. the quads read their corners from LDS (ds_read_b128; 4x the bandwidth of the texture path).
+// A window that does not fit the buffer (far offsets, or a coarse-level tile sampling a fine level) makes the
+// whole workgroup take the direct-gather route for that level, so any input is handled.  Out-of-level
+// corners read a zeroed slot with weight 0 (exact zero padding even if the value tensor holds Inf/NaN).
+constexpr int kTileW = 16;
+constexpr int kWinBytes = 64 * 1024;            // LDS window buffer (incl. the zero slot)
+constexpr int kZeroSlot = 128;                  // bytes
+constexpr int kWinSlack = 1024;                 // the last DMA wave may overrun by up to 63 pieces
+
+__host__ __device__ inline int tile_count(int H, int W, int TH)
+{
+    return ((H + TH - 1) / TH) * ((W + kTileW - 1) / kTileW);
+}
+
+// `win` = the window buffer (its first kZeroSlot bytes are zero), `wbase` = byte offset of this level's stretch
+template <typename VT>
+__device__ __forceinline__ void tile_sample(const unsigned char *win, int wbase, float x, float y, float w, int H,
+                                            int W, int bx0, int by0, int ww, int sub, float (&acc)[8])
+{
+    constexpr int ROWB = kD * (int)sizeof(VT);
+    const float Hf = (float)H, Wf = (float)W;
+    float h = fmaf(y, Hf, -0.5f), v = fmaf(x, Wf, -0.5f);
+    h = fminf(fmaxf(h, -2.f), Hf + 1.f);
+    v = fminf(fmaxf(v, -2.f), Wf + 1.f);
+    const float hf = floorf(h), wf = floorf(v);
+    const float lh = h - hf, lw = v - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const int ih = (int)hf, iw = (int)wf;
+    const bool y0 = (unsigned)ih < (unsigned)H, y1 = (unsigned)(ih + 1) < (unsigned)H;
+    const bool x0 = (unsigned)iw < (unsigned)W, x1 = (unsigned)(iw + 1) < (unsigned)W;
+    const int base = wbase + (__mul24(ih - by0, ww) + (iw - bx0)) * ROWB;
+    const int lane = sub * 8 * (int)sizeof(VT);
+    const int down = ww * ROWB;
+    const int a00 = (y0 && x0) ? base + lane : lane;              // invalid corner -> the zero slot
+    const int a01 = (y0 && x1) ? base + ROWB + lane : lane;
+    const int a10 = (y1 && x0) ? base + down + lane : lane;
+    const int a11 = (y1 && x1) ? base + down + ROWB + lane : lane;
+    const typename Vec8<VT>::raw r00 = Vec8<VT>::load_raw(reinterpret_cast<const VT *>(win + a00));
+    const typename Vec8<VT>::raw r01 = Vec8<VT>::load_raw(reinterpret_cast<const VT *>(win + a01));
+    const typename Vec8<VT>::raw r10 = Vec8<VT>::load_raw(reinterpret_cast<const VT *>(win + a10));
+    const typename Vec8<VT>::raw r11 = Vec8<VT>::load_raw(reinterpret_cast<const VT *>(win + a11));
+    const float a = hh * w, b = lh * w;
+    Vec8<VT>::fma(a * hw, r00, acc);
+    Vec8<VT>::fma(a * lw, r01, acc);
+    Vec8<VT>::fma(b * hw, r10, acc);
+    Vec8<VT>::fma(b * lw, r11, acc);
+}
+
+template <typename VT, int TH, int WAVES>
+__global__ __launch_bounds__(kTileW *TH * 4, WAVES) void tile_forward_kernel(
+    const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const float *__restrict__ loc, const float *__restrict__ aw, int N, int S, int M, int Lq,
+    unsigned value_bytes, VT *__restrict__ out, int dbg)
+{
+    constexpr int THREADS = kTileW * TH * 4;
+    constexpr int ROWB = kD * (int)sizeof(VT);
+    constexpr int PPR = ROWB / 16;                                   // 16-byte pieces per pixel row
+    constexpr int MAXPX = (kWinBytes - kZeroSlot - kWinSlack) / ROWB;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char tile_lds[];
+    unsigned char *win = tile_lds;
+    int *box = reinterpret_cast<int *>(tile_lds + kWinBytes);        // [4 levels][x0, y0, -x1, -y1] (all via min)
+
+    int tiles_per_image = 0;
+#pragma unroll
+    for (int l = 0; l < kL; ++l) tiles_per_image += tile_count((int)shapes[2 * l], (int)shapes[2 * l + 1], TH);
+    const int total_items = N * tiles_per_image * M;
+    constexpr int kXcds = 8;
+    const int per_xcd = (total_items + kXcds - 1) / kXcds;
+    const int xcd = blockIdx.x % kXcds, lane_blk = blockIdx.x / kXcds, blks = gridDim.x / kXcds;
+    const int item_end = min(total_items, (xcd + 1) * per_xcd);
+    const int row_bytes = M * ROWB;
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)value, 0, value_bytes, 0x00020000);
+    if (threadIdx.x < kZeroSlot / 4) reinterpret_cast<int *>(win)[threadIdx.x] = 0;
+
+    for (int item = xcd * per_xcd + lane_blk; item < item_end; item += blks) {
+        // Everything below is derived from an opaque copy of the thread id: otherwise the compiler hoists
+        // the per-thread address arithmetic of all four levels out of the item loop and spills it.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int sub = tid & 3, ql = tid >> 2;
+        // own level (= quad lane): dimensions for the bounding box
+        const int Hs = (int)shapes[2 * sub], Ws = (int)shapes[2 * sub + 1];
+        const int m = item % M;
+        int t = (item / M) % tiles_per_image;
+        const int n = item / (M * tiles_per_image);
+        int lq = 0, Hq = 1, Wq = 1;
+#pragma unroll
+        for (int l = 0; l < kL; ++l) {
+            const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+            const int nt = tile_count(Hl, Wl, TH);
+            if (t >= 0 && t < nt) { lq = l; Hq = Hl; Wq = Wl; t -= 1 << 30; }
+            else if (t >= 0) t -= nt;
+        }
+        t += 1 << 30;
+        const int tiles_x = (Wq + kTileW - 1) / kTileW;
+        const int qy = (t / tiles_x) * TH + (ql >> 4), qx = (t % tiles_x) * kTileW + (ql & 15);
+        const bool live = qy < Hq && qx < Wq;
+        const int q = live ? (int)starts[lq] + qy * Wq + qx : (int)starts[lq];
+        const long qm = ((long)n * Lq + q) * M + m;
+        const unsigned img_byte = (unsigned)n * (unsigned)S * (unsigned)row_bytes + (unsigned)(m * ROWB);
+        const unsigned lane_byte = img_byte + (unsigned)(sub * 8 * (int)sizeof(VT));
+
+        const float4 *loc4 = reinterpret_cast<const float4 *>(loc) + qm * 8 + sub * 2;
+        float4 la = loc4[0], lb = loc4[1];
+        float4 wa = reinterpret_cast<const float4 *>(aw)[qm * 4 + sub];
+        if (!live) wa = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        // ---- bounding boxes: quad lane j covers level j's 4 points --------------------------------------
+        if (tid < 16) box[tid] = 0x3fffffff;
+        __syncthreads();
+        if (live && !(dbg & 64)) {
+            int mnx = 0x3fffffff, mny = 0x3fffffff, mxx = -0x3fffffff, mxy = -0x3fffffff;
+            const float px[4] = {la.x, la.z, lb.x, lb.z}, py[4] = {la.y, la.w, lb.y, lb.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float h = fmaf(py[k], (float)Hs, -0.5f), v = fmaf(px[k], (float)Ws, -0.5f);
+                h = fminf(fmaxf(h, -2.f), (float)Hs + 1.f);
+                v = fminf(fmaxf(v, -2.f), (float)Ws + 1.f);
+                const int ih = (int)floorf(h), iw = (int)floorf(v);
+                const int ylo = max(ih, 0), yhi = min(ih + 1, Hs - 1), xlo = max(iw, 0), xhi = min(iw + 1, Ws - 1);
+                if (ylo <= yhi && xlo <= xhi) {
+                    mnx = min(mnx, xlo); mxx = max(mxx, xhi); mny = min(mny, ylo); mxy = max(mxy, yhi);
+                }
+            }
+            if (mnx <= mxx) {
+                atomicMin(&box[sub * 4 + 0], mnx);
+                atomicMin(&box[sub * 4 + 1], mny);
+                atomicMin(&box[sub * 4 + 2], -mxx);
+                atomicMin(&box[sub * 4 + 3], -mxy);
+            }
+        }
+        __syncthreads();
+
+        // ---- windows of all four levels, staged back to back (one DMA latency, one barrier) ----------------
+        // Level l gets the next free stretch of the buffer if its window fits, otherwise it is gathered
+        // directly.  The boxes are read into scalars now: the next item re-initialises box[] early.
+        int bx0[kL], by0[kL], ww[kL], wbase[kL];
+        bool staged[kL], any[kL];
+        int used = 0;
+#pragma unroll
+        for (int l = 0; l < kL; ++l) {
+            bx0[l] = __builtin_amdgcn_readfirstlane(box[l * 4 + 0]);
+            by0[l] = __builtin_amdgcn_readfirstlane(box[l * 4 + 1]);
+            const int bx1 = -__builtin_amdgcn_readfirstlane(box[l * 4 + 2]);
+            const int by1 = -__builtin_amdgcn_readfirstlane(box[l * 4 + 3]);
+            ww[l] = bx1 - bx0[l] + 1;
+            any[l] = bx0[l] <= bx1 && by0[l] <= by1;
+            const int npx = any[l] ? ww[l] * (by1 - by0[l] + 1) : 0;
+            staged[l] = npx > 0 && used + npx <= MAXPX;
+            wbase[l] = kZeroSlot + used * ROWB;
+            if (staged[l] && !(dbg & 16)) {
+                // window image: pixel-major, piece-minor -> piece i lands at byte 16 i of the stretch: exactly
+                // the lane-linear layout an LDS-DMA instruction writes
+                const int W = (int)shapes[2 * l + 1], start = (int)starts[l];
+                const int pieces = npx * PPR;
+                const float inv_ww = 1.f / (float)ww[l];
+                const unsigned lvl_byte = img_byte + (unsigned)__mul24(start + by0[l] * W + bx0[l], row_bytes);
+                for (int i0 = (tid & ~63); i0 < pieces; i0 += THREADS) {
+                    const int i = min(i0 + (tid & 63), pieces - 1);          // surplus lanes repeat the last piece
+                    const int pxi = i / PPR, part = i % PPR;
+                    const int wy = (int)(((float)pxi + 0.5f) * inv_ww);
+                    const int wx = pxi - wy * ww[l];
+                    const unsigned off = lvl_byte + (unsigned)__mul24(wy * W + wx, row_bytes) + (unsigned)(part * 16);
+                    const unsigned char *src = reinterpret_cast<const unsigned char *>(value) + off;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(win + wbase[l] + i0 * 16),
+                                                     16, 0, 0);
+                }
+                // a stretch is rounded up to whole 64-piece DMA waves so that the next one cannot be overrun
+                used += (npx * PPR + 63) / 64 * 64 / PPR;
+            }
+        }
+        __syncthreads();
+
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < kL; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
+            // (scheduling fences: the compiler otherwise hoists all 16 corner reads of a level and spills)
+            if (dbg & 32) {
+            } else if (staged[l]) {
+                tile_sample<VT>(win, wbase[l], quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, bx0[l], by0[l], ww[l], sub, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                tile_sample<VT>(win, wbase[l], quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, bx0[l], by0[l], ww[l], sub, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                tile_sample<VT>(win, wbase[l], quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, bx0[l], by0[l], ww[l], sub, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                tile_sample<VT>(win, wbase[l], quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, bx0[l], by0[l], ww[l], sub, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (any[l]) {
+                // rare route (window too large for the buffer): direct gathers, one sample at a time
+                float4 ta = la, tb = lb, tw = wa;
+#pragma unroll 1
+                for (int k = 0; k < 4; ++k) {
+                    fwd_sample<VT>(vr, quad_bcast<0>(ta.x), quad_bcast<0>(ta.y), quad_bcast<0>(tw.x), H, W, start, row_bytes, lane_byte, acc);
+                    ta = make_float4(ta.z, ta.w, tb.x, tb.y); tb = make_float4(tb.z, tb.w, 0.f, 0.f);
+                    tw = make_float4(tw.y, tw.z, tw.w, 0.f);
+                }
+            }
+            quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
+        }
+        if (live) Vec8<VT>::store(out + qm * kD + sub * 8, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dot8(const float (&a)[8], const float (&b)[8])
@@ -334,6 +548,28 @@ void launch_quad_forward(const Problem &p)
         hipLaunchKernelGGL((quad_forward_kernel<bf16_t, 5, 2>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                            total_qm, p.S, p.M, p.Lq, value_bytes(p), (bf16_t *)p.out, dbg);
+}
+
+// window-staged forward (encoder self-attention shapes); see tile_forward_kernel
+void launch_tile_forward(const Problem &p)
+{
+    static const int th = [] { const char *e = getenv("RLIPV2_MSDA_TILE_H"); return e ? atoi(e) : 8; }();
+    const char *de = getenv("RLIPV2_MSDA_DEBUG");       // ablation switches, profiling only
+    const int dbg = de ? atoi(de) : 0;
+    const char *g = getenv("RLIPV2_MSDA_GRID");
+    const int lds = kWinBytes + 64;
+#define MSDA_LAUNCH_TILE(VT, TH, WAVES, BLOCKS_PER_CU)                                                              \
+    hipLaunchKernelGGL((tile_forward_kernel<VT, TH, WAVES>), dim3(g ? atoi(g) : 256 * BLOCKS_PER_CU),               \
+                       dim3(kTileW * TH * 4), lds, p.stream, (const VT *)p.value, p.shapes, p.starts,              \
+                       (const float *)p.loc, (const float *)p.aw, p.N, p.S, p.M, p.Lq, value_bytes(p), (VT *)p.out, dbg)
+    if (p.dtype == MSDA_F32) {
+        if (th == 8) MSDA_LAUNCH_TILE(float, 8, 4, 2); else MSDA_LAUNCH_TILE(float, 16, 4, 1);
+    } else {
+        if (th == 8) MSDA_LAUNCH_TILE(bf16_t, 8, 4, 2);
+        else if (th == 12) MSDA_LAUNCH_TILE(bf16_t, 12, 5, 1);
+        else MSDA_LAUNCH_TILE(bf16_t, 16, 4, 1);
+    }
+#undef MSDA_LAUNCH_TILE
 }
 
 void launch_quad_backward(const Problem &p)

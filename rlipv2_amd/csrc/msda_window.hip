@@ -277,7 +277,8 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
 // + K2 (this scatter).  Levels larger than 2^24 pixels do not fit the direct path's record key.
 bool window_supports(const Problem &p, bool backward)
 {
-    if (!backward) return false;                       // forward: msda_quad.hip
+    // forward: the window-staged tile kernel of msda_quad.hip, for encoder self-attention (queries = pixels)
+    if (!backward && p.Lq != p.S) return false;
     if (p.dtype != MSDA_F32 && p.dtype != MSDA_BF16) return false;
     if (p.D != kD || p.L != kL || p.P != kP) return false;
     if (p.S < 1 || p.S >= (1 << 24)) return false;
@@ -286,7 +287,7 @@ bool window_supports(const Problem &p, bool backward)
     return quad_supports(p);
 }
 
-void launch_window_forward(const Problem &) {}
+void launch_window_forward(const Problem &p) { launch_tile_forward(p); }
 
 void launch_window_backward(const Problem &p)
 {

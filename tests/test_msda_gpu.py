@@ -64,7 +64,7 @@ def close32(got, ref, rtol=1e-4, atol_rel=1e-5):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol_rel * max(1.0, float(np.abs(ref).max())))
 
 
-WINDOW_FWD = False   # msda_window.hip implements: backward only (this round)
+WINDOW_FWD = True    # window-staged tile forward (msda_quad.hip), valid when Lq == S
 WINDOW_BWD = True
 
 
@@ -74,7 +74,7 @@ def variants_for(D, L, P, tdtype, S=0, Lq=-1):
     if D == 32 and L == 4 and P == 4 and tdtype != torch.float64:
         v.append(("quad", "quad"))
         # "window" backward = reduce kernel + sorted scatter kernel; valid for any Lq
-        v.append(("window" if WINDOW_FWD else "quad", "window" if WINDOW_BWD else "quad"))
+        v.append(("window" if (WINDOW_FWD and S == Lq) else "quad", "window" if WINDOW_BWD else "quad"))
     v.append(("auto", "auto"))
     return v
 

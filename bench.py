@@ -214,7 +214,8 @@ def run_train_step_bench(args, world, rank, local_rank, device):
                 train.freeze_parameters_without_gradient(step_module, criterion, batch)
             else:
                 synchronizer = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
-            step_module = train.graph_step_module(step_module, model, batch, synchronizer)
+            step_module = train.graph_step_module(step_module, model, batch, synchronizer,
+                                                  criterion=criterion if args.graph_criterion else None)
             graphed = True
         except Exception as e:                                  # noqa: BLE001 -- fall back to eager, say so
             import traceback
@@ -326,6 +327,8 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-graph-criterion", dest="graph_criterion", action="store_false",
+                    help="keep the criterion's device work eager (outside the HIP graphs)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (BASELINE config 2: 4)")

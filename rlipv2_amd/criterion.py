@@ -50,9 +50,13 @@ def generalized_box_iou(a, b):
 
 def paired_giou(a, b):
     """GIoU of xyxy boxes a[i] with b[i] ([N,4] x [N,4] -> [N]): the diagonal of generalized_box_iou"""
-    inter = ((torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0)).prod(-1)
+    # (explicit products: prod()'s backward inspects the data for zeros on the host -- a sync, and not
+    #  graph-capturable)
+    wh = (torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]
     union = _area(a) + _area(b) - inter
-    hull = ((torch.max(a[:, 2:], b[:, 2:]) - torch.min(a[:, :2], b[:, :2])).clamp(min=0)).prod(-1)
+    wh = (torch.max(a[:, 2:], b[:, 2:]) - torch.min(a[:, :2], b[:, :2])).clamp(min=0)
+    hull = wh[:, 0] * wh[:, 1]
     return inter / union - (hull - union) / hull
 
 
@@ -270,14 +274,22 @@ class SetCriterionHOI(nn.Module):
         so the cost matrix, the label / verb / box losses and the cardinality error are each computed once
         on a K-times larger tensor instead of K times (the per-layer loop is ~330 launch-bound kernels
         forward and as many backward; this is ~110), with ONE device->host copy (costs) and ONE
-        host->device copy (matched indices) per step.  Every entry equals `forward_per_layer`."""
+        host->device copy (matched indices) per step.  Every entry equals `forward_per_layer`.
+
+        The three stages are separate methods so that a HIP-graphed train step can put `prepare` at the end
+        of its forward graph and `losses` at the head of its backward graph, with only the host-side
+        assignment in between (train.GraphedStep)."""
+        state = self.prepare(outputs, targets)
+        index = self.assign(state).to(state['dev'], non_blocking=True)
+        return self.losses(state, index, self._num_interactions(state['sizes'], state['dev']))
+
+    def prepare(self, outputs, targets):
+        """Device-side part before the assignment: stacked float32 predictions, concatenated targets, the
+        cost matrix of every (layer, image, query) row against every target, the GIoU costs."""
         main = {k: v for k, v in outputs.items() if k != 'aux_outputs'}
         layers = [main] + list(outputs.get('aux_outputs', []))
         K = len(layers)
         bs, nq = main['pred_obj_logits'].shape[:2]
-        dev = main['pred_obj_logits'].device
-        sizes = [len(t['obj_labels']) for t in targets]
-        T = sum(sizes)
 
         def rows(key):                                         # [K*bs, nq, .], float32 (bf16 predictions upcast here)
             return (torch.cat([o[key] for o in layers], 0) if K > 1 else main[key]).float()
@@ -285,42 +297,82 @@ class SetCriterionHOI(nn.Module):
         if self.subject_class:
             pred['pred_sub_logits'] = rows('pred_sub_logits')
         C, c_giou = self.matcher.costs(pred, targets)           # [K*bs*nq, T]
-        C_host = C.float().cpu().view(K, bs, nq, T)
-        # Hungarian assignment on the host; rows of the stacked predictions / columns of the concatenated targets
-        flat_q, tgt_i, t0 = [], [], 0
+        st = {'K': K, 'bs': bs, 'nq': nq, 'dev': main['pred_obj_logits'].device,
+              'sizes': [len(t['obj_labels']) for t in targets], 'pred': pred, 'C': C, 'c_giou': c_giou,
+              't_obj': torch.cat([t['obj_labels'] for t in targets]),
+              't_verb': torch.cat([t['verb_labels'] for t in targets]),
+              't_sub_box': torch.cat([t['sub_boxes'] for t in targets]),
+              't_obj_box': torch.cat([t['obj_boxes'] for t in targets])}
+        if self.subject_class:
+            st['t_sub'] = torch.cat([t['sub_labels'] for t in targets])
+        if self.giou_verb_label and self.pseudo_verb:
+            st['sims'] = [o['target_verb_sim'] for o in layers]
+        return st
+
+    @staticmethod
+    def matched_pairs(sizes, nq, K):
+        """number of (query, target) pairs the assignment yields: min(nq, targets) per image and layer"""
+        return K * sum(min(nq, n) for n in sizes)
+
+    def assign(self, state):
+        """Host side: the cost matrix comes over in ONE copy, scipy solves the K*bs assignment problems;
+        returns int64 [2, K*n]: rows of the stacked predictions / columns of the concatenated targets."""
+        K, bs, nq, sizes = state['K'], state['bs'], state['nq'], state['sizes']
+        C_host = state['C'].float().cpu().view(K, bs, nq, sum(sizes))
         starts = [0]
         for n in sizes:
             starts.append(starts[-1] + n)
+        flat_q, tgt_i = [], []
         for k in range(K):
             for i in range(bs):
                 r, c = linear_sum_assignment(C_host[k, i, :, starts[i]:starts[i + 1]])
                 flat_q.append(torch.as_tensor(r, dtype=torch.int64) + (k * bs + i) * nq)
                 tgt_i.append(torch.as_tensor(c, dtype=torch.int64) + starts[i])
-        index = torch.stack([torch.cat(flat_q), torch.cat(tgt_i)]).to(dev, non_blocking=True)
+        return torch.stack([torch.cat(flat_q), torch.cat(tgt_i)])
+
+    def _constants(self, K, sizes, dev, dtype, kinds):
+        """small host-built tensors, cached (creating them would be a host->device copy per step, which is
+        also illegal during HIP-graph capture)"""
+        key = (K, tuple(sizes), str(dev), dtype, tuple(kinds))
+        cache = self.__dict__.setdefault('_const_cache', {})
+        if key not in cache:
+            w = torch.tensor([[self.weight_dict.get(k + ('' if li == 0 else f'_{li - 1}'), 0.0) for li in range(K)]
+                              for k in kinds], device=dev, dtype=dtype)
+            cache[key] = (torch.as_tensor(sizes, device=dev, dtype=torch.float), w)
+        return cache[key]
+
+    def _ce_weight(self, n_cls, dev, dtype):
+        """class weights of the label cross-entropy (eos_coef on the "no object" class), cached: writing a
+        Python scalar into a device tensor is a host->device copy"""
+        key = ('ce', n_cls, str(dev), dtype, self.eos_coef)
+        cache = self.__dict__.setdefault('_const_cache', {})
+        if key not in cache:
+            w = torch.ones(n_cls, dtype=dtype)
+            w[-1] = self.eos_coef
+            cache[key] = w.to(dev)
+        return cache[key]
+
+    def losses(self, state, index, num_interactions):
+        """Device-side part after the assignment (no host interaction: graph-capturable)."""
+        K, bs, nq, sizes, dev = state['K'], state['bs'], state['nq'], state['sizes'], state['dev']
+        pred, c_giou = state['pred'], state['c_giou']
         flat_q, tgt_i = index[0], index[1]
         n = flat_q.shape[0] // K                                # matched pairs per layer (the same for every layer)
-        num_interactions = self._num_interactions(sizes, dev)
-
-        t_obj = torch.cat([t['obj_labels'] for t in targets])
-        t_verb = torch.cat([t['verb_labels'] for t in targets])
-        t_sub_box = torch.cat([t['sub_boxes'] for t in targets])
-        t_obj_box = torch.cat([t['obj_boxes'] for t in targets])
         out = {}
 
         # --- object / subject labels: weighted cross-entropy per layer (hoi.py:3696) ---
         def label_ce(logits, t_lab):
             n_cls = logits.shape[-1]
             logits = logits.reshape(K * bs * nq, n_cls)
-            weight = torch.ones(n_cls, device=dev, dtype=logits.dtype)
-            weight[-1] = self.eos_coef
+            weight = self._ce_weight(n_cls, dev, logits.dtype)
             matched = t_lab[tgt_i]
             tgt = torch.full((K * bs * nq,), n_cls - 1, dtype=torch.int64, device=dev)
             tgt[flat_q] = matched
             nll = F.cross_entropy(logits, tgt, weight, reduction='none').view(K, -1).sum(1)
             return nll / weight[tgt].view(K, -1).sum(1), logits, matched
-        ce, o_logits, m_o = label_ce(pred['pred_obj_logits'], t_obj)
+        ce, o_logits, m_o = label_ce(pred['pred_obj_logits'], state['t_obj'])
         if self.subject_class:
-            ce_s, s_logits, m_s = label_ce(pred['pred_sub_logits'], torch.cat([t['sub_labels'] for t in targets]))
+            ce_s, s_logits, m_s = label_ce(pred['pred_sub_logits'], state['t_sub'])
             ce = ce + ce_s
         out['loss_obj_ce'] = ce
 
@@ -338,13 +390,13 @@ class SetCriterionHOI(nn.Module):
             v_logits = v_logits[:, :, :-1]
         nv = v_logits.shape[-1]
         v_logits = v_logits.reshape(K * bs * nq, nv)
-        lab = t_verb[tgt_i].to(v_logits.dtype)
+        lab = state['t_verb'][tgt_i].to(v_logits.dtype)
         if self.giou_verb_label:
             quality = (1 - c_giou[flat_q, tgt_i]) / 2           # matcher cost is -GIoU; GIoU -> [0, 1]
             if self.pseudo_verb:
-                sims = [o['target_verb_sim'] for o in layers]
+                sims = state['sims']
                 if all(s_ is sims[0] for s_ in sims):
-                    lab = lab + sims[0][tgt_i].float()
+                    lab = lab + sims[0].index_select(0, tgt_i).float()
                 else:
                     lab = lab + torch.stack(sims)[torch.arange(K, device=dev).repeat_interleave(n), tgt_i].float()
             lab = lab * quality.unsqueeze(-1)
@@ -363,13 +415,15 @@ class SetCriterionHOI(nn.Module):
             out['loss_verb_ce'] = torch.where(num_pos == 0, -nl, -(pl + nl) / num_pos.clamp(min=1))
 
         # --- boxes: L1 + GIoU of matched pairs (hoi.py:4162) ---
-        src_s = pred['pred_sub_boxes'].reshape(-1, 4)[flat_q]
-        src_o = pred['pred_obj_boxes'].reshape(-1, 4)[flat_q]
+        # (index_select: its backward is index_add_, which is graph-capturable; advanced indexing's backward
+        #  is a sort-based index_put_ that is not)
+        src_s = pred['pred_sub_boxes'].reshape(-1, 4).index_select(0, flat_q)
+        src_o = pred['pred_obj_boxes'].reshape(-1, 4).index_select(0, flat_q)
         if n == 0:
             z_s, z_o = src_s.sum().expand(K), src_o.sum().expand(K)
             out.update(loss_sub_bbox=z_s, loss_obj_bbox=z_o, loss_sub_giou=z_s, loss_obj_giou=z_o)
         else:
-            tgt_s, tgt_o = t_sub_box[tgt_i], t_obj_box[tgt_i]
+            tgt_s, tgt_o = state['t_sub_box'][tgt_i], state['t_obj_box'][tgt_i]
             exist = (tgt_o != 0).any(dim=1)
             n_exist = exist.view(K, -1).sum(1) + 1e-4
             out['loss_sub_bbox'] = (src_s - tgt_s).abs().view(K, -1).sum(1) / num_interactions
@@ -379,8 +433,10 @@ class SetCriterionHOI(nn.Module):
             out['loss_sub_giou'] = g_s.view(K, -1).sum(1) / num_interactions
             out['loss_obj_giou'] = (g_o * exist).view(K, -1).sum(1) / n_exist
 
+        kinds = [k for k in out if k in self.weight_dict]
+        lengths, w = self._constants(K, sizes, dev, out[kinds[0]].dtype, kinds)
+
         # --- cardinality error (hoi.py:3909), logging only ---
-        lengths = torch.as_tensor(sizes, device=dev, dtype=torch.float)
         card = (o_logits.argmax(-1) != o_logits.shape[-1] - 1).view(K, bs, nq).sum(2).float()
         out['obj_cardinality_error'] = (card - lengths).abs().mean(1)
 
@@ -392,9 +448,6 @@ class SetCriterionHOI(nn.Module):
             if li == 0:
                 losses.update(log)
         # the weighted total as one dot product instead of a chain of ~3*K tiny multiply-adds
-        kinds = [k for k in out if k in self.weight_dict]
-        w = torch.tensor([[self.weight_dict.get(k + ('' if li == 0 else f'_{li - 1}'), 0.0) for li in range(K)]
-                          for k in kinds], device=dev, dtype=out[kinds[0]].dtype)
         losses.total = (torch.stack([out[k] for k in kinds]) * w).sum()
         return losses
 

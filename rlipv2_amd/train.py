@@ -120,46 +120,91 @@ class GraphedStep:
     runs on them eagerly; `loss.backward()` fills their `.grad`; `step.backward()` replays the model's
     backward graph from those."""
 
-    def __init__(self, step_module, model, batch, warmup=3, synchronizer=None):
+    def __init__(self, step_module, model, batch, warmup=3, synchronizer=None, criterion=None):
         samples, text, targets = batch
         self.synchronizer = synchronizer
+        self.criterion = criterion
         self.wrapper = GraphedTrainForward(step_module, text["obj_pred_names_sums"],
                                            model.transformer.ho_decoder.num_layers, model.pseudo_verb)
         self.wrapper.no_padding = bool(getattr(samples, "no_padding", False))      # baked into the capture
         self.params = [p for p in step_module.parameters() if p.requires_grad]
         verbs = torch.cat([t["verb_labels"] for t in targets])
         self.static_in = [samples.tensors, samples.mask, text["input_ids"], text["attention_mask"], verbs]
+        # With a criterion the graphs hold the whole step except the host-side assignment:
+        #   forward graph  = model phases + stacked predictions + matcher cost matrices (criterion.prepare)
+        #   host           = ONE device->host copy, scipy assignment, ONE host->device copy (criterion.assign)
+        #   backward graph = losses (criterion.losses) + their backward + the model's backward (+ packing)
+        # so the ~110 + ~150 launch-bound eager kernels of the criterion and its backward become graph nodes.
+        # The target tensors are static inputs; the capture is specific to the number of targets per image.
+        self.static_targets = [{k: v.clone() for k, v in t.items() if torch.is_tensor(v)} for t in targets]
+        self.sizes = [len(t["obj_labels"]) for t in targets]
+
+        def forward_part():
+            outs = self.wrapper(*self.static_in)
+            state = None
+            if criterion is not None:
+                state = criterion.prepare(self.wrapper.unflatten(outs), self.static_targets)
+            return outs, state
+
+        def loss_and_grads(outs, state, index, num):
+            if criterion is None:
+                need = [o for o in outs if o.requires_grad]
+                return None, None, torch.autograd.grad(need, self.params, [torch.ones_like(o) for o in need],
+                                                       allow_unused=True)
+            ld = criterion.losses(state, index, num)
+            total = criterion.weighted_sum(ld)
+            return ld, total, torch.autograd.grad(total, self.params, allow_unused=True)
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                outs = self.wrapper(*self.static_in)
-                need = [o for o in outs if o.requires_grad]
-                torch.autograd.grad(need, self.params, [torch.ones_like(o) for o in need], allow_unused=True)
-            del outs, need
+                outs, state = forward_part()
+                if criterion is not None:
+                    index = criterion.assign(state).to(samples.tensors.device)
+                    num = criterion._num_interactions(self.sizes, samples.tensors.device).reshape(1)
+                    loss_and_grads(outs, state, index, num[0])
+                else:
+                    loss_and_grads(outs, None, None, None)
+            del outs, state
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.fwd_graph, pool=pool):
-            self.static_out = self.wrapper(*self.static_in)
-        self.diff = [i for i, o in enumerate(self.static_out) if o.requires_grad]
-        self.static_gout = [torch.zeros_like(self.static_out[i]) for i in self.diff]
-        with torch.cuda.graph(self.bwd_graph, pool=pool):
-            grads = torch.autograd.grad([self.static_out[i] for i in self.diff], self.params, self.static_gout,
-                                        allow_unused=True)
-            if synchronizer is not None:
-                grads = synchronizer.pack(grads)          # the packing copy is part of the backward graph
-        self.static_grads = grads
+            self.static_out, self.state = forward_part()
         self.leaves = None
+        if criterion is None:
+            self.diff = [i for i, o in enumerate(self.static_out) if o.requires_grad]
+            self.static_gout = [torch.zeros_like(self.static_out[i]) for i in self.diff]
+            with torch.cuda.graph(self.bwd_graph, pool=pool):
+                grads = torch.autograd.grad([self.static_out[i] for i in self.diff], self.params, self.static_gout,
+                                            allow_unused=True)
+                if synchronizer is not None:
+                    grads = synchronizer.pack(grads)          # the packing copy is part of the backward graph
+            self.static_grads = grads
+            return
+        self.static_index = index.clone()                      # [2, K * matched pairs]: shape fixed by `sizes`
+        self.static_num = num.clone()
+        self.pinned_index = torch.empty(index.shape, dtype=index.dtype, pin_memory=True)
+        with torch.cuda.graph(self.bwd_graph, pool=pool):
+            self.loss_dict, self.total, grads = loss_and_grads(self.static_out, self.state, self.static_index,
+                                                                self.static_num[0])
+            if synchronizer is not None:
+                grads = synchronizer.pack(grads)
+        self.static_grads = grads
 
-    def __call__(self, samples, text, targets):
+    def _load_inputs(self, samples, text, targets):
         if bool(getattr(samples, "no_padding", False)) != self.wrapper.no_padding:
             raise RuntimeError("GraphedStep was captured for a batch with a different padding hint; capture again")
         verbs = torch.cat([t["verb_labels"] for t in targets])
         for dst, src in zip(self.static_in, (samples.tensors, samples.mask, text["input_ids"], text["attention_mask"], verbs)):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
+
+    def __call__(self, samples, text, targets):
+        """model phases only (criterion=None protocol): detached output leaves for an eager criterion"""
+        self._load_inputs(samples, text, targets)
         self.fwd_graph.replay()
         self.leaves = [o.detach().requires_grad_(i in self.diff) for i, o in enumerate(self.static_out)]
         return self.wrapper.unflatten(self.leaves)
@@ -173,18 +218,40 @@ class GraphedStep:
             else:
                 buf.copy_(g)
         self.bwd_graph.replay()
+        self._deliver()
+        self.leaves = None
+
+    def _deliver(self):
         if self.synchronizer is not None:
             self.synchronizer.all_reduce()
         for p, g in zip(self.params, self.static_grads):
             p.grad = g
-        self.leaves = None
+
+    def run(self, samples, text, targets):
+        """Whole step up to the optimiser (criterion captured): forward graph, host assignment, backward
+        graph; leaves the gradients in `p.grad` and returns (loss dict, weighted total) as static tensors."""
+        if [len(t["obj_labels"]) for t in targets] != self.sizes:
+            raise RuntimeError("GraphedStep was captured for different numbers of targets per image; capture again")
+        self._load_inputs(samples, text, targets)
+        for dst, src in zip(self.static_targets, targets):
+            for k, v in dst.items():
+                if v.data_ptr() != src[k].data_ptr():
+                    v.copy_(src[k])
+        self.fwd_graph.replay()
+        self.pinned_index.copy_(self.criterion.assign(self.state))
+        self.static_index.copy_(self.pinned_index, non_blocking=True)
+        self.static_num.copy_(self.criterion._num_interactions(self.sizes, self.static_num.device).reshape(1))
+        self.bwd_graph.replay()
+        self._deliver()
+        return self.loss_dict, self.total
 
 
-def graph_step_module(step_module, model, batch, synchronizer=None):
+def graph_step_module(step_module, model, batch, synchronizer=None, criterion=None):
     """Capture `step_module` (both model phases, forward and backward) for the shapes of `batch`; returns a
     GraphedStep.  Raises if capture is not possible.  `synchronizer`: a GradientSynchronizer for data-parallel
-    runs (the gradient all-reduce then follows the backward replay)."""
-    return GraphedStep(step_module, model, batch, synchronizer=synchronizer)
+    runs (the gradient all-reduce then follows the backward replay).  `criterion`: capture the criterion's
+    device work into the two graphs as well (`GraphedStep.run`)."""
+    return GraphedStep(step_module, model, batch, synchronizer=synchronizer, criterion=criterion)
 
 
 def broadcast_parameters(module, src=0):
@@ -394,14 +461,18 @@ def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_
     matcher's single device->host copy of the cost matrices.  `autocast_dtype=None` runs the model
     in whatever dtype its parameters have (float32, or bfloat16 with MasterWeightAdamW)."""
     samples, text, targets = batch
-    with torch.autocast(samples.tensors.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
-        outputs = step_module(samples, text, targets)
-    loss_dict = criterion(outputs, targets)
-    loss = criterion.weighted_sum(loss_dict)
-    optimizer.zero_grad(set_to_none=True)
-    loss.backward()
-    if isinstance(step_module, GraphedStep):
-        step_module.backward()
+    if isinstance(step_module, GraphedStep) and step_module.criterion is not None:
+        optimizer.zero_grad(set_to_none=True)
+        _, loss = step_module.run(samples, text, targets)
+    else:
+        with torch.autocast(samples.tensors.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+            outputs = step_module(samples, text, targets)
+        loss_dict = criterion(outputs, targets)
+        loss = criterion.weighted_sum(loss_dict)
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if isinstance(step_module, GraphedStep):
+            step_module.backward()
     if isinstance(optimizer, (MasterWeightAdamW, FusedMasterAdamW)):
         optimizer.step(max_norm)
     else:

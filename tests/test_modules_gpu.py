@@ -221,3 +221,21 @@ def test_graphed_step_delivers_the_same_gradients_as_eager_autograd():
         # separates two eager runs) may separate the graphed from the eager gradients
         d = distance(grads_g, grads_e)
         assert d <= 2.0 * noise + 1e-2, (d, noise)
+
+    # the criterion captured as well: forward graph ends with the cost matrices, backward graph starts with the
+    # losses; same loss dict, same gradients
+    ref_ld = criterion(step(*batch), batch[2])
+    full = train.graph_step_module(step, model, batch, criterion=criterion)
+    for _ in range(2):
+        for _, p in params:
+            p.grad = None
+        ld, total = full.run(*batch)
+        torch.testing.assert_close(total.float(), loss_e, rtol=2e-2, atol=1e-3)
+        assert set(ld.keys()) == set(ref_ld.keys())
+        for k in ref_ld:
+            if k.startswith("loss_"):           # (class / cardinality errors are argmax counts: bf16 noise flips them)
+                torch.testing.assert_close(ld[k].float(), ref_ld[k].float(), rtol=5e-2, atol=2e-2,
+                                           msg=lambda m: f"{k}: {m}")
+        grads_f = {n: p.grad.detach().float().clone() for n, p in params}
+        d = distance(grads_f, grads_e)
+        assert d <= 2.0 * noise + 1e-2, (d, noise)

@@ -269,13 +269,12 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
 // n/64 workgroups (a thread-per-element loop over 128 chunks was latency-bound at ~30 us).
 // BIAS: n = M and the tail term is dy[t][e..e+3]; otherwise e = m*K + k and it is dy[t][m] * x[t][k..k+3].
 template <bool F32, bool BIAS>
-__global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__ partial, int chunks, size_t n,
-                                                       const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
-                                                       int tail0, int T, int M, int K, void *__restrict__ out)
+__device__ __forceinline__ void reduce_body(const float *__restrict__ partial, int chunks, size_t n, int block,
+                                            const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x, int tail0,
+                                            int T, int M, int K, void *__restrict__ out, float4 (*red)[16])
 {
-    __shared__ float4 red[16][16];
     const int q = threadIdx.x & 15, cg = threadIdx.x >> 4;
-    const size_t e = ((size_t)blockIdx.x * 16 + q) * 4;
+    const size_t e = ((size_t)block * 16 + q) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < n) {
 #pragma unroll 4
@@ -318,6 +317,22 @@ __global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__
         o.y = rne(s.z) | (rne(s.w) << 16);
         *reinterpret_cast<uint2 *>(static_cast<uint16_t *>(out) + e) = o;
     }
+}
+
+// one launch for both results: workgroups [0, dw_blocks) reduce the weight-gradient partials, the rest the
+// bias-gradient partials (db may be absent: then the grid is dw_blocks)
+template <bool F32>
+__global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__ partial,
+                                                       const float *__restrict__ bias_partial, int chunks, int dw_blocks,
+                                                       const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
+                                                       int tail0, int T, int M, int K, void *__restrict__ dw,
+                                                       void *__restrict__ db)
+{
+    __shared__ float4 red[16][16];
+    if ((int)blockIdx.x < dw_blocks)
+        reduce_body<F32, false>(partial, chunks, (size_t)M * K, blockIdx.x, dy, x, tail0, T, M, K, dw, red);
+    else
+        reduce_body<F32, true>(bias_partial, chunks, (size_t)M, blockIdx.x - dw_blocks, dy, x, tail0, T, M, K, db, red);
 }
 
 struct Plan { int chunks, steps_per_chunk, steps_total, tiles; size_t partial_floats, bias_floats; };
@@ -388,13 +403,12 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
     }
     const size_t n = (size_t)M * K;
     const int tail0 = pl.steps_total * BK;
-    const dim3 gw((n / 4 + 15) / 16), gb(((size_t)M / 4 + 15) / 16), blk(256);
-    if (out_f32) {
-        hipLaunchKernelGGL((reduce_partials<true, false>), gw, blk, 0, stream, partial, pl.chunks, n, dy16, x16, tail0, T, M, K, dw);
-        if (db) hipLaunchKernelGGL((reduce_partials<true, true>), gb, blk, 0, stream, bias_partial, pl.chunks, (size_t)M, dy16, x16, tail0, T, M, K, db);
-    } else {
-        hipLaunchKernelGGL((reduce_partials<false, false>), gw, blk, 0, stream, partial, pl.chunks, n, dy16, x16, tail0, T, M, K, dw);
-        if (db) hipLaunchKernelGGL((reduce_partials<false, true>), gb, blk, 0, stream, bias_partial, pl.chunks, (size_t)M, dy16, x16, tail0, T, M, K, db);
-    }
+    const int gw = (int)((n / 4 + 15) / 16), gb = db ? (int)(((size_t)M / 4 + 15) / 16) : 0;
+    if (out_f32)
+        hipLaunchKernelGGL(reduce_partials<true>, dim3(gw + gb), dim3(256), 0, stream, partial, bias_partial, pl.chunks, gw,
+                           dy16, x16, tail0, T, M, K, dw, db);
+    else
+        hipLaunchKernelGGL(reduce_partials<false>, dim3(gw + gb), dim3(256), 0, stream, partial, bias_partial, pl.chunks, gw,
+                           dy16, x16, tail0, T, M, K, dw, db);
     return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
 }

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from . import _lib
 
 # rows below this go to the library (its weight-gradient GEMM is fine when the reduction is short)
-MIN_ROWS = 4096
+MIN_ROWS = 256
 enabled = True
 
 _workspaces = {}

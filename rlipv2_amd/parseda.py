@@ -215,10 +215,11 @@ def _add_reference(delta, ref):
     """box head output + inverse_sigmoid(reference): all 4 coordinates for a reference box, only (x, y)
     for a 2-d reference point (reference hoi.py:2122-2138 / :3040-3056)."""
     inv = inverse_sigmoid(ref)
+    delta = delta.to(inv.dtype)              # no mixed-dtype elementwise ops (see decoder.py)
     if ref.shape[-1] == 4:
         return delta + inv
     assert ref.shape[-1] == 2
-    return torch.cat([delta[..., :2] + inv, delta[..., 2:].to(inv.dtype)], dim=-1)
+    return torch.cat([delta[..., :2] + inv, delta[..., 2:]], dim=-1)
 
 
 class RLIP_ParSeDA(nn.Module):

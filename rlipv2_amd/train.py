@@ -272,6 +272,7 @@ class GradientSynchronizer:
     def __init__(self, params, group=None):
         self.params = list(params)
         self.group = group
+        self._avg = None
         total = sum(p.numel() for p in self.params)
         p0 = self.params[0]
         self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
@@ -293,9 +294,26 @@ class GradientSynchronizer:
         torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         return self.views
 
+    def _probe_avg(self):
+        """ReduceOp.AVG is what RCCL/NCCL offer for this; gloo (CPU tests) does not -- find out once, with a
+        collective every rank takes part in, and fall back to SUM followed by a scale."""
+        import torch.distributed as dist
+        try:
+            dist.all_reduce(torch.zeros(1, dtype=self.flat.dtype, device=self.flat.device), op=dist.ReduceOp.AVG,
+                            group=self.group)
+            return True
+        except (RuntimeError, ValueError):
+            return False
+
     def all_reduce(self):
         import torch.distributed as dist
-        dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+        if self._avg is None:
+            self._avg = self._probe_avg()
+        if self._avg:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.flat, group=self.group)
+            self.flat.div_(dist.get_world_size(self.group))
 
     def __call__(self, grads):
         """grads: one tensor (or None) per parameter -> averaged gradients as views of the flat buffer"""

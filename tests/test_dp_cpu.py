@@ -121,16 +121,7 @@ def _sync_worker(rank, world, port, out):
         grads = [torch.randn(p.shape, generator=g) for p in params]
         grads[0] = grads[0].contiguous(memory_format=torch.channels_last)
         grads[3] = None                                    # a parameter without gradient on this step
-        try:
-            avg = sync(grads)
-        except RuntimeError:                               # gloo has no ReduceOp.AVG: emulate it for this CPU test
-            import torch.distributed as dist2
-            have = [(v, gr) for v, gr in zip(sync.views, grads) if gr is not None]
-            torch._foreach_zero_([v for v, gr in zip(sync.views, grads) if gr is None])
-            torch._foreach_copy_([v for v, _ in have], [gr for _, gr in have])
-            dist2.all_reduce(sync.flat)
-            sync.flat.div_(world)
-            avg = sync.views
+        avg = sync(grads)                                  # (gloo has no ReduceOp.AVG: exercises the SUM + scale route)
         out[rank] = ([p.detach().clone() for p in params], [a.clone() for a in avg],
                      [None if gr is None else gr.clone() for gr in grads])
     finally:

@@ -88,7 +88,8 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        if pointwise_as_gemm and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last):
+        if (pointwise_as_gemm and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_autocast_enabled()
+                and x.is_contiguous(memory_format=torch.channels_last)):
             out = pointwise_conv_bn(x, self.conv1, self.bn1, relu=True)
             out = F.relu(self.bn2(self.conv2(out)))
             if out.is_contiguous(memory_format=torch.channels_last):

@@ -137,6 +137,10 @@ class SmallLinearFunction(torch.autograd.Function):
 def token_linear(x, weight, bias=None, relu=False):
     """relu?(F.linear(x, weight, bias)) with the MFMA weight-gradient kernel behind it when the shape
     qualifies; `relu=True` puts the activation into the GEMM epilogue."""
+    if torch.is_autocast_enabled():
+        # autocast runs (float32 parameters, per-op casts): the custom backward paths assume one dtype throughout
+        y = F.linear(x, weight, bias)
+        return F.relu(y) if relu else y
     if torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
         if supported(x, weight):
             return TokenLinearFunction.apply(x, weight, bias, relu)

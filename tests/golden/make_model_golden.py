@@ -419,6 +419,41 @@ def gold_parsed():
     save("parsed", **rec)
 
 
+def postprocess_case():
+    """seeded model outputs for 3 images (43 object classes incl. "no object", 21 verbs) + image sizes"""
+    bs, nq, n_obj, n_verb = 3, 7, 43, 21
+    out = {"pred_obj_logits": rng_tensor(71, bs, nq, n_obj, scale=2.0),
+           "pred_sub_logits": rng_tensor(72, bs, nq, n_obj, scale=2.0),
+           "pred_verb_logits": rng_tensor(73, bs, nq, n_verb, scale=2.0),
+           "pred_sub_boxes": rng_tensor(74, bs, nq, 4).sigmoid(),
+           "pred_obj_boxes": rng_tensor(75, bs, nq, 4).sigmoid()}
+    # make some subjects "person" (class 0) so that the zero-shot filter keeps a ragged subset per image
+    out["pred_sub_logits"][:, ::2, 0] += 8.0
+    sizes = torch.tensor([[480, 640], [800, 1333], [333, 500]])
+    return out, sizes
+
+
+def gold_postprocess():
+    """PostProcessHOI (models/hoi.py:4769-4873): plain, temperature and zero-shot (subject-filtered) variants.
+    The constructor reads datasets/priors/obj_verb_cooccurrence.npz for a buffer its forward never uses (the
+    only use is commented out, :4862): the instance is built without running it."""
+    from models.hoi import PostProcessHOI
+    out, sizes = postprocess_case()
+    rec = {}
+    for name, kw in (("plain", dict(temperature=False, zero_shot_hoi_eval=False)),
+                     ("temperature", dict(temperature=True, zero_shot_hoi_eval=False)),
+                     ("zeroshot", dict(temperature=False, zero_shot_hoi_eval=True))):
+        pp = PostProcessHOI.__new__(PostProcessHOI)
+        torch.nn.Module.__init__(pp)
+        pp.subject_category_id, pp.sigmoid, pp.verb_curing = 0, True, False
+        pp.temperature, pp.zero_shot_hoi_eval, pp.tao = kw["temperature"], kw["zero_shot_hoi_eval"], 0.07
+        res = pp(out, sizes)
+        for i, r in enumerate(res):
+            for k, v in r.items():
+                rec[f"{name}_{i}_{k}"] = v
+    save("postprocess", **rec)
+
+
 def main():
     R.install()
     torch.manual_seed(0)
@@ -431,6 +466,7 @@ def main():
     gold_parseda()
     gold_criterion()
     gold_parsed()
+    gold_postprocess()
 
 
 if __name__ == "__main__":

@@ -430,3 +430,28 @@ def test_batched_criterion_equals_per_layer_loop(sizes):
             assert (x is None or not x.any()) and (y is None or not y.any())
         else:
             close(x, y, 1e-4, 1e-6, "grad")
+
+
+@pytest.mark.parametrize("variant", ["plain", "temperature", "zeroshot"])
+def test_postprocess_hoi_matches_reference(variant):
+    """PostProcessHOI against the reference's results for seeded outputs of 3 images (golden generated by
+    tests/golden/make_model_golden.py::gold_postprocess): labels / ids exact, scores and boxes to float32
+    rounding; the zero-shot variant keeps a ragged, per-image subset of the queries."""
+    sys.path.insert(0, GOLD)
+    from make_model_golden import postprocess_case
+    from rlipv2_amd.postprocess import PostProcessHOI
+    g = load("postprocess")
+    out, sizes = postprocess_case()
+    pp = PostProcessHOI(0, temperature=(variant == "temperature"), zero_shot_hoi_eval=(variant == "zeroshot"))
+    res = pp(out, sizes)
+    assert len(res) == 3
+    kept = []
+    for i, r in enumerate(res):
+        assert set(r.keys()) == {"labels", "boxes", "verb_scores", "sub_ids", "obj_ids"}
+        for k in ("labels", "sub_ids", "obj_ids"):
+            assert torch.equal(r[k], torch.as_tensor(g[f"{variant}_{i}_{k}"])), (i, k)
+        close(r["boxes"], g[f"{variant}_{i}_boxes"], 1e-5, 1e-3, "boxes")
+        close(r["verb_scores"], g[f"{variant}_{i}_verb_scores"], 1e-5, 1e-7, "verb_scores")
+        kept.append(r["verb_scores"].shape[0])
+    if variant == "zeroshot":
+        assert any(k < 7 for k in kept) and any(k > 0 for k in kept)

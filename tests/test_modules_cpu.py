@@ -455,3 +455,38 @@ def test_postprocess_hoi_matches_reference(variant):
         kept.append(r["verb_scores"].shape[0])
     if variant == "zeroshot":
         assert any(k < 7 for k in kept) and any(k > 0 for k in kept)
+
+
+def test_checkpoint_interop_reference_layout(tmp_path):
+    """checkpoint.py: a reference-layout checkpoint ({'model': state_dict}) round-trips; `--pretrained`
+    semantics cut the learned queries to the run's num_queries (util/misc.py:479-490) and load non-strictly;
+    `--resume` semantics are strict."""
+    from rlipv2_amd import checkpoint as CK
+    big, _ = build_small_parseda()                                   # 20 queries
+    path = tmp_path / "ckpt.pth"
+    CK.save_checkpoint(path, big, epoch=3)
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(blob) == {"model", "epoch"} and blob["epoch"] == 3
+    # resume: strict, identical weights
+    twin, _ = build_small_parseda()
+    with torch.no_grad():
+        for p in twin.parameters():
+            p.add_(1.0)
+    CK.load_resume(twin, str(path))
+    for (n, a), (_, b) in zip(big.state_dict().items(), twin.state_dict().items()):
+        assert torch.equal(a, b), n
+    # pretrained into a model with fewer queries: tgt / verb_tgt / refpoint embeddings are the first rows
+    args = parseda.default_args(num_queries=12, enc_layers=4, dec_layers=2, dim_feedforward=512, pseudo_verb=True)
+    small = parseda.build_parseda(_FeatureBackbone((32, 64, 128)), args).eval()
+    with pytest.raises(RuntimeError):
+        CK.load_resume(small, blob)                                  # size mismatch without the filter
+    missing, unexpected = CK.load_pretrained(small, blob, num_queries=12, family="parseda")
+    assert missing == [] and unexpected == []
+    assert torch.equal(small.tgt_embed.weight, big.tgt_embed.weight[:12])
+    assert torch.equal(small.verb_tgt_embed.weight, big.verb_tgt_embed.weight[:12])
+    assert torch.equal(small.refpoint_embed.weight, big.refpoint_embed.weight[:12])
+    # ParSeD family filter: query_embed rows, verb_query_embed to half
+    sd = CK.filter_queries({"query_embed.weight": torch.zeros(100, 8), "transformer.verb_query_embed.weight": torch.zeros(50, 8),
+                            "other": torch.zeros(3)}, 40, family="parsed")
+    assert sd["query_embed.weight"].shape[0] == 40 and sd["transformer.verb_query_embed.weight"].shape[0] == 20
+    assert sd["other"].shape[0] == 3

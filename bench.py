@@ -187,7 +187,7 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     from rlipv2_amd import parseda, train
     margs = parseda.default_args(num_queries=args.queries)
     torch.manual_seed(0 + rank)                                       # reference main.py:505
-    model, criterion = train.build_training(margs, device=device, with_text_encoder=True)
+    model, criterion = train.build_training(margs, device=device, with_text_encoder=True, backbone_name=args.backbone)
     batch = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=8, device=device, seed=rank)
     master = args.dtype == "bf16" and args.precision == "master"
     if master:      # bf16 parameters / activations / gradients, float32 master weights in the optimiser
@@ -335,6 +335,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="train_step", choices=["train_step", "msda_step"])
     ap.add_argument("--queries", type=int, default=300)
+    ap.add_argument("--backbone", default="resnet50", choices=["resnet50", "swin_tiny", "swin_large"],
+                    help="resnet50 = BASELINE config 2 (the metric's configuration); swin_large = config 4 (use --batch 2)")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="do not capture the model phases as HIP graphs (single-GPU runs capture by default)")
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
@@ -361,7 +363,8 @@ def main():
         elapsed, kern, loss, n_params, graphed = run_train_step_bench(args, world, rank, local_rank, device)
         if rank == 0:
             emit(args, world, elapsed, kern, lib, workload_text=(
-                "train_step: RLIP_ParSeDA_v2 R50 4-scale %d-query train step (fwd phase A+B, SetCriterionHOI, bwd, "
+                "train_step: RLIP_ParSeDA_v2 " + {"resnet50": "R50", "swin_large": "Swin-L", "swin_tiny": "Swin-T"}[args.backbone]
+                + " 4-scale %d-query train step (fwd phase A+B, SetCriterionHOI, bwd, "
                 "clip 0.1, AdamW), batch %d/GPU, 800x1333, 64 relation/object texts, RoBERTa-base-shaped text "
                 "encoder in the step, %s; %.1f M trainable parameters; "
                 "final loss %.4f" % (args.queries, args.batch,

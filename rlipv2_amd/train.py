@@ -365,9 +365,15 @@ def freeze_parameters_without_gradient(step_module, criterion, batch, autocast_d
     return frozen
 
 
-def build_training(args=None, device="cuda:0", with_text_encoder=True):
+def build_training(args=None, device="cuda:0", with_text_encoder=True, backbone_name="resnet50"):
+    """model + criterion of the train step; `backbone_name`: "resnet50" (BASELINE configs 2-3) or a swin name
+    ("swin_large": configs 4-5)"""
     args = default_args() if args is None else args
-    backbone = build_r50_backbone(args.hidden_dim, train_backbone=True)
+    if "swin" in backbone_name:
+        from .swin import build_swin_backbone
+        backbone = build_swin_backbone(backbone_name, args.hidden_dim, num_feature_levels=3)
+    else:
+        backbone = build_r50_backbone(args.hidden_dim, train_backbone=True)
     text_encoder = TextEncoderStub() if with_text_encoder else None
     model = build_parseda(backbone, args, text_encoder=text_encoder).to(device)
     freeze_statically_unused(model)

@@ -454,6 +454,35 @@ def gold_postprocess():
     save("postprocess", **rec)
 
 
+SWIN_CFG = dict(embed_dim=24, depths=[2, 2, 2, 2], num_heads=[3, 6, 12, 24], window_size=7, out_indices=(1, 2, 3),
+                drop_path_rate=0.0)
+
+
+def swin_input():
+    return rng_tensor(81, 2, 3, 70, 90)              # sizes that need patch / window / merge padding
+
+
+def gold_swin():
+    """SwinTransformer (models/swin/swin_transformer.py:596-763), a 4-stage toy configuration: the three
+    output maps and gradients w.r.t. the image, a qkv weight, a merge weight and a relative-position table."""
+    from models.swin.swin_transformer import SwinTransformer
+    m = SwinTransformer(**SWIN_CFG).eval()
+    R.fill_closed_form(m)
+    x = swin_input().requires_grad_(True)
+    outs = m(x)
+    rec = {"keys": np.array(sorted(m.state_dict().keys()))}
+    total = 0
+    for i, (k, v) in enumerate(sorted(outs.items())):
+        rec[k] = v
+        total = total + (v * rng_tensor(90 + i, *v.shape)).sum()
+    total.backward()
+    rec["g_x"] = x.grad
+    for name in ("layers.0.blocks.1.attn.qkv.weight", "layers.1.downsample.reduction.weight",
+                 "layers.2.blocks.1.attn.relative_position_bias_table", "norm2.weight"):
+        rec["g_" + name] = dict(m.named_parameters())[name].grad
+    save("swin", **rec)
+
+
 def main():
     R.install()
     torch.manual_seed(0)
@@ -467,6 +496,7 @@ def main():
     gold_criterion()
     gold_parsed()
     gold_postprocess()
+    gold_swin()
 
 
 if __name__ == "__main__":

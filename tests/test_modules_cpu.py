@@ -490,3 +490,37 @@ def test_checkpoint_interop_reference_layout(tmp_path):
                             "other": torch.zeros(3)}, 40, family="parsed")
     assert sd["query_embed.weight"].shape[0] == 40 and sd["transformer.verb_query_embed.weight"].shape[0] == 20
     assert sd["other"].shape[0] == 3
+
+
+def test_swin_backbone_matches_reference():
+    """swin.SwinTransformer against the reference (golden: tests/golden/make_model_golden.py::gold_swin): same
+    state_dict keys, the three stage outputs, and gradients w.r.t. the image and four parameters; then the
+    SwinBackbone wrapper: preset channels / strides and the reference's freezing rule."""
+    sys.path.insert(0, GOLD)
+    from make_model_golden import SWIN_CFG, swin_input
+    from rlipv2_amd import swin
+    g = load("swin")
+    m = swin.SwinTransformer(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in SWIN_CFG.items()}).eval()
+    with np.load(os.path.join(GOLD, "model_swin.npz"), allow_pickle=False) as z:
+        assert sorted(m.state_dict().keys()) == [str(k) for k in z["keys"]]
+    fill_closed_form(m)
+    x = swin_input().requires_grad_(True)
+    outs = m(x)
+    total = 0
+    for i, (k, v) in enumerate(sorted(outs.items())):
+        close(v, g[k], 1e-4, 1e-5, k)
+        gen = torch.Generator().manual_seed(90 + i)
+        total = total + (v * torch.randn(*v.shape, generator=gen, dtype=torch.float64).float()).sum()
+    total.backward()
+    close(x.grad, g["g_x"], 1e-3, 1e-6, "g_x")
+    params = dict(m.named_parameters())
+    for name in ("layers.0.blocks.1.attn.qkv.weight", "layers.1.downsample.reduction.weight",
+                 "layers.2.blocks.1.attn.relative_position_bias_table", "norm2.weight"):
+        close(params[name].grad, g["g_" + name], 1e-3, 1e-5, name)
+
+    bb = swin.SwinBackbone("swin_large", 3)
+    assert bb.num_channels == [384, 768, 1536] and bb.strides == [8, 16, 32]
+    frozen = [n for n, p in bb.body.named_parameters() if not p.requires_grad]
+    assert frozen and all(("norm" in n) or ("relative_position_bias_table" in n) for n in frozen)
+    assert all(p.requires_grad for n, p in bb.body.named_parameters()
+               if "norm" not in n and "relative_position_bias_table" not in n)

@@ -239,3 +239,30 @@ def test_graphed_step_delivers_the_same_gradients_as_eager_autograd():
         grads_f = {n: p.grad.detach().float().clone() for n, p in params}
         d = distance(grads_f, grads_e)
         assert d <= 2.0 * noise + 1e-2, (d, noise)
+
+
+def test_swin_backbone_on_gpu_matches_reference_golden():
+    """swin.SwinTransformer on the GPU (float32: ROCm's scaled_dot_product_attention with the additive
+    relative-position / shift mask) against the reference golden; bf16 within a bf16 band of the float32 run."""
+    sys.path.insert(0, C.GOLD)
+    from make_model_golden import SWIN_CFG, swin_input
+    from rlipv2_amd import swin
+    g = C.load("swin")
+    m = swin.SwinTransformer(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in SWIN_CFG.items()}).eval()
+    fill_closed_form(m)
+    m = m.to(DEV)
+    x = swin_input().to(DEV).requires_grad_(True)
+    outs = m(x)
+    total = 0
+    for i, (k, v) in enumerate(sorted(outs.items())):
+        C.close(v.cpu(), g[k], 1e-3, 1e-4, k)
+        gen = torch.Generator().manual_seed(90 + i)
+        total = total + (v * torch.randn(*v.shape, generator=gen, dtype=torch.float64).float().to(DEV)).sum()
+    total.backward()
+    C.close(x.grad.cpu(), g["g_x"], 5e-3, 1e-4, "g_x")
+    mb = m.to(torch.bfloat16)
+    ob = mb(x.detach().to(torch.bfloat16))
+    for k, v in ob.items():
+        ref = g[k]
+        rel = float((v.float().cpu() - ref).norm() / ref.norm())
+        assert rel < 0.05, (k, rel)

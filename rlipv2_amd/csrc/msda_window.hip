@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
         const int nrec = misc[5];
         if (!(dbg & 4)) {
             const int ch = tid & 31;
-            constexpr int kChunk = 32;
+            const int kChunk = (dbg >> 8) ? (dbg >> 8) : 32;        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8)
             for (int base = (tid >> 5) * kChunk; base < nrec; base += (kThreads / 32) * kChunk) {
                 const int last = min(base + kChunk, nrec) - 1;
                 float acc = 0.f;

@@ -254,6 +254,10 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     if graphed:                          # every rank: the criterion holds a collective
         # kernels inside a replayed graph cannot be bracketed with events: probe them in two eager steps
         # of the very same train step (same model, batch, optimiser), right after the timed region
+        # (one untimed eager step first: the first eager backward after the graph replays re-grows the caching
+        #  allocator's pools, which showed up as 4x longer decoder launches in the probe)
+        train.train_step(eager_step, criterion, optimizer, batch, autocast_dtype=dtype)
+        torch.cuda.synchronize()
         timer.enabled = True
         for _ in range(2):
             train.train_step(eager_step, criterion, optimizer, batch, autocast_dtype=dtype)

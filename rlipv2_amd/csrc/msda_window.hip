@@ -172,7 +172,9 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
         if (tid == 0) misc[5] = 0;
 
         // ---- this thread's point: 4 corners (record key, weight, sort bucket) ---------------------------
-        // key = (level-relative target pixel << 8) | local query; bucket = low 5 bits of (y, x): equal
+        // key = (level-relative target pixel << 15) | (local query << 7): the low 15 bits ARE the byte offset of
+        // the query's staged grad_out row (128 bytes per row), so the walk needs one v_and_or per record for
+        // the LDS address instead of shift + mask + add; bucket = low 5 bits of (y, x): equal
         // targets always share a bucket, and a window of up to 32 x 32 pixels maps to buckets 1:1.
         unsigned key[4];
         int bkt[4];
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
             cw[2] = (hh_ok && wl) ? lh * hw * wgt : 0.f;    cw[3] = (hh_ok && wh_ok) ? lh * lw * wgt : 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                key[k] = ((unsigned)(cy[k >> 1] * W + cx[k & 1]) << 8) | (unsigned)ql;
+                key[k] = ((unsigned)(cy[k >> 1] * W + cx[k & 1]) << 15) | ((unsigned)ql << 7);
                 bkt[k] = ((cy[k >> 1] & 31) << 5) | (cx[k & 1] & 31);
             }
         }
@@ -238,33 +240,49 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
         // line + ~8 clk per 32-byte sector, per CU, whatever the lane count -- so a row must leave
         // in one instruction, not four.  Work is balanced by records, not by pixels: a coarse
         // level's hot pixel with hundreds of records is shared by many half-waves.
-        const int nrec = misc[5];
+        // pad the record list to a multiple of 8 with zero-weight copies of the last record (they extend its
+        // run and add nothing): the 4-way unrolled walk below then needs no per-record tail guards
+        int nrec = misc[5];
+        {
+            constexpr int kUnrollPad = 8;
+            const int pad = (kUnrollPad - (nrec & (kUnrollPad - 1))) & (kUnrollPad - 1);
+            if (nrec > 0 && tid < pad) rec[nrec + tid] = make_uint2(rec[nrec - 1].x, 0u);
+            nrec += (nrec > 0) ? pad : 0;
+            __syncthreads();
+        }
         if (!(dbg & 4)) {
+            constexpr int kUnroll = 8;
             const int ch = tid & 31;
-            const int kChunk = (dbg >> 8) ? (dbg >> 8) : 32;        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8)
+            const unsigned ch_byte = (unsigned)ch * 4u;
+            const unsigned row_bytes = (unsigned)row * 4u;
+            const unsigned char *go_bytes = reinterpret_cast<const unsigned char *>(go);
+            char *gbytes = reinterpret_cast<char *>(gimg);
+            const int kChunk = (dbg >> 8) ? (dbg >> 8) : 32;        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8; multiple of 8)
             for (int base = (tid >> 5) * kChunk; base < nrec; base += (kThreads / 32) * kChunk) {
-                const int last = min(base + kChunk, nrec) - 1;
+                const int end = min(base + kChunk, nrec);           // (end - base) is a multiple of 4
                 float acc = 0.f;
-                unsigned cur_px = rec[base].x >> 8;
-                for (int e = base; e <= last; e += 4) {
-                    uint2 r[4];
-                    float g[4];
+                unsigned cur_px = rec[base].x >> 15;
+                for (int e = base; e < end; e += kUnroll) {
+                    uint2 r[kUnroll];
+                    float g[kUnroll];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) r[i] = rec[min(e + i, last)];
+                    for (int i = 0; i < kUnroll; ++i) r[i] = rec[e + i];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) g[i] = go[(r[i].x & 255u) * kGoStride + ch];
+                    for (int i = 0; i < kUnroll; ++i)
+                        g[i] = *reinterpret_cast<const float *>(go_bytes + ((r[i].x & 0x7f80u) | ch_byte));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const unsigned px = r[i].x >> 8;
+                    for (int i = 0; i < kUnroll; ++i) {
+                        const unsigned px = r[i].x >> 15;
                         if (px != cur_px) {                     // the run of cur_px is complete
-                            if (!(dbg & 2)) atomic_add(gimg + (long)cur_px * row + ch, acc);
+                            if (!(dbg & 2))
+                                atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc);
                             acc = 0.f;
                             cur_px = px;
                         }
-                        acc = fmaf(e + i <= last ? __uint_as_float(r[i].y) : 0.f, g[i], acc);
+                        acc = fmaf(__uint_as_float(r[i].y), g[i], acc);
                     }
                 }
-                if (!(dbg & 2)) atomic_add(gimg + (long)cur_px * row + ch, acc);
+                if (!(dbg & 2)) atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc);
             }
         }
         __syncthreads();      // the next item reuses go / rec / cnt
@@ -281,8 +299,8 @@ bool window_supports(const Problem &p, bool backward)
     if (!backward && p.Lq != p.S) return false;
     if (p.dtype != MSDA_F32 && p.dtype != MSDA_BF16) return false;
     if (p.D != kD || p.L != kL || p.P != kP) return false;
-    if (p.S < 1 || p.S >= (1 << 24)) return false;
-    if ((long)p.S * p.M * kD >= (1L << 31)) return false;
+    if (p.S < 1 || p.S >= (1 << 17)) return false;          // record key: 17 bits of level-relative pixel index
+    if ((long)p.S * p.M * kD * 4 >= (1L << 32)) return false;   // 32-bit byte offsets inside one image's grad_value
     if ((long)p.N * p.Lq * p.M * kL * kP >= (1L << 31)) return false;
     return quad_supports(p);
 }

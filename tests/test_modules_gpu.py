@@ -266,3 +266,46 @@ def test_swin_backbone_on_gpu_matches_reference_golden():
         ref = g[k]
         rel = float((v.float().cpu() - ref).norm() / ref.norm())
         assert rel < 0.05, (k, rel)
+
+
+def test_graphed_data_parallel_step_on_one_rank_rccl():
+    """The data-parallel flavour of the graphed step on a 1-rank RCCL group: parameters broadcast, gradients
+    packed into the flat bf16 buffer inside the backward graph, one all-reduce, `p.grad` = views of the buffer
+    in the parameters' own layouts, and a fused optimiser step on them.  (Rank counts > 1 are covered on CPU
+    over gloo, tests/test_dp_cpu.py; this checks the RCCL / graph plumbing on the device.)"""
+    import torch.distributed as dist
+    from rlipv2_amd import parseda, train
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        torch.manual_seed(0)
+        margs = parseda.default_args(num_queries=40, enc_layers=4, dec_layers=2)
+        model, criterion = train.build_training(margs, device=DEV, with_text_encoder=True)
+        train.to_bf16(model)
+        batch = train.synthetic_batch(2, 256, 320, device=DEV, triplets=3)
+        batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        step = train.ParSeDATrainStep(model)
+        model.eval()
+        train.broadcast_parameters(model, 0)
+        train.freeze_parameters_without_gradient(step, criterion, batch)
+        params = [p for p in step.parameters() if p.requires_grad]
+        sync = train.GradientSynchronizer(params)
+        graphed = train.graph_step_module(step, model, batch, synchronizer=sync, criterion=criterion)
+        opt = train.FusedMasterAdamW(model)
+        before = [p.detach().float().clone() for p in params[:20]]
+        for _ in range(2):
+            loss = train.train_step(graphed, criterion, opt, batch, autocast_dtype=None)
+        assert torch.isfinite(loss)
+        lo, hi = sync.flat.data_ptr(), sync.flat.data_ptr() + sync.flat.numel() * 2
+        for p in params:
+            assert p.grad is not None and lo <= p.grad.data_ptr() < hi          # views of the flat buffer
+            assert p.grad.shape == p.shape and p.grad.stride() == p.stride()
+        assert float(sync.flat.float().abs().sum()) > 0
+        assert any(not torch.equal(b, p.detach().float()) for b, p in zip(before, params[:20]))
+    finally:
+        if created:
+            dist.destroy_process_group()

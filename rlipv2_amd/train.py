@@ -170,14 +170,18 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
+        # "thread_local": other threads of the process may call HIP while we capture -- with a process group
+        # alive, RCCL's watchdog thread polls events, which in the default "global" mode invalidates the capture
+        # (observed: abort in capture_end, depending on timing)
+        mode = "thread_local"
         self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.fwd_graph, pool=pool):
+        with torch.cuda.graph(self.fwd_graph, pool=pool, capture_error_mode=mode):
             self.static_out, self.state = forward_part()
         self.leaves = None
         if criterion is None:
             self.diff = [i for i, o in enumerate(self.static_out) if o.requires_grad]
             self.static_gout = [torch.zeros_like(self.static_out[i]) for i in self.diff]
-            with torch.cuda.graph(self.bwd_graph, pool=pool):
+            with torch.cuda.graph(self.bwd_graph, pool=pool, capture_error_mode=mode):
                 grads = torch.autograd.grad([self.static_out[i] for i in self.diff], self.params, self.static_gout,
                                             allow_unused=True)
                 if synchronizer is not None:
@@ -187,7 +191,7 @@ class GraphedStep:
         self.static_index = index.clone()                      # [2, K * matched pairs]: shape fixed by `sizes`
         self.static_num = num.clone()
         self.pinned_index = torch.empty(index.shape, dtype=index.dtype, pin_memory=True)
-        with torch.cuda.graph(self.bwd_graph, pool=pool):
+        with torch.cuda.graph(self.bwd_graph, pool=pool, capture_error_mode=mode):
             self.loss_dict, self.total, grads = loss_and_grads(self.static_out, self.state, self.static_index,
                                                                 self.static_num[0])
             if synchronizer is not None:

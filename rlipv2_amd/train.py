@@ -295,7 +295,15 @@ class GradientSynchronizer:
         missing = [v for v, g in zip(self.views, grads) if g is None]
         if missing:
             torch._foreach_zero_(missing)
-        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        # one mismatching (dst, src) layout pair sends the WHOLE _foreach_copy_ down its per-tensor slow path
+        # (747 copy kernels = 4 ms inside the backward graph, measured): keep those pairs out of it.  They are
+        # the ~20 convolution weights held channels-last whose gradients arrive contiguous.
+        same = [(v, g) for v, g in have if v.stride() == g.stride() and v.dtype == g.dtype]
+        other = [(v, g) for v, g in have if not (v.stride() == g.stride() and v.dtype == g.dtype)]
+        if same:
+            torch._foreach_copy_([v for v, _ in same], [g for _, g in same])
+        for v, g in other:
+            v.copy_(g)
         return self.views
 
     def _probe_avg(self):

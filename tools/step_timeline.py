@@ -13,7 +13,18 @@ batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=
 step_module = train.ParSeDATrainStep(model)
 opt = MasterWeightAdamW(model)
 model.train()
-graphed = train.graph_step_module(step_module, model, batch, criterion=criterion)
+sync = None
+if os.environ.get("STEP_DP") in ("1", "2", "3"):                     # 1-rank RCCL group: the data-parallel flavour of the step
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29579")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    train.freeze_parameters_without_gradient(step_module, criterion, batch)
+    sync = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
+    if os.environ["STEP_DP"] in ("2", "3"):
+        sync.all_reduce = lambda: None                     # ablation: no collective
+    if os.environ["STEP_DP"] == "3":
+        sync.pack = lambda grads: grads                    # ablation: no packing either
+graphed = train.graph_step_module(step_module, model, batch, synchronizer=sync, criterion=criterion)
 names = ["forward graph (model + cost matrices)", "host: D2H + assignment + H2D", "backward graph (losses + backward)", "optimizer"]
 acc_gpu = [0.0] * 4; acc_host = [0.0] * 4
 for it in range(steps + 3):

@@ -579,6 +579,85 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_kernel(
     }
 }
 
+// Geometry-sharing K1 (grad_sampling_loc / grad_attn_weight only): as quad_forward_shared_kernel, quad lane p
+// owns point p of every level -- it computes that sample's geometry once, the quad fetches the corner offsets
+// with DPP broadcasts, all four lanes take part in the channel dot products (8 channels each + quad reduction),
+// and lane p turns the four reduced dots of ITS sample into (g_x, g_y, g_aw).  PMC on the kernel above: VALU
+// busy 75 % of the kernel time with ~45 of ~150 instructions per sample being the replicated geometry.
+template <typename VT, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void quad_backward_shared_kernel(
+    const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const float *__restrict__ loc, const float *__restrict__ aw, const VT *__restrict__ grad_out, int total_qm,
+    int S, int M, int Lq, unsigned value_bytes, float *__restrict__ g_loc, float *__restrict__ g_aw)
+{
+    const int t = xcd_block_id() * kBlock + threadIdx.x;
+    int qm = t >> 2;
+    const int sub = t & 3;
+    const bool live = qm < total_qm;
+    qm = live ? qm : total_qm - 1;
+    const int m = qm % M;
+    const int n = (qm / M) / Lq;
+    const int row_bytes = M * kD * (int)sizeof(VT);
+    const unsigned head_byte = (unsigned)n * (unsigned)S * (unsigned)row_bytes + (unsigned)(m * kD) * (unsigned)sizeof(VT);
+    const unsigned sub_byte = (unsigned)(sub * 8) * (unsigned)sizeof(VT);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)value, 0, value_bytes, 0x00020000);
+    // memory side as in quad_backward_kernel: quad lane j loads / stores the 4 points of level j as whole
+    // 16-byte vectors (128 + 64 contiguous bytes per quad); the per-point ownership below is a register
+    // redistribution inside the quad (8-byte per-lane accesses measured 55 us slower)
+    const float4 *loc4 = reinterpret_cast<const float4 *>(loc) + (long)qm * 8 + sub * 2;
+    float4 la = loc4[0], lb = loc4[1];
+    float4 wa = reinterpret_cast<const float4 *>(aw)[(long)qm * 4 + sub];
+    float tg[8];
+    Vec8<VT>::load(grad_out + (long)qm * kD + sub * 8, tg);
+    float4 gla = make_float4(0.f, 0.f, 0.f, 0.f), glb = gla, ga = gla;
+    auto pick = [&](float v0, float v1, float v2, float v3) {     // element `sub` of the level-owner's vector
+        const float b0 = quad_bcast<0>(v0), b1 = quad_bcast<0>(v1), b2 = quad_bcast<0>(v2), b3 = quad_bcast<0>(v3);
+        return sub == 0 ? b0 : sub == 1 ? b1 : sub == 2 ? b2 : b3;
+    };
+#pragma unroll 1
+    for (int l = 0; l < kL; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
+        // (after l rotations quad lane 0 holds level l) -> this lane's own point of the level
+        const float px = pick(la.x, la.z, lb.x, lb.z), py = pick(la.y, la.w, lb.y, lb.w);
+        const float pw = pick(wa.x, wa.y, wa.z, wa.w);
+        const Corners c = corners_of<sizeof(VT)>(px, py, H, W, start, row_bytes, head_byte);
+        const float h_im = fmaf(py, (float)H, -0.5f), w_im = fmaf(px, (float)W, -0.5f);
+        const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+        const float wgt = inside ? pw : 0.f;
+        float out_a = 0.f, out_x = 0.f, out_y = 0.f;
+#pragma unroll
+        for (int s = 0; s < kP; ++s) {
+            const unsigned o00 = quad_bcast_u(s, c.o00) + sub_byte, o01 = quad_bcast_u(s, c.o01) + sub_byte;
+            const unsigned o10 = quad_bcast_u(s, c.o10) + sub_byte, o11 = quad_bcast_u(s, c.o11) + sub_byte;
+            const typename Corner8<VT>::raw r00 = Corner8<VT>::load(vr, o00), r01 = Corner8<VT>::load(vr, o01);
+            const typename Corner8<VT>::raw r10 = Corner8<VT>::load(vr, o10), r11 = Corner8<VT>::load(vr, o11);
+            float f[8];
+            Corner8<VT>::unpack(r00, f); const float e1 = quad_sum(dot8(tg, f));
+            Corner8<VT>::unpack(r01, f); const float e2 = quad_sum(dot8(tg, f));
+            Corner8<VT>::unpack(r10, f); const float e3 = quad_sum(dot8(tg, f));
+            Corner8<VT>::unpack(r11, f); const float e4 = quad_sum(dot8(tg, f));
+            // every lane evaluates the formulas with ITS sample's fractions; only lane s keeps the result
+            const float a_ = inside ? c.hh * (c.hw * e1 + c.lw * e2) + c.lh * (c.hw * e3 + c.lw * e4) : 0.f;
+            const float x_ = (float)W * wgt * (c.hh * (e2 - e1) + c.lh * (e4 - e3));
+            const float y_ = (float)H * wgt * (c.hw * (e3 - e1) + c.lw * (e4 - e2));
+            if (sub == s) { out_a = a_; out_x = x_; out_y = y_; }
+            if (s & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        // point p's results live in lane p: gather the level's 4 points into vectors, owner lane l keeps them
+        const float4 ra = make_float4(quad_bcast<0>(out_x), quad_bcast<0>(out_y), quad_bcast<1>(out_x), quad_bcast<1>(out_y));
+        const float4 rb = make_float4(quad_bcast<2>(out_x), quad_bcast<2>(out_y), quad_bcast<3>(out_x), quad_bcast<3>(out_y));
+        const float4 rw = make_float4(quad_bcast<0>(out_a), quad_bcast<1>(out_a), quad_bcast<2>(out_a), quad_bcast<3>(out_a));
+        if (sub == l) { gla = ra; glb = rb; ga = rw; }
+        quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
+    }
+    if (live) {
+        float4 *gl4 = reinterpret_cast<float4 *>(g_loc) + (long)qm * 8 + sub * 2;
+        gl4[0] = gla;
+        gl4[1] = glb;
+        reinterpret_cast<float4 *>(g_aw)[(long)qm * 4 + sub] = ga;
+    }
+}
+
 }  // namespace
 
 static unsigned value_bytes(const Problem &p)
@@ -671,6 +750,20 @@ void launch_quad_backward_reduce(const Problem &p)
 {
     const int total_qm = p.N * p.Lq * p.M;
     const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
+    static const int shared = [] { const char *v = getenv("RLIPV2_MSDA_K1_SHARED"); return v ? atoi(v) : 1; }();
+    if (shared) {
+        if (p.dtype == MSDA_F32)
+            hipLaunchKernelGGL((quad_backward_shared_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, p.stream,
+                               (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
+                               (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_loc,
+                               (float *)p.g_aw);
+        else
+            hipLaunchKernelGGL((quad_backward_shared_kernel<bf16_t, 4>), dim3(grid), dim3(kBlock), 0, p.stream,
+                               (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
+                               (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_loc,
+                               (float *)p.g_aw);
+        return;
+    }
     if (p.dtype == MSDA_F32)
         hipLaunchKernelGGL((quad_backward_kernel<float, 4, false>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,

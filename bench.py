@@ -355,11 +355,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # Development aid for boxes with ONE GPU: RLIPV2_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # RLIPV2_DIST_BACKEND=gloo carries the collectives over the host (RCCL refuses two ranks per device), so that
+    # the multi-rank control flow (broadcast, capture, synchroniser, collectives) runs for real.  Not a benchmark.
+    if os.environ.get("RLIPV2_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1 or (os.environ.get("RLIPV2_FORCE_DP") == "1" and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        backend = os.environ.get("RLIPV2_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     lib = _lib.lib()

@@ -264,26 +264,28 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
 }
 
 // out[e] = sum_c partial[c][e] + the contribution of the tail rows [tail0, T) the main kernel left out.
-// A workgroup owns 16 consecutive float4s (256 bytes per chunk) and splits the chunks (and the tail rows)
-// over 16 thread groups, so every thread has only chunks/16 independent loads in flight and the grid is
-// n/64 workgroups (a thread-per-element loop over 128 chunks was latency-bound at ~30 us).
+// A workgroup owns 256/CG consecutive float4s and splits the chunks (and the tail rows) over CG thread groups:
+// with many chunks (CG = 16) every thread has only chunks/16 independent loads in flight and the grid is n/64
+// workgroups (a thread-per-element loop over 128 chunks was latency-bound at ~30 us); with a handful of chunks
+// (small token counts) CG = 4 or 1 keeps all 256 threads busy instead of 15 idle groups out of 16.
 // BIAS: n = M and the tail term is dy[t][e..e+3]; otherwise e = m*K + k and it is dy[t][m] * x[t][k..k+3].
-template <bool F32, bool BIAS>
+template <bool F32, bool BIAS, int CG>
 __device__ __forceinline__ void reduce_body(const float *__restrict__ partial, int chunks, size_t n, int block,
                                             const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x, int tail0,
-                                            int T, int M, int K, void *__restrict__ out, float4 (*red)[16])
+                                            int T, int M, int K, void *__restrict__ out, float4 *red)
 {
-    const int q = threadIdx.x & 15, cg = threadIdx.x >> 4;
-    const size_t e = ((size_t)block * 16 + q) * 4;
+    constexpr int Q = 256 / CG;
+    const int q = threadIdx.x % Q, cg = threadIdx.x / Q;
+    const size_t e = ((size_t)block * Q + q) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < n) {
 #pragma unroll 4
-        for (int c = cg; c < chunks; c += 16) {
+        for (int c = cg; c < chunks; c += CG) {
             const float4 v = *reinterpret_cast<const float4 *>(partial + (size_t)c * n + e);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         const int m = BIAS ? (int)e : (int)(e / K), k = BIAS ? 0 : (int)(e % K);
-        for (int t = tail0 + cg; t < T; t += 16) {
+        for (int t = tail0 + cg; t < T; t += CG) {
             if (BIAS) {
                 const uint2 d = *reinterpret_cast<const uint2 *>(dy + (size_t)t * M + m);
                 s.x += bf16_to_float(d.x & 0xffffu); s.y += bf16_to_float(d.x >> 16);
@@ -296,14 +298,17 @@ __device__ __forceinline__ void reduce_body(const float *__restrict__ partial, i
             }
         }
     }
-    red[cg][q] = s;
-    __syncthreads();
-    if (cg != 0 || e >= n) return;
+    if (CG > 1) {
+        red[cg * Q + q] = s;
+        __syncthreads();
+        if (cg != 0) return;
 #pragma unroll
-    for (int g2 = 1; g2 < 16; ++g2) {
-        const float4 v = red[g2][q];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int g2 = 1; g2 < CG; ++g2) {
+            const float4 v = red[g2 * Q + q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
+    if (e >= n) return;
     if (F32) {
         *reinterpret_cast<float4 *>(static_cast<float *>(out) + e) = s;
     } else {
@@ -321,18 +326,18 @@ __device__ __forceinline__ void reduce_body(const float *__restrict__ partial, i
 
 // one launch for both results: workgroups [0, dw_blocks) reduce the weight-gradient partials, the rest the
 // bias-gradient partials (db may be absent: then the grid is dw_blocks)
-template <bool F32>
+template <bool F32, int CG>
 __global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__ partial,
                                                        const float *__restrict__ bias_partial, int chunks, int dw_blocks,
                                                        const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                        int tail0, int T, int M, int K, void *__restrict__ dw,
                                                        void *__restrict__ db)
 {
-    __shared__ float4 red[16][16];
+    __shared__ float4 red[256];
     if ((int)blockIdx.x < dw_blocks)
-        reduce_body<F32, false>(partial, chunks, (size_t)M * K, blockIdx.x, dy, x, tail0, T, M, K, dw, red);
+        reduce_body<F32, false, CG>(partial, chunks, (size_t)M * K, blockIdx.x, dy, x, tail0, T, M, K, dw, red);
     else
-        reduce_body<F32, true>(bias_partial, chunks, (size_t)M, blockIdx.x - dw_blocks, dy, x, tail0, T, M, K, db, red);
+        reduce_body<F32, true, CG>(bias_partial, chunks, (size_t)M, blockIdx.x - dw_blocks, dy, x, tail0, T, M, K, db, red);
 }
 
 struct Plan { int chunks, steps_per_chunk, steps_total, tiles; size_t partial_floats, bias_floats; };
@@ -345,7 +350,9 @@ bool make_plan(int T, int M, int K, Plan &pl)
     // two workgroups per CU in flight (a third fits, but its extra partial sums cost more than it hides)
     static int target = [] { const char *e = getenv("RLIPV2_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();   // measured: 512 beats 768 (fewer partials) and 256
     int chunks = (target + pl.tiles - 1) / pl.tiles;
-    if (chunks > pl.steps_total) chunks = pl.steps_total;
+    // a workgroup that runs only a step or two pays the pipeline prologue and a partial-sum slot for nothing
+    static int min_steps = [] { const char *e = getenv("RLIPV2_WGRAD_MINSTEPS"); return e ? atoi(e) : 8; }();   // measured (tools/wgrad_small.py): 8 beats 1-4 and 16 on the 256-1200-token shapes
+    if (chunks > pl.steps_total / min_steps) chunks = pl.steps_total / min_steps;
     if (chunks < 1) chunks = 1;
     pl.steps_per_chunk = pl.steps_total ? (pl.steps_total + chunks - 1) / chunks : 0;
     pl.chunks = pl.steps_total ? (pl.steps_total + pl.steps_per_chunk - 1) / pl.steps_per_chunk : 0;
@@ -403,12 +410,14 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
     }
     const size_t n = (size_t)M * K;
     const int tail0 = pl.steps_total * BK;
-    const int gw = (int)((n / 4 + 15) / 16), gb = db ? (int)(((size_t)M / 4 + 15) / 16) : 0;
-    if (out_f32)
-        hipLaunchKernelGGL(reduce_partials<true>, dim3(gw + gb), dim3(256), 0, stream, partial, bias_partial, pl.chunks, gw,
-                           dy16, x16, tail0, T, M, K, dw, db);
-    else
-        hipLaunchKernelGGL(reduce_partials<false>, dim3(gw + gb), dim3(256), 0, stream, partial, bias_partial, pl.chunks, gw,
-                           dy16, x16, tail0, T, M, K, dw, db);
+    // chunk groups per workgroup of the second pass (tail rows count like chunks: they are split the same way)
+    const int terms = pl.chunks + (T - tail0 + 3) / 4;
+    const int cg = terms >= 16 ? 16 : terms >= 4 ? 4 : 1, q = 256 / cg;
+    const int gw = (int)((n / 4 + q - 1) / q), gb = db ? (int)(((size_t)M / 4 + q - 1) / q) : 0;
+#define REDUCE(F, C) hipLaunchKernelGGL((reduce_partials<F, C>), dim3(gw + gb), dim3(256), 0, stream, partial, bias_partial, \
+                                        pl.chunks, gw, dy16, x16, tail0, T, M, K, dw, db)
+    if (out_f32) { if (cg == 16) REDUCE(true, 16); else if (cg == 4) REDUCE(true, 4); else REDUCE(true, 1); }
+    else         { if (cg == 16) REDUCE(false, 16); else if (cg == 4) REDUCE(false, 4); else REDUCE(false, 1); }
+#undef REDUCE
     return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
 }

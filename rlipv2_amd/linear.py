@@ -10,6 +10,7 @@ reference models/dab_deformable/deformable_transformer.py:571-576).
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -21,6 +22,26 @@ MIN_ROWS = 256
 enabled = True
 
 _workspaces = {}
+
+
+TUNED_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
+
+
+def use_tuned_library_gemms(path: str = TUNED_TABLE) -> bool:
+    """Lookup-only use of the hipBLASLt solution table recorded by `tools/tune_gemms.py` for the token-major
+    library GEMMs (forward / input gradient of the big Linears; the default heuristic is 10-35 % slower on
+    them).  Nothing is tuned at run time and nothing is written; a table recorded for other library versions
+    is rejected by PyTorch's validator and the defaults stay in force.  RLIPV2_TUNED_GEMMS=0 disables it."""
+    if os.environ.get("RLIPV2_TUNED_GEMMS", "1") == "0" or not os.path.exists(path):
+        return False
+    import torch.cuda.tunable as tunable
+    tunable.enable(True)
+    tunable.tuning_enable(False)
+    tunable.record_untuned_enable(False)
+    ok = bool(tunable.read_file(path))
+    import tempfile
+    tunable.set_filename(os.path.join(tempfile.gettempdir(), "rlipv2_tunableop_%d.csv" % os.getpid()))   # exit-time dump: out of the tree
+    return ok
 
 
 def _workspace(device, nbytes):

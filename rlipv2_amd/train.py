@@ -381,6 +381,9 @@ def build_training(args=None, device="cuda:0", with_text_encoder=True, backbone_
     """model + criterion of the train step; `backbone_name`: "resnet50" (BASELINE configs 2-3) or a swin name
     ("swin_large": configs 4-5)"""
     args = default_args() if args is None else args
+    if torch.cuda.is_available() and str(device).startswith("cuda"):
+        from .linear import use_tuned_library_gemms
+        use_tuned_library_gemms()
     if "swin" in backbone_name:
         from .swin import build_swin_backbone
         backbone = build_swin_backbone(backbone_name, args.hidden_dim, num_feature_levels=3)

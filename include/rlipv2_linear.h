@@ -39,6 +39,20 @@ int linear_wgrad_supported(int T, int M, int K);
 int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, int K, void *dw, void *db, int out_f32,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* 1 if (T, N, K) runs on the expand kernel: K == 256, N a multiple of 64, T >= 1. */
+int linear_expand_supported(int T, int N, int K);
+
+/* c[t, n] = epilogue(sum_k a[t, k] * b[n, k]) for the Linears that widen the 256-channel token tensors:
+ *   a [T, K] bf16 row-major, b [N, K] bf16 row-major (nn.Linear's weight layout), c [T, N] bf16; all 16-byte aligned;
+ *   bias [N] bf16 or NULL: added before the activation (the `F.linear(x, w, b)` of `DeformableTransformerEncoderLayer.
+ *   forward_ffn`, dab_deformable/deformable_transformer.py:1285-1289);
+ *   relu != 0: max(., 0) (the `activation` of the same line);
+ *   mask [T, N] bf16 or NULL: c is zeroed where mask <= 0 -- with mask = the saved ReLU output and b = W2^T this
+ *   is `threshold_backward(dy @ W2, h, 0)`, the input gradient of `linear2(relu(.))` reaching `linear1`, in one pass.
+ * float32 accumulation, one bf16 rounding at the end.  Returns 0, or an msda_status code (rlipv2_msda.h). */
+int linear_expand_bf16(const void *a, const void *b, const void *bias, const void *mask, int T, int N, int K, int relu,
+                       void *c, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librlipv2_msda.so")
+LIB_PATH = os.environ.get("RLIPV2_LIB_PATH") or os.path.join(_HERE, "librlipv2_msda.so")   # (override: ablation builds)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 # enum msda_dtype / msda_variant (include/rlipv2_msda.h)
@@ -24,6 +24,7 @@ EXPORTS = (
     "msda_prepare_forward", "msda_prepare_backward",
     # include/rlipv2_linear.h
     "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
+    "linear_expand_supported", "linear_expand_bf16",
     # include/rlipv2_norm.h
     "add_layernorm_supported", "add_layernorm_workspace_bytes", "add_layernorm_forward_bf16",
     "add_layernorm_backward_bf16",
@@ -81,6 +82,10 @@ def lib() -> ctypes.CDLL:
     L.linear_wgrad_supported.restype = i
     L.linear_wgrad_bf16.argtypes = [vp, vp, i, i, i, vp, vp, i, vp, ctypes.c_size_t, vp]
     L.linear_wgrad_bf16.restype = i
+    L.linear_expand_supported.argtypes = [i, i, i]
+    L.linear_expand_supported.restype = i
+    L.linear_expand_bf16.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, vp]
+    L.linear_expand_bf16.restype = i
     lg, f32 = ctypes.c_long, ctypes.c_float
     L.add_layernorm_supported.argtypes = [lg, i]
     L.add_layernorm_supported.restype = i

@@ -88,6 +88,83 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True, out_
     return dw, db
 
 
+EXPAND_MIN_ROWS = 4096      # below this the library GEMM + elementwise pair is launch-bound anyway
+
+
+def expand_supported(a: torch.Tensor, n: int) -> bool:
+    return (enabled and a.is_cuda and a.dtype == torch.bfloat16
+            and bool(_lib.lib().linear_expand_supported(a.numel() // a.shape[-1], n, a.shape[-1])))
+
+
+def expand_gemm(a: torch.Tensor, b: torch.Tensor, bias=None, mask=None, relu: bool = False) -> torch.Tensor:
+    """epilogue(a[..., 256] @ b[N, 256]^T) -> [..., N] (bf16, float32 accumulation) on the hand-written MFMA kernel
+    `csrc/expand_gemm.hip`: bias and ReLU applied in the workgroup, `mask` (a saved ReLU output, shape [..., N])
+    zeroes the result where mask <= 0 -- `threshold_backward` without its own pass over the [T, N] tensor."""
+    if not a.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise RuntimeError("expand_gemm: bfloat16 operands expected")
+    K = a.shape[-1]
+    a2 = a.reshape(-1, K).contiguous()
+    b = b.contiguous()
+    T, N = a2.shape[0], b.shape[0]
+    if b.shape[1] != K:
+        raise RuntimeError("expand_gemm: a and b disagree on the reduction width")
+    if bias is not None:
+        bias = bias.to(torch.bfloat16).contiguous()
+    if mask is not None:
+        if mask.dtype != torch.bfloat16 or mask.numel() != T * N:
+            raise RuntimeError("expand_gemm: mask must be bfloat16 of the output's shape")
+        mask = mask.contiguous()
+    c = torch.empty(T, N, dtype=torch.bfloat16, device=a.device)
+    st = _lib.lib().linear_expand_bf16(a2.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       mask.data_ptr() if mask is not None else None, T, N, K, int(relu), c.data_ptr(),
+                                       torch.cuda.current_stream(a.device).cuda_stream)
+    if st:
+        raise RuntimeError(f"expand_gemm: {_lib.strerror(st)} (T={T} N={N} K={K})")
+    return c.view(*a.shape[:-1], N)
+
+
+class FusedFFNFunction(torch.autograd.Function):
+    """linear2(relu(linear1(x))) of the encoder layer (`forward_ffn`, dab_deformable/deformable_transformer.py:1285-1289,
+    dropout 0) as ONE autograd node, so that the backward can hand the ReLU mask to the GEMM that produces the
+    hidden gradient: dh = (dy W2) * (h > 0) leaves `expand_gemm` already masked.  Saves per layer and step the
+    1.1 GB `threshold_backward` pass over the [88 892, 2048] tensors; both weight gradients on `token_gemm.hip`."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        # forward stays on the library (bias + ReLU in the hipBLASLt epilogue, tuned solution): measured 135-145 us
+        # against 150 us for expand_gemm(bias, relu) at N = 2048 -- the fused mask is where the own kernel pays
+        h = _linear_forward(x, w1, b1, True)
+        y = F.linear(h, w2, b2)
+        ctx.save_for_backward(x, w1, w2, h)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w1, w2, h = ctx.saved_tensors
+        dy = dy.contiguous()
+        dw2, db2 = linear_wgrad(dy, h, with_bias=True, out_dtype=w2.dtype)
+        dh = expand_gemm(dy, w2.t(), mask=h)                     # w2.t().contiguous(): 1 MB, inside expand_gemm
+        dw1, db1 = linear_wgrad(dh, x, with_bias=True, out_dtype=w1.dtype)
+        dx = dh.matmul(w1) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2
+
+
+def fused_ffn(x, linear1, linear2):
+    """linear2(relu(linear1(x))) -- fused node when the shapes are the encoder's (token-major, 256 -> N -> 256,
+    bf16 parameters, training), the two `token_linear` calls otherwise."""
+    w1, b1, w2, b2 = linear1.weight, linear1.bias, linear2.weight, linear2.bias
+    T = x.numel() // x.shape[-1]
+    if (not torch.is_autocast_enabled() and torch.is_grad_enabled() and b1 is not None and b2 is not None
+            and w1.requires_grad and w2.requires_grad and T >= EXPAND_MIN_ROWS and x.dtype == w1.dtype == w2.dtype
+            and expand_supported(x, w1.shape[0]) and supported(x, w1)
+            and w2.shape[0] % 128 == 0 and w1.shape[0] % 128 == 0 and os.environ.get("RLIPV2_FUSED_FFN", "1") != "0"):
+        return FusedFFNFunction.apply(x, w1, b1, w2, b2)
+    return token_linear(token_linear(x, w1, b1, relu=True), w2, b2)
+
+
 def _linear_forward(x, weight, bias, relu):
     if relu and bias is not None:
         # bias + ReLU in the GEMM epilogue (hipBLASLt): no separate activation pass over the output

@@ -165,3 +165,82 @@ def test_backbone_pointwise_gemm_route_matches_convolution_route():
         a, r = a.float(), r.float()
         assert float((a - r).norm() / r.norm()) < 5e-2
         assert float((a - r).abs().max()) < 0.25 * float(r.abs().max())
+
+
+# ---- expand GEMM (csrc/expand_gemm.hip): C = epilogue(A[T,256] B[N,256]^T) ---------------------------------------------
+def _expand_ref(a, b, bias, mask, relu):
+    c = a.float() @ b.float().t()
+    if bias is not None:
+        c = c + bias.float()
+    if relu:
+        c = c.relu()
+    c = c.to(torch.bfloat16)
+    if mask is not None:
+        c = torch.where(mask > 0, c, torch.zeros_like(c))
+    return c
+
+
+@gpu
+@pytest.mark.parametrize("T", [1, 63, 128, 129, 4097, 88892])
+@pytest.mark.parametrize("N", [64, 256, 2048])
+@pytest.mark.parametrize("mode", ["plain", "bias_relu", "mask", "bias_mask"])
+def test_expand_gemm_matches_float32_reference(T, N, mode):
+    from rlipv2_amd import linear
+    if T == 88892 and N != 2048:
+        pytest.skip("full-size case runs at the FFN width only")
+    g = torch.Generator(device="cuda").manual_seed(T * 7 + N)
+    a = torch.randn(T, 256, device="cuda", generator=g).to(torch.bfloat16)
+    b = (torch.randn(N, 256, device="cuda", generator=g) / 16).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16) if "bias" in mode else None
+    mask = torch.randn(T, N, device="cuda", generator=g).relu().to(torch.bfloat16) if "mask" in mode else None
+    relu = mode == "bias_relu"
+    c = linear.expand_gemm(a, b, bias=bias, mask=mask, relu=relu)
+    ref = _expand_ref(a, b, bias, mask, relu)
+    assert c.shape == (T, N) and c.dtype == torch.bfloat16
+    # float32 accumulation in a different order, one bf16 rounding: at most one bf16 ulp apart
+    err = (c.float() - ref.float()).abs()
+    tol = 2.0 ** -7 * ref.float().abs() + 1e-3
+    assert bool((err <= tol).all()), float((err - tol).max())
+    if mask is not None:
+        assert bool((c[mask <= 0] == 0).all())
+    if relu:
+        assert bool((c >= 0).all())
+
+
+@gpu
+def test_expand_gemm_rejects_what_it_cannot_do():
+    from rlipv2_amd import linear
+    a = torch.randn(8, 128, device="cuda").to(torch.bfloat16)
+    b = torch.randn(64, 128, device="cuda").to(torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        linear.expand_gemm(a, b)                                   # K != 256
+    a = torch.randn(8, 256, device="cuda").to(torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        linear.expand_gemm(a, torch.randn(65, 256, device="cuda").to(torch.bfloat16))   # N % 64
+    with pytest.raises(RuntimeError):
+        linear.expand_gemm(a.cpu(), b.cpu())
+
+
+@gpu
+def test_fused_ffn_gradients_match_the_unfused_path():
+    from rlipv2_amd import linear
+    torch.manual_seed(3)
+    T = 4 * 2222
+    lin1 = torch.nn.Linear(256, 1024).cuda().to(torch.bfloat16)
+    lin2 = torch.nn.Linear(1024, 256).cuda().to(torch.bfloat16)
+    x = torch.randn(4, T // 4, 256, device="cuda").to(torch.bfloat16).requires_grad_()
+    dy = torch.randn(4, T // 4, 256, device="cuda").to(torch.bfloat16)
+
+    def run(fn):
+        for p in (*lin1.parameters(), *lin2.parameters(), x):
+            p.grad = None
+        y = fn()
+        y.backward(dy)
+        return [y.detach().float()] + [p.grad.float() for p in (x, *lin1.parameters(), *lin2.parameters())]
+
+    fused = run(lambda: linear.fused_ffn(x, lin1, lin2))
+    plain = run(lambda: torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(x, lin1.weight, lin1.bias)),
+                                                   lin2.weight, lin2.bias))
+    for f, p in zip(fused, plain):
+        rel = (f - p).norm() / p.norm().clamp_min(1e-6)
+        assert float(rel) < 2e-2, float(rel)

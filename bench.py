@@ -188,6 +188,8 @@ class KernelTimer:
 def run_train_step_bench(args, world, rank, local_rank, device):
     from rlipv2_amd import parseda, train
     margs = parseda.default_args(num_queries=args.queries)
+    if os.environ.get("RLIPV2_MIOPEN_FIND", "0") == "1":
+        torch.backends.cudnn.benchmark = True       # MIOpen Find on first use of every convolution shape
     torch.manual_seed(0 + rank)                                       # reference main.py:505
     model, criterion = train.build_training(margs, device=device, with_text_encoder=True, backbone_name=args.backbone)
     batch = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=8, device=device, seed=rank)

@@ -32,6 +32,7 @@ from .blocks import (MLP, FeatureResizer, MultiBranchFusion, NestedTensor, inver
                      nested_tensor_from_tensor_list)
 from .decoder import DABDeformableTransformerDecoderHOI, DeformableTransformerDecoderLayer
 from .deform_attn import MSDeformAttn
+from .linear import add_row_vector
 from .encoder import DeformableTransformerEncoderLayer, RLIPv2_DeformableTransformerEncoder, _clones
 
 
@@ -139,7 +140,7 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
             bs = srcs[0].shape[0]
             src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
             mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
-            lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
+            lvl_pos = torch.cat([add_row_vector(p.flatten(2).transpose(1, 2), self.level_embed[l])
                                  for l, p in enumerate(pos_embeds)], 1)
             # device-resident int64 metadata, built once per pyramid shape (a host->device copy per step
             # would also be illegal inside a HIP-graph capture)

@@ -244,3 +244,18 @@ def test_fused_ffn_gradients_match_the_unfused_path():
     for f, p in zip(fused, plain):
         rel = (f - p).norm() / p.norm().clamp_min(1e-6)
         assert float(rel) < 2e-2, float(rel)
+
+
+@gpu
+def test_add_row_vector_gradient_matches_broadcast_add():
+    from rlipv2_amd import linear
+    torch.manual_seed(5)
+    full = torch.randn(4, 3000, 256, device="cuda").to(torch.bfloat16)
+    x = full[:, 500:2500]                                  # a strided slice, as the per-level pieces of the pyramid are
+    row = torch.randn(256, device="cuda").to(torch.bfloat16).requires_grad_()
+    g = torch.randn(4, 3000, 256, device="cuda").to(torch.bfloat16)[:, 500:2500]
+    y = linear.add_row_vector(x, row)
+    assert torch.equal(y, x + row.view(1, 1, -1))
+    y.backward(g)
+    ref = g.float().sum((0, 1))
+    assert float((row.grad.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())

@@ -308,7 +308,8 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
 
 extern "C" int linear_expand_supported(int T, int N, int K)
 {
-    return (T >= 1 && K == XK && N >= XBN && N % XBN == 0) ? 1 : 0;
+    // (32-bit byte offsets inside the [T, N] tensors)
+    return (T >= 1 && K == XK && N >= XBN && N % XBN == 0 && (size_t)T * N * 2 < ((size_t)1 << 32)) ? 1 : 0;
 }
 
 extern "C" int linear_expand_bf16(const void *a, const void *b, const void *bias, const void *mask, int T, int N, int K,

@@ -39,7 +39,7 @@ int linear_wgrad_supported(int T, int M, int K);
 int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, int K, void *dw, void *db, int out_f32,
                       void *workspace, size_t workspace_bytes, void *stream);
 
-/* 1 if (T, N, K) runs on the expand kernel: K == 256, N a multiple of 64, T >= 1. */
+/* 1 if (T, N, K) runs on the expand kernel: K == 256, N a multiple of 64, T >= 1, T * N * 2 < 2^32. */
 int linear_expand_supported(int T, int N, int K);
 
 /* c[t, n] = epilogue(sum_k a[t, k] * b[n, k]) for the Linears that widen the 256-channel token tensors:

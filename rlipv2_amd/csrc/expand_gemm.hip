@@ -22,15 +22,21 @@
 //   * the product is taken "swapped" (weights as the MFMA A operand, activations as B): a lane then owns one
 //     token and 4 consecutive output columns per accumulator quad, so the bf16 results leave as 8-byte LDS
 //     writes into a per-wave 64 x 64 staging tile (XOR-swizzled, no padding) and come back as 16-byte pieces of
-//     whole 128-byte rows for the coalesced epilogue: mask load, select, store.  The 64 columns of a step are
-//     computed as two halves of 32 (2 accumulators = 32 VGPRs): all 64 at once left no registers for the epilogue;
+//     whole 128-byte rows for the coalesced stores.  The 64 columns of a step are computed as two halves of 32
+//     (2 accumulators = 32 VGPRs): all 64 at once left no registers for the epilogue;
+//   * the mask rows of a step arrive by LDS-DMA in that same staging tile (same swizzle) while the first MFMA loop
+//     runs, are read back in the accumulator layout and applied to the packed results before these overwrite them:
+//     no registers are held across the MFMA loops (32 VGPRs of prefetched mask spilled), and the mask's HBM latency
+//     (~10 000 cycles per step when loaded next to its use, tools/expand_timeline.py) overlaps the MFMAs;
 //   * ALL LDS traffic is inline asm: hipcc makes every LDS access it can see wait for vmcnt(0) while an LDS-DMA may
 //     be in flight -- in the epilogue that meant waiting for the previous rows' global stores on every row.
 // Measured (tools/expand_bench.py, tools/expand_ablate.sh; T = 88 892, N = 2048): masked input gradient 215 us
 // against 360 us for the library GEMM + threshold_backward; bias + ReLU forward 150 us against 135-145 us for the
 // tuned library GEMM, so the forward stays on the library.  Ablation: skeleton 45 us + MFMA 34 + output stores 33 +
-// A loads 33 + DMA 7 add up -- the phases of a wave do not overlap yet (next: coalesced A loads through LDS, a
-// phase offset between the two workgroups of a CU).
+// A loads 33 + DMA 7 add up; the cycle-stamp timeline (tools/expand_timeline.py, -DXDBG=64) shows why: every
+// vector-memory instruction takes hundreds of cycles to ISSUE (8 DMA instructions: 800-3000 cycles) -- the memory
+// system is saturated by 128-byte pieces at 4 KB stride (one output / mask row segment per wave and step), at about
+// half the HBM rate.  Next: 256-512-byte runs per row (waves of a workgroup side by side in N instead of in T).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -58,6 +64,16 @@ constexpr int XWAVES = XTHREADS / 64;
 #endif
 #ifndef XDBG
 #define XDBG 0   // ablation build switches (tools/expand_ablate.sh); 0 in the product
+#endif
+#if XDBG & 64
+__device__ unsigned long long xdbg_ts[4 * 16 * 10];      // [probe][step][point] cycle stamps (timeline builds only)
+#define XTS(k)                                                                                             \
+    do {                                                                                                   \
+        if ((blockIdx.x == 0 || blockIdx.x == 301) && blockIdx.y == 0 && (tid == 0 || tid == 192))        \
+            xdbg_ts[(((blockIdx.x != 0) * 2 + (tid != 0)) * 16 + (i - step0)) * 10 + (k)] = clock64();    \
+    } while (0)
+#else
+#define XTS(k) do { } while (0)
 #endif
 constexpr int BTILE = XBN * XK * 2;         // 32 KB
 constexpr int CSTAGE = 64 * 128;            // per wave: 64 tokens x 64 columns bf16 = 8 KB
@@ -176,6 +192,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
         constexpr int BUF = 0;
         __builtin_amdgcn_s_barrier();          // tile i is in LDS, for every wave
         asm volatile("" ::: "memory");
+        XTS(0);
 
         // The 64-column tile is taken as two 32-column halves, one after the other: a half needs 2 accumulators
         // (32 VGPRs) next to the 128 of the resident A fragments; both halves at once (64) left the epilogue
@@ -183,8 +200,28 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
         const int ncol = i * XBN;
         unsigned swz = (unsigned)l32;              // opaque copy of the lane id: keeps the 16 swizzled addresses
         asm volatile("" : "+v"(swz));              // from being hoisted out of the column loop (16 registers)
-        const unsigned sw_w = (unsigned)(l32 >> 1) & 15u;                 // staging swizzle of this lane's token row
-        const unsigned wbase = stage_lds + (unsigned)l32 * 128u, hx = ((unsigned)hi ^ sw_w) << 3;
+        // staging tile of this wave: [64 tokens][128 bytes], 16-byte piece c of row r stored at piece c ^ ((r >> 1) & 7)
+        // (the same map for the mask that arrives by DMA and for the results that replace it)
+        const unsigned s3 = ((unsigned)(l32 >> 1) & 7u) << 4;
+        const unsigned wbase = stage_lds + (unsigned)l32 * 128u + (unsigned)hi * 8u;
+        const int q8 = lane & 7, r0 = lane >> 3;
+        const unsigned off0 = ((unsigned)(t0 + r0) * (unsigned)N + (unsigned)(ncol + q8 * 8)) * 2u, rstep = 16u * (unsigned)N;
+        char *cbytes = reinterpret_cast<char *>(c);
+        if (MASK) {
+            // the mask rows of this step travel straight into the staging tile (no registers) while the first MFMA
+            // loop runs: loaded next to their use (timeline build, tools/expand_timeline.py) the wave sat ~10 000
+            // cycles per step waiting for HBM.  DMA instruction j, lane l -> slot 64 j + l: row 8 j + (l >> 3),
+            // physical piece l & 7.  (32-bit byte offsets: the host checks T * N * 2 < 2^32.)
+            const char *mbytes = reinterpret_cast<const char *>(mask);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * j + r0;
+                const unsigned row = (unsigned)min(t0 + r, T - 1);
+                const unsigned src = (row * (unsigned)N + (unsigned)(ncol + ((q8 ^ ((r >> 1) & 7)) << 3))) * 2u;
+                __builtin_amdgcn_global_load_lds((global_void *)(mbytes + src),
+                                                 (lds_void *)(smem + BTILE + wave * CSTAGE + j * 1024), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             f32x16 acc[2];
@@ -229,6 +266,18 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
             // accumulator register q of lane (l32, hi) is column 8 (q / 4) + 4 hi + q % 4 of this half, token l32 of
             // token sub-tile mt.  All LDS traffic below is inline asm as well: a plain LDS access would make the
             // compiler wait for vmcnt(0), i.e. for the previous rows' global stores, every time.
+            XTS(1 + 2 * nt);
+            u32x2 mraw[2][4];
+            if (MASK) {
+                if (nt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the mask tile has landed
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mraw[mt][g] = lds_read_b64(wbase + mt * 32 * 128 + (s3 ^ ((4 * nt + g) << 4)));
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(mraw[0][0]), "+v"(mraw[0][1]), "+v"(mraw[0][2]), "+v"(mraw[0][3]), "+v"(mraw[1][0]),
+                               "+v"(mraw[1][1]), "+v"(mraw[1][2]), "+v"(mraw[1][3]));
+            }
             u32x2 braw[4];
             if (BIAS) {
                 const unsigned baddr = bias_lds + (unsigned)((i - step0) * XBN + nt * 32 + 4 * hi) * 2u;
@@ -254,57 +303,56 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
                     u32x2 o;
                     o[0] = pack_bf16(v[0], v[1]);
                     o[1] = pack_bf16(v[2], v[3]);
-                    lds_write_b64(wbase + mt * 32 * 128 + (hx ^ ((8 * nt + 2 * g) << 3)), o);
+                    if (MASK) {
+                        o[0] = keep_positive(o[0], mraw[mt][g][0]);
+                        o[1] = keep_positive(o[1], mraw[mt][g][1]);
+                    }
+                    lds_write_b64(wbase + mt * 32 * 128 + (s3 ^ ((4 * nt + g) << 4)), o);
                 }
+            XTS(2 + 2 * nt);
         }
         // every wave is done with tile i -> the next tile may overwrite it; its latency hides behind the rest of
         // the epilogue and, beyond that, behind the sibling workgroup
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        XTS(5);
         if (!(XDBG & 16) && i + 1 < step1) issue(i + 1);
         // read back whole rows: lane -> row (lane >> 3) + 8 jj, 16-byte slot lane & 7 (LDS runs a wave's
         // instructions in order, so the reads see the writes above without a wait in between)
-        asm volatile("" ::: "memory");          // keep the mask loads below the staging writes: the accumulators are dead there
-        const int q8 = lane & 7, r0 = lane >> 3;
-        const unsigned off0 = ((unsigned)(t0 + r0) * (unsigned)N + (unsigned)(ncol + q8 * 8)) * 2u, rstep = 16u * (unsigned)N;
-        const char *mbytes = reinterpret_cast<const char *>(mask);
-        char *cbytes = reinterpret_cast<char *>(c);
-        uint4 hmask[8];
-        if (MASK) {
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
-                hmask[jj] = (t0 + r0 + 8 * jj < T) ? *reinterpret_cast<const uint4 *>(mbytes + (off0 + jj * rstep))
-                                                   : make_uint4(0u, 0u, 0u, 0u);
-        }
+        XTS(6);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             u32x4 rv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned r = (unsigned)(r0 + 8 * (4 * half + j)), sw = (r >> 1) & 15u;
-                rv[j] = lds_read_b128<0>(stage_lds + r * 128u + (((unsigned)q8 ^ (sw >> 1)) << 4));
+                const unsigned r = (unsigned)(r0 + 8 * (4 * half + j));
+                rv[j] = lds_read_b128<0>(stage_lds + r * 128u + (((unsigned)q8 ^ ((r >> 1) & 7u)) << 4));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int jj = 4 * half + j, r = r0 + 8 * jj, sw = (r >> 1) & 15;
-                uint4 v = (sw & 1) ? make_uint4(rv[j][2], rv[j][3], rv[j][0], rv[j][1])
-                                   : make_uint4(rv[j][0], rv[j][1], rv[j][2], rv[j][3]);
-                if (MASK) {
-                    v.x = keep_positive(v.x, hmask[jj].x); v.y = keep_positive(v.y, hmask[jj].y);
-                    v.z = keep_positive(v.z, hmask[jj].z); v.w = keep_positive(v.w, hmask[jj].w);
-                }
+                const int jj = 4 * half + j, r = r0 + 8 * jj;
+                const uint4 v = make_uint4(rv[j][0], rv[j][1], rv[j][2], rv[j][3]);
                 if ((XDBG & 4) ? (v.x == 0x12345u && t0 + r < T) : (t0 + r < T))
                     *reinterpret_cast<uint4 *>(cbytes + (off0 + jj * rstep)) = v;
             }
         }
+        XTS(8);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile i+1 has landed (and this step's stores have left)
+        XTS(9);
     };
 
     for (int i = step0; i < step1; ++i) step_body(i);
 }
 
 }  // namespace
+
+#if XDBG & 64
+extern "C" int linear_expand_debug_read(void *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(xdbg_ts), sizeof(unsigned long long) * 4 * 16 * 10);
+}
+#endif
 
 extern "C" int linear_expand_supported(int T, int N, int K)
 {

@@ -43,6 +43,21 @@
 #include "msda_device.h"
 #include "msda_internal.h"
 
+#ifdef MSDA_K2_TIMELINE      // cycle stamps of workgroups 0 / 100 / 301 (timeline builds only, tools/k2_timeline.py)
+__device__ unsigned long long k2_ts[3 * 32 * 10];
+#define K2TS(k)                                                                                                  \
+    do {                                                                                                         \
+        if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 301) && ts_item < 32)           \
+            k2_ts[(((blockIdx.x != 0) + (blockIdx.x == 301)) * 32 + ts_item) * 10 + (k)] = clock64();          \
+    } while (0)
+extern "C" int msda_debug_k2_timeline(void *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(k2_ts), sizeof(k2_ts));
+}
+#else
+#define K2TS(k) do { } while (0)
+#endif
+
 namespace msda {
 
 namespace {
@@ -148,7 +163,11 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
     if (item >= item_end) return;
     ItemLoad<VT> nxt = load_item<VT, TILED>(item, tiles_per_image, shapes, starts, loc, aw, grad_out, M, Lq, ql, pt);
 
+    int ts_item = -1;
+    (void)ts_item;
     for (; item < item_end; item += blks) {
+        ++ts_item;
+        K2TS(0);
         const ItemLoad<VT> me = nxt;
         // software prefetch: the next item's operands travel while this item is sorted and walked
         if (item + blks < item_end)
@@ -199,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
             }
         }
         __syncthreads();
+        K2TS(1);
 
         // ---- counting sort by bucket: equal targets become adjacent records ----------------------------
         if (!(dbg & 16)) {
@@ -206,6 +226,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
             for (int k = 0; k < 4; ++k)
                 if (cw[k] != 0.f) atomicAdd(&cnt[bkt[k]], 1);
             __syncthreads();
+            K2TS(2);
             {   // exclusive scan of cnt[0..1024) -> cur[]; one element per thread
                 const int v = cnt[tid];
                 int inc = v;
@@ -216,13 +237,22 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
                 }
                 if ((tid & 63) == 63) misc[8 + (tid >> 6)] = inc;
                 __syncthreads();
-                int base = 0;
+                K2TS(3);
+                // prefix over the 16 wave totals inside every wave (one LDS read + 4 shuffles instead of 16 LDS reads
+                // and 16 selects per thread: this step took 2 100 of an item's 30 000 cycles, tools/k2_timeline.py)
+                int ws = ((tid & 63) < kThreads / 64) ? misc[8 + (tid & 63)] : 0;
 #pragma unroll
-                for (int wv = 0; wv < kThreads / 64; ++wv) base += (wv < (tid >> 6)) ? misc[8 + wv] : 0;
+                for (int off = 1; off < kThreads / 64; off <<= 1) {
+                    const int u = __shfl_up(ws, off, 64);
+                    if ((tid & 63) >= off) ws += u;
+                }
+                const int wv = tid >> 6;
+                const int base = wv ? __shfl(ws, wv - 1, 64) : 0;
                 cur[tid] = base + inc - v;
                 if (tid == kThreads - 1) misc[5] = base + inc;       // number of records
             }
             __syncthreads();
+            K2TS(4);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (cw[k] != 0.f) rec[atomicAdd(&cur[bkt[k]], 1)] = make_uint2(key[k], __float_as_uint(cw[k]));
@@ -232,6 +262,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
                 if (cw[k] != 0.f) rec[atomicAdd(&misc[5], 1)] = make_uint2(key[k], __float_as_uint(cw[k]));
         }
         __syncthreads();
+        K2TS(5);
 
         // ---- walk: 32 lanes (one channel each) per chunk of consecutive records ----------------------------
         // A run of records with the same target is summed in registers and leaves as ONE 32-lane
@@ -249,13 +280,19 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
             if (nrec > 0 && tid < pad) rec[nrec + tid] = make_uint2(rec[nrec - 1].x, 0u);
             nrec += (nrec > 0) ? pad : 0;
             __syncthreads();
+            K2TS(6);
         }
         if (!(dbg & 4)) {
             constexpr int kUnroll = 8;
             const int ch = tid & 31;
             const unsigned ch_byte = (unsigned)ch * 4u;
             const unsigned row_bytes = (unsigned)row * 4u;
-            const unsigned char *go_bytes = reinterpret_cast<const unsigned char *>(go);
+            // LDS address of this lane's channel in staged row 0; `go` sits at LDS offset 0 of a kernel without static
+            // LDS, so (row offset from the record key) | go_ch is the whole address: one v_and_or_b32 per record instead
+            // of and + add (the trap guards the assumption)
+            typedef const __attribute__((address_space(3))) float lds_cfloat;
+            const unsigned go_ch = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)go + ch_byte;
+            if (go_ch & 0x7f80u) __builtin_trap();
             char *gbytes = reinterpret_cast<char *>(gimg);
             const int kChunk = (dbg >> 8) ? (dbg >> 8) : 32;        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8; multiple of 8)
             for (int base = (tid >> 5) * kChunk; base < nrec; base += (kThreads / 32) * kChunk) {
@@ -269,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
                     for (int i = 0; i < kUnroll; ++i) r[i] = rec[e + i];
 #pragma unroll
                     for (int i = 0; i < kUnroll; ++i)
-                        g[i] = *reinterpret_cast<const float *>(go_bytes + ((r[i].x & 0x7f80u) | ch_byte));
+                        g[i] = *(lds_cfloat *)(uintptr_t)((r[i].x & 0x7f80u) | go_ch);
 #pragma unroll
                     for (int i = 0; i < kUnroll; ++i) {
                         const unsigned px = r[i].x >> 15;
@@ -277,6 +314,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
                             if (!(dbg & 2))
                                 atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc);
                             acc = 0.f;
+                            asm volatile("" : "+v"(acc));       // keep the reset inside the branch (no select outside it)
                             cur_px = px;
                         }
                         acc = fmaf(__uint_as_float(r[i].y), g[i], acc);
@@ -285,7 +323,9 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
                 if (!(dbg & 2)) atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc);
             }
         }
+        K2TS(8);
         __syncthreads();      // the next item reuses go / rec / cnt
+        K2TS(9);
     }
 }
 

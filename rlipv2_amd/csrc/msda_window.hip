@@ -129,7 +129,9 @@ __device__ __forceinline__ ItemLoad<VT> load_item(int item, int tiles_per_image,
 }
 
 template <typename VT, bool TILED>
-__global__ __launch_bounds__(kThreads) void scatter_kernel(
+// 8 waves per SIMD = 64 VGPRs = TWO of these 1024-thread workgroups per CU (the LDS carve-up is sized for two): at 70
+// VGPRs only one fits and the phases of an item (sort barriers, walk tail) have nothing to overlap with -- 870 vs 776 us
+__global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts, const float *__restrict__ loc,
     const float *__restrict__ aw, const VT *__restrict__ grad_out, int N, int S, int M, int Lq,
     float *__restrict__ g_value, int dbg)
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
         // run and add nothing): the 4-way unrolled walk below then needs no per-record tail guards
         int nrec = misc[5];
         {
-            constexpr int kUnrollPad = 8;
+            constexpr int kUnrollPad = 16;
             const int pad = (kUnrollPad - (nrec & (kUnrollPad - 1))) & (kUnrollPad - 1);
             if (nrec > 0 && tid < pad) rec[nrec + tid] = make_uint2(rec[nrec - 1].x, 0u);
             nrec += (nrec > 0) ? pad : 0;
@@ -283,7 +285,6 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
             K2TS(6);
         }
         if (!(dbg & 4)) {
-            constexpr int kUnroll = 8;
             const int ch = tid & 31;
             const unsigned ch_byte = (unsigned)ch * 4u;
             const unsigned row_bytes = (unsigned)row * 4u;
@@ -294,31 +295,51 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(
             const unsigned go_ch = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)go + ch_byte;
             if (go_ch & 0x7f80u) __builtin_trap();
             char *gbytes = reinterpret_cast<char *>(gimg);
-            const int kChunk = (dbg >> 8) ? (dbg >> 8) : 32;        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8; multiple of 8)
+            // records per half-wave visit: every visit ends with a flush, so 64 instead of 32 removes ~1/5 of the row
+            // atomics (893 -> 772 us once the walk itself was no longer the limit; 128 is no better and balances worse)
+            const int kChunk = (dbg >> 8) ? (dbg >> 8) : 64;        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8; multiple of 16)
+            // Records reach the 32 lanes of a half-wave through the registers, not through 32-fold broadcast reads:
+            // every row of 16 lanes loads 16 consecutive records with ONE ds_read_b64 (lane j: record j) and record i
+            // is handed to the row by DPP row_newbcast:i -- the key with a v_mov_dpp, the weight as the DPP operand of
+            // the v_fmac itself.  The LDS pipe was the walk's limit (2 of 3 LDS cycles per record were these
+            // broadcasts: tools/k2_timeline.py + the K2_NOBOUNDARY experiment); it is now 1/8 + 1 cycles per record.
+            const int l16 = tid & 15;
             for (int base = (tid >> 5) * kChunk; base < nrec; base += (kThreads / 32) * kChunk) {
-                const int end = min(base + kChunk, nrec);           // (end - base) is a multiple of 4
+                const int end = min(base + kChunk, nrec);           // (end - base) is a multiple of 16
                 float acc = 0.f;
                 unsigned cur_px = rec[base].x >> 15;
-                for (int e = base; e < end; e += kUnroll) {
-                    uint2 r[kUnroll];
-                    float g[kUnroll];
+                for (int e = base; e < end; e += 16) {
+                    const uint2 mine = rec[e + l16];
+                    unsigned key[16];
+                    float g[16];
+#define K2_KEY(I) key[I] = __builtin_amdgcn_update_dpp(0u, mine.x, 0x150 + I, 0xf, 0xf, false);
+                    K2_KEY(0) K2_KEY(1) K2_KEY(2) K2_KEY(3) K2_KEY(4) K2_KEY(5) K2_KEY(6) K2_KEY(7)
+                    K2_KEY(8) K2_KEY(9) K2_KEY(10) K2_KEY(11) K2_KEY(12) K2_KEY(13) K2_KEY(14) K2_KEY(15)
+#undef K2_KEY
 #pragma unroll
-                    for (int i = 0; i < kUnroll; ++i) r[i] = rec[e + i];
-#pragma unroll
-                    for (int i = 0; i < kUnroll; ++i)
-                        g[i] = *(lds_cfloat *)(uintptr_t)((r[i].x & 0x7f80u) | go_ch);
-#pragma unroll
-                    for (int i = 0; i < kUnroll; ++i) {
-                        const unsigned px = r[i].x >> 15;
-                        if (px != cur_px) {                     // the run of cur_px is complete
-                            if (!(dbg & 2))
-                                atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc);
-                            acc = 0.f;
-                            asm volatile("" : "+v"(acc));       // keep the reset inside the branch (no select outside it)
-                            cur_px = px;
-                        }
-                        acc = fmaf(__uint_as_float(r[i].y), g[i], acc);
+                    for (int i = 0; i < 16; ++i) g[i] = *(lds_cfloat *)(uintptr_t)((key[i] & 0x7f80u) | go_ch);
+#ifdef K2_NOBOUNDARY       // experiment: no run detection at all (wrong results; lower bound of the walk's cost)
+#define K2_BOUNDARY(px) false
+#else
+#define K2_BOUNDARY(px) ((px) != cur_px)
+#endif
+#define K2_STEP(I)                                                                                                   \
+                    {                                                                                                \
+                        const unsigned px = key[I] >> 15;                                                            \
+                        if (K2_BOUNDARY(px)) {                  /* the run of cur_px is complete */                  \
+                            if (!(dbg & 2))                                                                          \
+                                atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc); \
+                            acc = 0.f;                                                                               \
+                            asm volatile("" : "+v"(acc));       /* keep the reset inside the branch */               \
+                            cur_px = px;                                                                             \
+                        }                                                                                            \
+                        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #I " row_mask:0xf bank_mask:0xf"      \
+                                     : "+v"(acc) : "v"(mine.y), "v"(g[I]));                                          \
                     }
+                    K2_STEP(0) K2_STEP(1) K2_STEP(2) K2_STEP(3) K2_STEP(4) K2_STEP(5) K2_STEP(6) K2_STEP(7)
+                    K2_STEP(8) K2_STEP(9) K2_STEP(10) K2_STEP(11) K2_STEP(12) K2_STEP(13) K2_STEP(14) K2_STEP(15)
+#undef K2_STEP
+#undef K2_BOUNDARY
                 }
                 if (!(dbg & 2)) atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc);
             }

@@ -295,9 +295,11 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
             const unsigned go_ch = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)go + ch_byte;
             if (go_ch & 0x7f80u) __builtin_trap();
             char *gbytes = reinterpret_cast<char *>(gimg);
-            // records per half-wave visit: every visit ends with a flush, so 64 instead of 32 removes ~1/5 of the row
-            // atomics (893 -> 772 us once the walk itself was no longer the limit; 128 is no better and balances worse)
-            const int kChunk = (dbg >> 8) ? (dbg >> 8) : 64;        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8; multiple of 16)
+            // records per half-wave visit: every visit ends with a flush, so 64 instead of 32 removed ~1/5 of the row
+            // atomics (893 -> 772 us once the walk itself was no longer the limit).  Now ONE visit per half-wave, sized to
+            // the item (a multiple of the 16-record group): full tiles get 128, partly filled ones stay balanced
+            // (780 -> 771 us against a fixed 64; RLIPV2_MSDA_DEBUG bit 32 restores the fixed size)
+            const int kChunk = (dbg >> 8) ? (dbg >> 8) : ((dbg & 32) ? 64 : max(16, (((nrec + 31) / 32) + 15) & ~15));        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8; multiple of 16)
             // Records reach the 32 lanes of a half-wave through the registers, not through 32-fold broadcast reads:
             // every row of 16 lanes loads 16 consecutive records with ONE ds_read_b64 (lane j: record j) and record i
             // is handed to the row by DPP row_newbcast:i -- the key with a v_mov_dpp, the weight as the DPP operand of

@@ -11,7 +11,7 @@
 //   qproj  [R, M*L*P*3]   f32 or bf16: M*L*P*2 offsets (m, l, p, xy) then M*L*P logits (m, l, p)
 //   ref    [R, L, 2|4]    f32, normalised (x, y[, w, h])
 //   loc    [R, M, L, P, 2], aw [R, M, L, P]   f32            (R = N * Lq)
-// thread = (row, head): 32 offsets + 16 logits in registers, softmax without any cross-lane traffic.
+// thread = (row, head, level): see the kernels.
 #include "msda_device.h"
 #include "msda_internal.h"
 
@@ -71,45 +71,100 @@ __device__ __forceinline__ void level_scale(const float *ref_row, const int64_t 
     }
 }
 
+// n consecutive elements of the projection row as floats (n = 4 or 8)
+template <typename QT, int NV> __device__ __forceinline__ void load_n(const QT *p, float (&v)[NV]);
+template <> __device__ __forceinline__ void load_n<float, 4>(const float *p, float (&v)[4])
+{
+    const float4 a = *reinterpret_cast<const float4 *>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ __forceinline__ void load_n<float, 8>(const float *p, float (&v)[8])
+{
+    const float4 a = reinterpret_cast<const float4 *>(p)[0], b = reinterpret_cast<const float4 *>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load_n<bf16_t, 4>(const bf16_t *p, float (&v)[4])
+{
+    const uint2 a = *reinterpret_cast<const uint2 *>(p);
+    v[0] = bf16_lo(a.x); v[1] = bf16_hi(a.x); v[2] = bf16_lo(a.y); v[3] = bf16_hi(a.y);
+}
+template <> __device__ __forceinline__ void load_n<bf16_t, 8>(const bf16_t *p, float (&v)[8])
+{
+    const uint4 a = *reinterpret_cast<const uint4 *>(p);
+    v[0] = bf16_lo(a.x); v[1] = bf16_hi(a.x); v[2] = bf16_lo(a.y); v[3] = bf16_hi(a.y);
+    v[4] = bf16_lo(a.z); v[5] = bf16_hi(a.z); v[6] = bf16_lo(a.w); v[7] = bf16_hi(a.w);
+}
+template <typename QT, int NV> __device__ __forceinline__ void store_n(QT *p, const float (&v)[NV]);
+template <> __device__ __forceinline__ void store_n<float, 4>(float *p, const float (&v)[4])
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store_n<float, 8>(float *p, const float (&v)[8])
+{
+    reinterpret_cast<float4 *>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4 *>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store_n<bf16_t, 4>(bf16_t *p, const float (&v)[4])
+{
+    *reinterpret_cast<uint2 *>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+template <> __device__ __forceinline__ void store_n<bf16_t, 8>(bf16_t *p, const float (&v)[8])
+{
+    *reinterpret_cast<uint4 *>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                               pack_bf16x2(v[6], v[7]));
+}
+
+__device__ __forceinline__ float quad_max(float v)
+{
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    return fmaxf(v, __shfl_xor(v, 2, 64));
+}
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v += __shfl_xor(v, 1, 64);
+    return v + __shfl_xor(v, 2, 64);
+}
+
+// thread = (row, head, level): the four lanes of a (row, head) sit in one DPP quad, the softmax over the 16 samples is
+// 4 values per lane + two quad shuffles.  Every load / store instruction of a wave then covers one contiguous
+// kilobyte (16 bytes per lane) or two interleaved ones (the 32-byte location / offset pieces) -- with a thread per
+// (row, head) and 64-128 bytes per thread every store instruction touched 64 different lines (54 / 61 us per encoder
+// call against 25 us of HBM time).
 template <typename QT, int REFDIM>
 __global__ __launch_bounds__(kBlock) void prep_forward_kernel(const QT *__restrict__ qproj, const float *__restrict__ ref,
                                                               const int64_t *__restrict__ shapes, int R, int M,
                                                               float *__restrict__ loc, float *__restrict__ aw)
 {
     const long t = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= (long)R * M) return;
-    const long r = t / M;
-    const int m = (int)(t % M);
+    const long pair = t >> 2;                   // (row, head)
+    const int l = (int)(t & 3);                 // level
+    if (pair >= (long)R * M) return;            // (whole quads leave together)
+    const long r = pair / M;
+    const int m = (int)(pair % M);
     const QT *row = qproj + r * (M * kLP * 3);
     const float *ref_row = ref + r * (kL * REFDIM);
-    float off[2][16], lg[16];
-    load16<QT>(row + m * 32, off[0]);
-    load16<QT>(row + m * 32 + 16, off[1]);
-    load16<QT>(row + M * 32 + m * 16, lg);
-    // softmax over the 16 samples
-    float mx = lg[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, lg[i]);
+    float off[8], lg[4];
+    load_n<QT, 8>(row + m * 32 + l * 8, off);
+    load_n<QT, 4>(row + M * 32 + m * 16 + l * 4, lg);
+    // softmax over the 16 samples of the head
+    const float mx = quad_max(fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3])));
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { lg[i] = __expf(lg[i] - mx); sum += lg[i]; }
-    const float inv = 1.f / sum;
+    for (int i = 0; i < 4; ++i) { lg[i] = __expf(lg[i] - mx); sum += lg[i]; }
+    const float inv = 1.f / quad_sum(sum);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) lg[i] *= inv;
-    store16<float>(aw + t * 16, lg);
-    // locations: flat index within the head = (l*P + p)*2 + xy; off[h] holds flat 16h .. 16h+15
+    for (int i = 0; i < 4; ++i) lg[i] *= inv;
+    store_n<float, 4>(aw + pair * 16 + l * 4, lg);
+    float sx, sy;
+    level_scale<REFDIM>(ref_row, shapes, l, sx, sy);
+    const float rx = ref_row[l * REFDIM], ry = ref_row[l * REFDIM + 1];
+    float o[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float o[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int flat = 16 * h + i, l = flat >> 3, xy = flat & 1;
-            float sx, sy;
-            level_scale<REFDIM>(ref_row, shapes, l, sx, sy);
-            o[i] = fmaf(off[h][i], xy ? sy : sx, ref_row[l * REFDIM + xy]);
-        }
-        store16<float>(loc + t * 32 + 16 * h, o);
+    for (int pnt = 0; pnt < 4; ++pnt) {
+        o[2 * pnt] = fmaf(off[2 * pnt], sx, rx);
+        o[2 * pnt + 1] = fmaf(off[2 * pnt + 1], sy, ry);
     }
+    store_n<float, 8>(loc + pair * 32 + l * 8, o);
 }
 
 template <typename QT, int REFDIM>
@@ -121,46 +176,49 @@ __global__ __launch_bounds__(kBlock) void prep_backward_kernel(const QT *__restr
                                                                QT *__restrict__ g_qproj, float *__restrict__ g_ref)
 {
     const long t = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= (long)R * M) return;
-    const long r = t / M;
-    const int m = (int)(t % M);
+    const long pair = t >> 2;
+    const int l = (int)(t & 3);
+    if (pair >= (long)R * M) return;
+    const long r = pair / M;
+    const int m = (int)(pair % M);
     const float *ref_row = ref + r * (kL * REFDIM);
     QT *grow = g_qproj + r * (M * kLP * 3);
     // softmax backward: g_logit = aw * (g_aw - sum_j aw_j g_aw_j)
-    float a[16], ga[16];
-    load16<float>(aw + t * 16, a);
-    load16<float>(g_aw + t * 16, ga);
+    float a[4], ga[4];
+    load_n<float, 4>(aw + pair * 16 + l * 4, a);
+    load_n<float, 4>(g_aw + pair * 16 + l * 4, ga);
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dot = fmaf(a[i], ga[i], dot);
+    for (int i = 0; i < 4; ++i) dot = fmaf(a[i], ga[i], dot);
+    dot = quad_sum(dot);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ga[i] = a[i] * (ga[i] - dot);
-    store16<QT>(grow + M * 32 + m * 16, ga);
+    for (int i = 0; i < 4; ++i) ga[i] = a[i] * (ga[i] - dot);
+    store_n<QT, 4>(grow + M * 32 + m * 16 + l * 4, ga);
     // offsets: g_off = g_loc * scale; reference points: g_ref_xy = sum g_loc, g_ref_wh = sum g_loc * off * 0.5 / P
-    float gr[kL][4];
+    float gl[8], o[8], sx, sy;
+    load_n<float, 8>(g_loc + pair * 32 + l * 8, gl);
+    level_scale<REFDIM>(ref_row, shapes, l, sx, sy);
 #pragma unroll
-    for (int l = 0; l < kL; ++l) gr[l][0] = gr[l][1] = gr[l][2] = gr[l][3] = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float gl[16], off[16], o[16];
-        load16<float>(g_loc + t * 32 + 16 * h, gl);
-        if (REFDIM == 4 && g_ref) load16<QT>(qproj + r * (M * kLP * 3) + m * 32 + 16 * h, off);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int flat = 16 * h + i, l = flat >> 3, xy = flat & 1;
-            float sx, sy;
-            level_scale<REFDIM>(ref_row, shapes, l, sx, sy);
-            o[i] = gl[i] * (xy ? sy : sx);
-            gr[l][xy] += gl[i];
-            if (REFDIM == 4 && g_ref) gr[l][2 + xy] += gl[i] * off[i] * (0.5f / kP);
-        }
-        store16<QT>(grow + m * 32 + 16 * h, o);
+    for (int pnt = 0; pnt < 4; ++pnt) {
+        o[2 * pnt] = gl[2 * pnt] * sx;
+        o[2 * pnt + 1] = gl[2 * pnt + 1] * sy;
     }
+    store_n<QT, 8>(grow + m * 32 + l * 8, o);
     if (g_ref) {
+        float gr[4] = {0.f, 0.f, 0.f, 0.f};
+        float off[8];
+        if (REFDIM == 4) load_n<QT, 8>(qproj + r * (M * kLP * 3) + m * 32 + l * 8, off);
 #pragma unroll
-        for (int l = 0; l < kL; ++l)
+        for (int pnt = 0; pnt < 4; ++pnt) {
+            gr[0] += gl[2 * pnt];
+            gr[1] += gl[2 * pnt + 1];
+            if (REFDIM == 4) {
+                gr[2] += gl[2 * pnt] * off[2 * pnt] * (0.5f / kP);
+                gr[3] += gl[2 * pnt + 1] * off[2 * pnt + 1] * (0.5f / kP);
+            }
+        }
 #pragma unroll
-            for (int k = 0; k < REFDIM; ++k) atomic_add(g_ref + r * (kL * REFDIM) + l * REFDIM + k, gr[l][k]);
+        for (int k = 0; k < REFDIM; ++k) atomic_add(g_ref + r * (kL * REFDIM) + l * REFDIM + k, gr[k]);
     }
 }
 
@@ -179,7 +237,7 @@ int msda_prepare_forward(int qdtype, const void *qproj, const float *ref, int re
     if (L != kL || P != kP || (refdim != 2 && refdim != 4) || R < 0 || M < 0) return MSDA_ERR_BAD_SHAPE;
     if ((long)R * M == 0) return MSDA_OK;
     if (!qproj || !ref || !shapes || !loc || !aw) return MSDA_ERR_NULL_POINTER;
-    const int grid = (int)(((long)R * M + kBlock - 1) / kBlock);
+    const int grid = (int)(((long)R * M * 4 + kBlock - 1) / kBlock);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
 #define MSDA_PREP_FWD(QT, RD)                                                                                   \
@@ -199,7 +257,7 @@ int msda_prepare_backward(int qdtype, const void *qproj, const float *ref, int r
     if (L != kL || P != kP || (refdim != 2 && refdim != 4) || R < 0 || M < 0) return MSDA_ERR_BAD_SHAPE;
     if ((long)R * M == 0) return MSDA_OK;
     if (!qproj || !ref || !shapes || !aw || !g_loc || !g_aw || !g_qproj) return MSDA_ERR_NULL_POINTER;
-    const int grid = (int)(((long)R * M + kBlock - 1) / kBlock);
+    const int grid = (int)(((long)R * M * 4 + kBlock - 1) / kBlock);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
     if (g_ref && hipMemsetAsync(g_ref, 0, (size_t)R * kL * refdim * sizeof(float), s) != hipSuccess) return MSDA_ERR_LAUNCH;

@@ -1,2 +1,2 @@
-timeout 900 python -m pytest tests/test_msda_gpu.py -x -q -m gpu 2>&1 | tail -1
-timeout 600 python tools/msda_microbench.py --quick --variants window --out gpurun_out/mb.json 2>&1 | grep -E "^enc .*(model|uniform) .*(bfloat16|float32) +window +bwd|^dec.*bfloat16.*window +bwd"
+echo new; timeout 300 python tools/prep_bench.py 2>&1 | grep -v -i "warn\|run_backward"
+echo old; RLIPV2_LIB_PATH=$PWD/rlipv2_amd/_prep_old.so timeout 300 python tools/prep_bench.py 2>&1 | grep -v -i "warn\|run_backward"

@@ -108,7 +108,10 @@ __device__ __forceinline__ void mfma_step(const StepFragments &s, f32x16 (&acc)[
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
 }
 
-template <int dbg>
+// DIRECT != 0 (only when ONE chunk covers all tokens and there are no tail rows): the tile is final, so it is written
+// straight to dW / db -- bf16 (1) or float32 (2) -- and the second pass is not launched at all.  That is the case of the
+// 256- and 320-token Linears of the text layers: ~100 of the 230 weight gradients of a train step.
+template <int dbg, int DIRECT = 0>
 __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
     const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x, int M, int K, int steps_total,
     int steps_per_chunk, int chunks, float *__restrict__ partial, float *__restrict__ bias_partial)
@@ -237,7 +240,12 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
     __builtin_amdgcn_s_barrier();
 
     // partial[chunk][m][k]: accumulator register q of lane l is row 8*(q/4) + 4*(l/32) + q%4, column l%32
-    float *out = partial + ((size_t)chunk * M + (size_t)tm * BM + wm * 64) * K + (size_t)tk * BN + wn * 64;
+    auto rne = [](float f) -> uint16_t {
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);     // NaN stays NaN
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    const size_t tile_off = ((size_t)(DIRECT ? 0 : chunk) * M + (size_t)tm * BM + wm * 64) * K + (size_t)tk * BN + wn * 64;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -245,7 +253,9 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = i * 32 + 8 * (q >> 2) + 4 * (lane >> 5) + (q & 3);
-                out[(size_t)row * K + j * 32 + (lane & 31)] = acc[i][j][q];
+                const size_t e = tile_off + (size_t)row * K + j * 32 + (lane & 31);
+                if (DIRECT == 1) reinterpret_cast<uint16_t *>(partial)[e] = rne(acc[i][j][q]);   // `partial` IS dW here
+                else partial[e] = acc[i][j][q];
             }
 
     if (want_bias) {                                           // (all waves are past their last LDS read)
@@ -258,7 +268,9 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
             float s = 0.f;
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) s += red[rg * BM + tid];
-            bias_partial[(size_t)chunk * M + tm * BM + tid] = s;
+            const size_t e = (size_t)(DIRECT ? 0 : chunk) * M + tm * BM + tid;
+            if (DIRECT == 1) reinterpret_cast<uint16_t *>(bias_partial)[e] = rne(s);              // `bias_partial` IS db
+            else bias_partial[e] = s;
         }
     }
 }
@@ -391,6 +403,18 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
     const uint16_t *dy16 = static_cast<const uint16_t *>(dy), *x16 = static_cast<const uint16_t *>(x);
     float *partial = static_cast<float *>(workspace);
     float *bias_partial = partial + pl.partial_floats;
+    if (pl.chunks == 1 && T % BK == 0) {        // one chunk, no tail rows: final results straight from the main kernel
+        const int grid = ((pl.tiles + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+        if (out_f32)
+            hipLaunchKernelGGL((wgrad_kernel<0, 2>), dim3(grid), dim3(THREADS), LDS_BYTES, stream, dy16, x16, M, K,
+                               pl.steps_total, pl.steps_per_chunk, pl.chunks, static_cast<float *>(dw),
+                               static_cast<float *>(db));
+        else
+            hipLaunchKernelGGL((wgrad_kernel<0, 1>), dim3(grid), dim3(THREADS), LDS_BYTES, stream, dy16, x16, M, K,
+                               pl.steps_total, pl.steps_per_chunk, pl.chunks, static_cast<float *>(dw),
+                               static_cast<float *>(db));
+        return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+    }
     if (pl.chunks > 0) {
         const int total = pl.chunks * pl.tiles;
         const int grid = ((total + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;

@@ -21,7 +21,8 @@ def _case(T, M, K, seed=0):
 
 
 @gpu
-@pytest.mark.parametrize("T,M,K", [(1, 128, 128), (31, 128, 128), (32, 128, 128), (33, 256, 128), (1000, 128, 256),
+@pytest.mark.parametrize("T,M,K", [(1, 128, 128), (31, 128, 128), (32, 128, 128), (320, 768, 768), (256, 768, 3072),
+                                   (480, 384, 128), (33, 256, 128), (1000, 128, 256),
                                    (600, 256, 256), (2048, 384, 256), (2049, 256, 384), (2079, 128, 128),
                                    (4099, 384, 256), (22223, 256, 256), (88892, 256, 256), (88892, 1024, 256),
                                    (88892, 256, 1024), (88892, 384, 256)])

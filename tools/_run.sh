@@ -1,2 +1,2 @@
-echo new; timeout 300 python tools/prep_bench.py 2>&1 | grep -v -i "warn\|run_backward"
-echo old; RLIPV2_LIB_PATH=$PWD/rlipv2_amd/_prep_old.so timeout 300 python tools/prep_bench.py 2>&1 | grep -v -i "warn\|run_backward"
+timeout 900 python -m pytest tests/test_linear_gpu.py -x -q -m gpu 2>&1 | tail -1
+timeout 300 python tools/wgrad_small.py 2>&1 | grep "T=" | head -8

@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             name = r.get("Kernel_Name", "")
             if "msda" not in name: continue
             import re
-            mm = re.search(r"(quad_forward_kernel|quad_backward_kernel|scatter_kernel|generic_\w+_kernel|prep_\w+_kernel)<([^>]*)>", name)
+            mm = re.search(r"(quad_forward_kernel|quad_forward_shared_kernel|quad_backward_shared_kernel|quad_backward_kernel|tile_forward_kernel|scatter_kernel|generic_\w+_kernel|prep_\w+_kernel)<([^>]*)>", name)
             short = f"{mm.group(1)}<{mm.group(2)}>" if mm else name[:60]
             res[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(res.items()):

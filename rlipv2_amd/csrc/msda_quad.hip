@@ -702,10 +702,18 @@ void launch_quad_forward(const Problem &p)
         hipLaunchKernelGGL((quad_forward_kernel<float, 6, 2>), dim3(grid), dim3(kBlock), 0, p.stream,
                            (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                            total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.out, dbg);
-    else
-        hipLaunchKernelGGL((quad_forward_kernel<bf16_t, 5, 2>), dim3(grid), dim3(kBlock), 0, p.stream,
-                           (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                           total_qm, p.S, p.M, p.Lq, value_bytes(p), (bf16_t *)p.out, dbg);
+    else {
+        // register budget = 512 / waves per SIMD: 4 (128 VGPRs, no spills) 147 us, 5 (96 VGPRs, 16 bytes spilled) 155-163 us,
+        // 6 / 8 spill into the gather loop (415 / 823 us); 2-3 change nothing (the kernel needs ~110)
+        static const int waves = [] { const char *v = getenv("RLIPV2_MSDA_FWD_WAVES"); return v ? atoi(v) : 4; }();
+#define MSDA_FWD_BF16(W)                                                                                           \
+        hipLaunchKernelGGL((quad_forward_kernel<bf16_t, W, 2>), dim3(grid), dim3(kBlock), 0, p.stream,             \
+                           (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, \
+                           total_qm, p.S, p.M, p.Lq, value_bytes(p), (bf16_t *)p.out, dbg)
+        if (waves == 5) MSDA_FWD_BF16(5); else if (waves == 3) MSDA_FWD_BF16(3);
+        else MSDA_FWD_BF16(4);
+#undef MSDA_FWD_BF16
+    }
 }
 
 // window-staged forward (encoder self-attention shapes); see tile_forward_kernel
@@ -757,11 +765,17 @@ void launch_quad_backward_reduce(const Problem &p)
                                (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                                (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_loc,
                                (float *)p.g_aw);
-        else
-            hipLaunchKernelGGL((quad_backward_shared_kernel<bf16_t, 4>), dim3(grid), dim3(kBlock), 0, p.stream,
-                               (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
-                               (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_loc,
-                               (float *)p.g_aw);
+        else {
+            static const int waves = [] { const char *v = getenv("RLIPV2_MSDA_K1_WAVES"); return v ? atoi(v) : 4; }();
+#define MSDA_K1_BF16(W)                                                                                                \
+            hipLaunchKernelGGL((quad_backward_shared_kernel<bf16_t, W>), dim3(grid), dim3(kBlock), 0, p.stream,        \
+                               (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, \
+                               (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_loc, \
+                               (float *)p.g_aw)
+            if (waves == 5) MSDA_K1_BF16(5); else if (waves == 3) MSDA_K1_BF16(3);
+            else MSDA_K1_BF16(4);     // (4: 763 us whole backward, 5: 778, 6: 944, 8: 1194 -- spills)
+#undef MSDA_K1_BF16
+        }
         return;
     }
     if (p.dtype == MSDA_F32)

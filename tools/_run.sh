@@ -1,1 +1,2 @@
-timeout 1200 python tools/train_sanity.py 2>&1 | grep -v -i "warn\|run_backward" | tail -30
+timeout 900 python -m pytest tests/test_msda_gpu.py -x -q -m gpu 2>&1 | tail -1
+timeout 300 python tools/msda_microbench.py --quick --variants quad --out gpurun_out/mb.json 2>&1 | grep -E "bfloat16 +quad +fwd"

@@ -18,7 +18,7 @@ res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        mm = re.search(r"(quad_backward_kernel|scatter_kernel)", name)
+        mm = re.search(r"(quad_backward_shared_kernel|quad_backward_kernel|scatter_kernel)", name)
         if not mm: continue
         res[mm.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(res.items()):

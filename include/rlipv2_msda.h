@@ -42,6 +42,7 @@
 #ifndef RLIPV2_MSDA_H
 #define RLIPV2_MSDA_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -73,7 +74,9 @@ typedef enum msda_variant {
     MSDA_VARIANT_AUTO = 0,
     MSDA_VARIANT_GENERIC = 1,   /* any M, D, L, P; f32 / f64 / bf16: one wave per (n, q, m) */
     MSDA_VARIANT_QUAD = 2,      /* D = 32, L*P = 16: four lanes per (n, q, m), direct gathers */
-    MSDA_VARIANT_WINDOW = 3     /* D = 32, L*P = 16: LDS-staged sampling windows per query tile */
+    MSDA_VARIANT_WINDOW = 3,    /* D = 32, L*P = 16: LDS-staged sampling windows per query tile */
+    MSDA_VARIANT_DEST = 4       /* backward only, D = 32, L*P = 16: destination-stationary grad_value (no float atomics,
+                                   deterministic); needs a workspace and a host copy of spatial_shapes: msda_backward_ws */
 } msda_variant;
 
 /* Replaces ms_deform_attn_forward (reference models/ops/src/ms_deform_attn.h:36-53,
@@ -100,6 +103,10 @@ int msda_backward(int dtype,
  * grad_value on `stream`, skip the memset inside (lets a profiler time the kernel alone). */
 #define MSDA_FLAG_GRAD_VALUE_ZEROED 0x100
 
+/* Flag for msda_backward_ws with MSDA_BF16 and the DEST variant: grad_value is written as bfloat16 [N, S, M, D]
+ * (every row has exactly one writer there, so the float32 staging tensor and its cast are not needed). */
+#define MSDA_FLAG_GRAD_VALUE_BF16 0x200
+
 /* Same as the two calls above with an explicit kernel choice (msda_variant | flags). */
 int msda_forward_ex(int variant, int dtype,
                     const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
@@ -112,6 +119,25 @@ int msda_backward_ex(int variant, int dtype,
                      int N, int S, int M, int D, int L, int Lq, int P,
                      void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
                      void *stream);
+
+/* Backward with a caller-provided workspace and a HOST copy of spatial_shapes (int64 [L, 2], same values as the
+ * device tensor).  The host copy lets the library size its grids and workspace without a device sync and check
+ * sum(H_l * W_l) == S -- the assert of the reference module (models/ops/modules/ms_deform_attn.py:96), which the
+ * reference pays a sync for; a mismatch returns MSDA_ERR_BAD_SHAPE.  With it MSDA_VARIANT_AUTO picks the
+ * destination-stationary grad_value pass (MSDA_VARIANT_DEST): no float atomics, no zero-fill, results repeatable bit
+ * for bit.  spatial_shapes_host == NULL or workspace_bytes too small: falls back to msda_backward_ex (AUTO) or returns
+ * MSDA_ERR_BAD_VARIANT (explicit DEST / bfloat16 grad_value).  msda_backward_workspace_bytes returns 0 when the DEST
+ * variant does not support the problem.  The workspace is scratch: its contents need not survive the call, and
+ * concurrent calls on different streams need different workspaces. */
+size_t msda_backward_workspace_bytes(int dtype, const int64_t *spatial_shapes_host,
+                                     int N, int S, int M, int D, int L, int Lq, int P);
+int msda_backward_ws(int variant, int dtype,
+                     const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                     const int64_t *spatial_shapes_host,
+                     const void *sampling_loc, const void *attn_weight, const void *grad_out,
+                     int N, int S, int M, int D, int L, int Lq, int P,
+                     void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
+                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* Fused "sampling geometry" of the MSDeformAttn module (reference models/ops/modules/ms_deform_attn.py:101-112:
  * view + softmax over the L*P logits + offsets/(W,H) or offsets/P*wh*0.5 + reference point), L = 4, P = 4.

@@ -15,13 +15,15 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 # enum msda_dtype / msda_variant (include/rlipv2_msda.h)
 MSDA_F32, MSDA_F64, MSDA_BF16 = 0, 1, 2
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_QUAD, VARIANT_WINDOW = 0, 1, 2, 3
-VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "quad": VARIANT_QUAD, "window": VARIANT_WINDOW}
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_QUAD, VARIANT_WINDOW, VARIANT_DEST = 0, 1, 2, 3, 4
+VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "quad": VARIANT_QUAD, "window": VARIANT_WINDOW,
+            "dest": VARIANT_DEST}
+FLAG_GRAD_VALUE_ZEROED, FLAG_GRAD_VALUE_BF16 = 0x100, 0x200
 
 EXPORTS = (
     "msda_forward", "msda_backward", "msda_forward_ex", "msda_backward_ex", "msda_check_im2col_step",
     "msda_algorithmic_bytes", "msda_strerror", "msda_abi_version", "msda_variant_name", "msda_pick_variant",
-    "msda_prepare_forward", "msda_prepare_backward",
+    "msda_prepare_forward", "msda_prepare_backward", "msda_backward_workspace_bytes", "msda_backward_ws",
     # include/rlipv2_linear.h
     "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
     "linear_expand_supported", "linear_expand_bf16",
@@ -60,6 +62,10 @@ def lib() -> ctypes.CDLL:
     L.msda_backward.argtypes = [i, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp]
     L.msda_forward_ex.argtypes = [i, i, vp, vp, vp, vp, vp, *dims, vp, vp]
     L.msda_backward_ex.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp]
+    L.msda_backward_workspace_bytes.argtypes = [i, vp, *dims]
+    L.msda_backward_workspace_bytes.restype = ctypes.c_size_t
+    L.msda_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.msda_backward_ws.restype = i
     for f in (L.msda_forward, L.msda_backward, L.msda_forward_ex, L.msda_backward_ex):
         f.restype = i
     L.msda_prepare_forward.argtypes = [i, vp, vp, i, vp, i, i, i, i, vp, vp, vp]

@@ -74,6 +74,7 @@ const char *msda_variant_name(int variant)
         case MSDA_VARIANT_GENERIC: return "generic";
         case MSDA_VARIANT_QUAD: return "quad";
         case MSDA_VARIANT_WINDOW: return "window";
+        case MSDA_VARIANT_DEST: return "dest";
         default: return "?";
     }
 }
@@ -202,6 +203,68 @@ int msda_backward_ex(int variant, int dtype, const void *value, const int64_t *s
         default: return MSDA_ERR_BAD_VARIANT;
     }
     return finish_launch();
+}
+
+size_t msda_backward_workspace_bytes(int dtype, const int64_t *spatial_shapes_host, int N, int S, int M, int D, int L,
+                                     int Lq, int P)
+{
+    if (validate(dtype, N, S, M, D, L, Lq, P) != MSDA_OK || !spatial_shapes_host) return 0;
+    if ((long)N * S * M * D == 0 || (long)N * Lq * M * L * P == 0) return 0;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    return dest_workspace_bytes(p, spatial_shapes_host);
+}
+
+int msda_backward_ws(int variant, int dtype, const void *value, const int64_t *spatial_shapes,
+                     const int64_t *level_start, const int64_t *spatial_shapes_host, const void *sampling_loc,
+                     const void *attn_weight, const void *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                     void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    const int st = validate(dtype, N, S, M, D, L, Lq, P);
+    if (st != MSDA_OK) return st;
+    const bool out_bf16 = (variant & MSDA_FLAG_GRAD_VALUE_BF16) != 0;
+    const int v = variant & 0xff;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.loc = sampling_loc; p.aw = attn_weight;
+    p.grad_out = grad_out; p.g_value = grad_value; p.g_loc = grad_sampling_loc; p.g_aw = grad_attn_weight;
+    p.stream = (hipStream_t)stream;
+    if (spatial_shapes_host && L > 0 && !dest_shapes_consistent(p, spatial_shapes_host)) return MSDA_ERR_BAD_SHAPE;
+    const bool nonempty = (long)N * S * M * D > 0 && (long)N * Lq * M * L * P > 0;
+    if (!nonempty) {   // degenerate problems: zero-filled gradients (bfloat16 grad_value: half the bytes)
+        const long v_elems = (long)N * S * M * D, samples = (long)N * Lq * M * L * P;
+        hipStream_t hs = (hipStream_t)stream;
+        if (v_elems > 0 && (!grad_value || hipMemsetAsync(grad_value, 0, v_elems * (out_bf16 ? 2 : grad_value_elem(dtype)), hs) != hipSuccess))
+            return grad_value ? MSDA_ERR_LAUNCH : MSDA_ERR_NULL_POINTER;
+        if (samples > 0) {
+            if (!grad_sampling_loc || !grad_attn_weight) return MSDA_ERR_NULL_POINTER;
+            if (hipMemsetAsync(grad_sampling_loc, 0, samples * 2 * loc_elem(dtype), hs) != hipSuccess ||
+                hipMemsetAsync(grad_attn_weight, 0, samples * loc_elem(dtype), hs) != hipSuccess)
+                return MSDA_ERR_LAUNCH;
+        }
+        return MSDA_OK;
+    }
+    const size_t need = nonempty && spatial_shapes_host ? dest_workspace_bytes(p, spatial_shapes_host) : 0;
+    const bool can = need > 0 && workspace && workspace_bytes >= need &&
+                     aligned16(value) && aligned16(sampling_loc) && aligned16(attn_weight) && aligned16(grad_out) &&
+                     aligned16(grad_value) && aligned16(grad_sampling_loc) && aligned16(grad_attn_weight) &&
+                     aligned16(workspace);
+    if ((v == MSDA_VARIANT_AUTO || v == MSDA_VARIANT_DEST) && can) {
+        if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_out || !grad_value ||
+            !grad_sampling_loc || !grad_attn_weight)
+            return MSDA_ERR_NULL_POINTER;
+        if (out_bf16 && dtype != MSDA_BF16) return MSDA_ERR_BAD_VARIANT;
+        (void)hipGetLastError();
+        // (K1 forked onto a second stream beside the grad_value pass was measured: 678 vs 633 us -- K1's 44 k
+        //  workgroups fill the chip first, nothing overlaps)
+        launch_quad_backward_reduce(p);                                     // grad_sampling_loc / grad_attn_weight
+        launch_dest_scatter(p, spatial_shapes_host, workspace, out_bf16);   // grad_value, every row written once
+        return finish_launch();
+    }
+    if (v == MSDA_VARIANT_DEST || out_bf16) return MSDA_ERR_BAD_VARIANT;
+    return msda_backward_ex(variant, dtype, value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_out, N, S,
+                            M, D, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, stream);
 }
 
 int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,

@@ -40,4 +40,10 @@ bool window_supports(const Problem &p, bool backward);
 void launch_window_forward(const Problem &p);
 void launch_window_backward(const Problem &p);
 
+// destination-stationary grad_value (msda_dest.hip); shapes_host = host copy of spatial_shapes
+bool dest_supports(const Problem &p, const int64_t *shapes_host);
+int dest_shapes_consistent(const Problem &p, const int64_t *shapes_host);
+size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host);
+void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *workspace, bool out_bf16);
+
 }  // namespace msda

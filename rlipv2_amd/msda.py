@@ -17,6 +17,8 @@ the reference does (models/ops/src/ms_deform_attn.h:54) -- there is no fallback 
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -69,6 +71,28 @@ def _aux_dtype(value):
     return torch.float64 if value.dtype == torch.float64 else torch.float32
 
 
+def host_shapes(spatial_shapes):
+    """Host copy of the int64 [L, 2] level shapes, cached on the tensor object.  Callers that build the pyramid on
+    the host attach it up front (``attach_host_shapes``); otherwise the first use reads the tensor back once -- the
+    sync the reference module pays on every call for its ``sum(H*W) == Len_in`` assert (ms_deform_attn.py:96).
+    Returns None while a HIP graph is being captured and nothing is cached."""
+    cached = getattr(spatial_shapes, "_msda_host_shapes", None)
+    if cached is not None and cached[0] == spatial_shapes._version:
+        return cached[1]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    hs = tuple(int(v) for v in spatial_shapes.reshape(-1).tolist())
+    attach_host_shapes(spatial_shapes, hs)
+    return hs
+
+
+def attach_host_shapes(spatial_shapes, shapes):
+    """Record the host-side values of a device ``spatial_shapes`` tensor (list of (H, W))."""
+    flat = tuple(int(v) for hw in shapes for v in (hw if isinstance(hw, (tuple, list)) else (hw,)))
+    spatial_shapes._msda_host_shapes = (spatial_shapes._version, flat)
+    return spatial_shapes
+
+
 def _raise(status):
     raise RuntimeError(f"ms_deform_attn: {_lib.strerror(status)} (status {status})")
 
@@ -97,7 +121,11 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
                             im2col_step):
-    """Reference: ms_deform_attn_backward (vision.cpp:15) -> [grad_value, grad_sampling_loc, grad_attn_weight]."""
+    """Reference: ms_deform_attn_backward (vision.cpp:15) -> [grad_value, grad_sampling_loc, grad_attn_weight].
+
+    With a host copy of the level shapes available (``host_shapes``) the library runs its destination-stationary
+    grad_value pass (csrc/msda_dest.hip): no float atomics, repeatable bit for bit, grad_value written directly in
+    value's dtype."""
     _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                   extra=(("grad_output", grad_output),))
     L = _lib.lib()
@@ -109,15 +137,34 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     loc = sampling_loc if sampling_loc.dtype == aux else sampling_loc.to(aux)
     aw = attn_weight if attn_weight.dtype == aux else attn_weight.to(aux)
     go = grad_output if grad_output.dtype == value.dtype else grad_output.to(value.dtype)
-    g_value = torch.empty(value.shape, dtype=aux, device=value.device)   # zero-filled inside the library
     g_loc = torch.empty(sampling_loc.shape, dtype=aux, device=value.device)
     g_aw = torch.empty(attn_weight.shape, dtype=aux, device=value.device)
+    hs = host_shapes(spatial_shapes) if _variant_bwd in (_lib.VARIANT_AUTO, _lib.VARIANT_DEST) else None
+    ws_bytes = 0
+    if hs is not None:
+        hs_arr = (ctypes.c_int64 * len(hs))(*hs)
+        if sum(hs[0::2][k] * hs[1::2][k] for k in range(len(hs) // 2)) != S:
+            raise RuntimeError("ms_deform_attn: sum(H*W) of spatial_shapes != value.shape[1]")   # ms_deform_attn.py:96
+        ws_bytes = int(L.msda_backward_workspace_bytes(_DTYPES[value.dtype], hs_arr, N, S, M, D, nL, Lq, P))
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
-        st = L.msda_backward_ex(_variant_bwd, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
-                                level_start_index.data_ptr(), loc.data_ptr(), aw.data_ptr(), go.data_ptr(),
-                                N, S, M, D, nL, Lq, P, g_value.data_ptr(), g_loc.data_ptr(), g_aw.data_ptr(),
-                                stream)
+        if ws_bytes:
+            # every grad_value row has exactly one writer: written in value's dtype, no zero-fill
+            flags = _lib.FLAG_GRAD_VALUE_BF16 if value.dtype == torch.bfloat16 else 0
+            g_value = torch.empty(value.shape, dtype=value.dtype, device=value.device)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+            st = L.msda_backward_ws(_variant_bwd | flags, _DTYPES[value.dtype], value.data_ptr(),
+                                    spatial_shapes.data_ptr(), level_start_index.data_ptr(), hs_arr, loc.data_ptr(),
+                                    aw.data_ptr(), go.data_ptr(), N, S, M, D, nL, Lq, P, g_value.data_ptr(),
+                                    g_loc.data_ptr(), g_aw.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+        else:
+            if _variant_bwd == _lib.VARIANT_DEST:
+                _raise(-6)
+            g_value = torch.empty(value.shape, dtype=aux, device=value.device)   # zero-filled inside the library
+            st = L.msda_backward_ex(_variant_bwd, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                                    level_start_index.data_ptr(), loc.data_ptr(), aw.data_ptr(), go.data_ptr(),
+                                    N, S, M, D, nL, Lq, P, g_value.data_ptr(), g_loc.data_ptr(), g_aw.data_ptr(),
+                                    stream)
     if st:
         _raise(st)
     if g_value.dtype != value.dtype:

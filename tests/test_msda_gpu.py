@@ -75,6 +75,7 @@ def variants_for(D, L, P, tdtype, S=0, Lq=-1):
         v.append(("quad", "quad"))
         # "window" backward = reduce kernel + sorted scatter kernel; valid for any Lq
         v.append(("window" if (WINDOW_FWD and S == Lq) else "quad", "window" if WINDOW_BWD else "quad"))
+        v.append(("quad", "dest"))       # destination-stationary grad_value (msda_dest.hip)
     v.append(("auto", "auto"))
     return v
 
@@ -400,3 +401,53 @@ def test_full_size_encoder_backward_variants_agree(dtype, mode):
         for name, x, y in zip(("g_value", "g_loc", "g_aw"), r, base):
             err = (x - y).abs().max().item() / max(1e-6, y.abs().max().item())
             assert err <= (tol if name == "g_value" else 1e-4), (k, name, err)
+
+
+# ---------------------------------------------------------------------------------------------
+# destination-stationary backward (msda_dest.hip): determinism, full-size oracle comparison
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dest_backward_is_bitwise_repeatable(dtype):
+    """No float atomics and a fixed summation order: two runs give identical bits (the reference's
+    atomicAdd scatter, ms_deform_im2col_cuda.cuh:122-158, and the window variant do not)."""
+    from tools.msda_inputs import make_inputs
+    inp = make_inputs(2, mode="model", dtype=dtype, device=DEV, seed=11)
+    a = (inp["value"], inp["shapes"], inp["starts"], inp["loc"], inp["aw"], inp["grad_out"])
+    msda.set_variant("quad", "dest")
+    try:
+        first = msda.ms_deform_attn_backward(*a, 64)
+        for _ in range(3):
+            again = msda.ms_deform_attn_backward(*a, 64)
+            for x, y in zip(first, again):
+                assert torch.equal(x, y)
+    finally:
+        msda.set_variant("auto")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_size_single_image_vs_oracle(dtype):
+    """One 800x1333 image (S = Lq = 22223) through the product kernels (auto: quad forward, K1 + destination-
+    stationary backward) against the CPU oracle -- ties the full-size fast path to the oracle directly."""
+    from tools.msda_inputs import make_inputs
+    inp = make_inputs(1, mode="model", dtype=dtype, device=DEV, seed=5)
+    value = inp["value"].float().cpu().numpy()
+    go = inp["grad_out"].float().cpu().numpy()
+    shapes = inp["shapes"].cpu().numpy()
+    starts = inp["starts"].cpu().numpy()
+    loc = inp["loc"].cpu().numpy()
+    aw = inp["aw"].cpu().numpy()
+    ref_out = O.forward(value, shapes, starts, loc, aw, omp=True)
+    ref_gv, ref_gl, ref_ga = O.backward(value, shapes, starts, loc, aw, go, omp=True)
+    out = msda.ms_deform_attn_forward(inp["value"], inp["shapes"], inp["starts"], inp["loc"], inp["aw"], 64)
+    gv, gl, ga = msda.ms_deform_attn_backward(inp["value"], inp["shapes"], inp["starts"], inp["loc"], inp["aw"],
+                                              inp["grad_out"], 64)
+    out, gv = out.float().cpu().numpy(), gv.float().cpu().numpy()
+    if dtype == torch.bfloat16:
+        np.testing.assert_allclose(out, ref_out, rtol=2 ** -7, atol=2 ** -7 * float(np.abs(ref_out).max()))
+        np.testing.assert_allclose(gv, ref_gv, rtol=2 ** -7, atol=2 ** -7 * float(np.abs(ref_gv).max()))
+    else:
+        close32(out, ref_out)
+        close32(gv, ref_gv)
+    close32(ga.cpu().numpy(), ref_ga)
+    keep = ~kink_samples(dict(loc=loc, shapes=shapes))
+    close32(gl.cpu().numpy()[keep], ref_gl[keep])

@@ -37,6 +37,8 @@ import sys
 import time
 
 import torch
+import ctypes
+
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -62,11 +64,18 @@ class MsdaCall:
         self.code = _lib.MSDA_BF16 if dtype == torch.bfloat16 else _lib.MSDA_F32
         N, S, M, D, L, Lq, P = self.dims
         self.out = torch.empty(N, Lq, M * D, dtype=dtype, device=device)
-        self.g_value = torch.empty(N, S, M, D, dtype=torch.float32, device=device)
+        # the library's backward with a workspace and the host copy of the level shapes (msda_backward_ws): grad_value
+        # comes back in value's dtype, every row written exactly once (no zero-fill, no float atomics)
+        self.host_shapes = (ctypes.c_int64 * (2 * L))(*[int(v) for hw in PYRAMID_800x1333 for v in hw])
+        self.ws_bytes = int(_lib.lib().msda_backward_workspace_bytes(self.code, self.host_shapes, *self.dims))
+        self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=device)
+        self.bf16_grad = self.ws_bytes > 0 and dtype == torch.bfloat16
+        self.g_value = torch.empty(N, S, M, D, dtype=dtype if self.ws_bytes else torch.float32, device=device)
         self.g_loc = torch.empty_like(inp["loc"])
         self.g_aw = torch.empty_like(inp["aw"])
         self.bytes_fwd = _lib.algorithmic_bytes(self.code, False, *self.dims)
-        self.bytes_bwd = _lib.algorithmic_bytes(self.code, True, *self.dims)
+        self.bytes_bwd = _lib.algorithmic_bytes(self.code, True, *self.dims) - (N * S * M * D * 2 if self.bf16_grad else 0)
+        self.variant_bwd = "dest" if self.ws_bytes else None
         self.ev = {"fwd": [], "bwd": []}
 
     def forward(self, lib, stream, timed):
@@ -84,14 +93,15 @@ class MsdaCall:
 
     def backward(self, lib, stream, timed):
         i = self.inp
-        self.g_value.zero_()      # the reference's at::zeros_like; kept outside the event bracket
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-        st = lib.msda_backward_ex(_lib.VARIANT_AUTO | 0x100, self.code, i["value"].data_ptr(),
-                                  i["shapes"].data_ptr(), i["starts"].data_ptr(), i["loc"].data_ptr(),
+        flags = _lib.FLAG_GRAD_VALUE_BF16 if self.bf16_grad else 0
+        st = lib.msda_backward_ws(_lib.VARIANT_AUTO | flags, self.code, i["value"].data_ptr(),
+                                  i["shapes"].data_ptr(), i["starts"].data_ptr(), self.host_shapes, i["loc"].data_ptr(),
                                   i["aw"].data_ptr(), i["grad_out"].data_ptr(), *self.dims,
-                                  self.g_value.data_ptr(), self.g_loc.data_ptr(), self.g_aw.data_ptr(), stream)
+                                  self.g_value.data_ptr(), self.g_loc.data_ptr(), self.g_aw.data_ptr(),
+                                  self.ws.data_ptr(), self.ws_bytes, stream)
         if timed:
             b.record()
             self.ev["bwd"].append((a, b))
@@ -159,27 +169,30 @@ class KernelTimer:
         msda.ms_deform_attn_backward = self._wrap(self._bwd, "bwd")
 
     def _wrap(self, fn, direction):
-        def timed(value, shapes, starts, loc, aw, *rest):
+        def timed(value, shapes, starts, loc, aw, *rest, **kw):
             if not self.enabled:
-                return fn(value, shapes, starts, loc, aw, *rest)
+                return fn(value, shapes, starts, loc, aw, *rest, **kw)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            out = fn(value, shapes, starts, loc, aw, *rest)
+            out = fn(value, shapes, starts, loc, aw, *rest, **kw)
             b.record()
             N, S, M, D = value.shape
             dims = (N, S, M, D, shapes.shape[0], loc.shape[1], loc.shape[4])
             code = _lib.MSDA_BF16 if value.dtype == torch.bfloat16 else (_lib.MSDA_F64 if value.dtype == torch.float64 else _lib.MSDA_F32)
-            self.records.append((direction, dims, code, a, b))
+            # grad_value written directly as bfloat16 (destination-stationary backward): 2 bytes per element less
+            # than the float32 grad_value msda_algorithmic_bytes assumes
+            saved = N * S * M * D * 2 if (direction == "bwd" and out[0].dtype == torch.bfloat16) else 0
+            self.records.append((direction, dims, code, a, b, saved, self.msda.last_variant.get(direction)))
             return out
         return timed
 
     def summary(self):
         kern = {}
-        for direction, dims, code, a, b in self.records:
+        for direction, dims, code, a, b, saved, variant in self.records:
             kind = "enc" if dims[5] == dims[1] else f"dec{dims[5]}"
             k = kern.setdefault(f"{kind}_{direction}", {"ms": 0.0, "n": 0, "dims": dims, "code": code,
-                                                         "bwd": direction == "bwd",
-                                                         "bytes": _lib.algorithmic_bytes(code, direction == "bwd", *dims)})
+                                                         "bwd": direction == "bwd", "variant": variant,
+                                                         "bytes": _lib.algorithmic_bytes(code, direction == "bwd", *dims) - saved})
             k["ms"] += a.elapsed_time(b)
             k["n"] += 1
         return kern
@@ -227,6 +240,14 @@ def run_train_step_bench(args, world, rank, local_rank, device):
             print(f"[bench] graph capture failed, running eager: {type(e).__name__}\n{tb}", file=sys.stderr)
             torch.cuda.synchronize()
             step_module = eager_step
+        if world > 1:
+            # every rank must run the same collective schedule (one flat all-reduce vs DDP buckets): if the capture
+            # failed anywhere, all ranks fall back to the eager / DDP path together
+            ok = torch.tensor([1 if graphed else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and graphed:
+                print("[bench] graph capture failed on another rank, running eager here too", file=sys.stderr)
+                graphed, step_module, synchronizer = False, eager_step, None
     if (world > 1 or force_dp) and not graphed:
         step_module = torch.nn.parallel.DistributedDataParallel(
             eager_step, device_ids=[local_rank], find_unused_parameters=False, gradient_as_bucket_view=True,
@@ -287,7 +308,7 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
     kd = kern[dominant]
     mean_s = kd["ms"] / kd["n"] * 1e-3
     achieved = kd["bytes"] / mean_s / 1e9
-    variant = lib.msda_variant_name(lib.msda_pick_variant(int(kd["bwd"]), kd["code"], *kd["dims"])).decode()
+    variant = kd.get("variant") or lib.msda_variant_name(lib.msda_pick_variant(int(kd["bwd"]), kd["code"], *kd["dims"])).decode()
     images = args.batch * world * args.steps
     line = {
         "metric": METRIC,
@@ -430,7 +451,8 @@ def main():
             for d in ("fwd", "bwd"):
                 ms = [a.elapsed_time(b) for a, b in c.ev[d]]
                 k = kern.setdefault(f"{kind}_{d}", {"ms": 0.0, "n": 0, "bytes": c.bytes_fwd if d == "fwd" else c.bytes_bwd,
-                                                    "dims": c.dims, "code": c.code, "bwd": d == "bwd"})
+                                                    "dims": c.dims, "code": c.code, "bwd": d == "bwd",
+                                                    "variant": c.variant_bwd if d == "bwd" else None})
                 k["ms"] += sum(ms)
                 k["n"] += len(ms)
         emit(args, world, elapsed, kern, lib, workload_text=(

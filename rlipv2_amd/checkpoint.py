@@ -53,9 +53,26 @@ def load_resume(model, checkpoint):
     model.load_state_dict(_weights(checkpoint))
 
 
+def master_state_dict(model, optimizer):
+    """model.state_dict() with the optimiser's float32 master weights in place of the bf16-rounded parameters
+    (the reference's checkpoints hold float32 weights, main.py:599-629); buffers and frozen parameters are
+    upcast copies."""
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = getattr(optimizer, "names", None)
+    masters = getattr(optimizer, "master", None)
+    if names is not None and masters is not None:
+        for n, m in zip(names, masters):
+            if n in sd:
+                sd[n] = m.detach().clone().view_as(sd[n])
+    return {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
 def save_checkpoint(path, model, optimizer=None, epoch=None, extra=None):
-    """the reference's layout: {'model', 'optimizer', 'epoch', ...} (engine / util.misc.save_on_master)"""
-    ckpt = {"model": model.state_dict()}
+    """the reference's layout: {'model', 'optimizer', 'epoch', ...} (engine / util.misc.save_on_master).  With a
+    master-weight optimiser (bf16 parameters) 'model' holds the float32 masters, so that save -> resume continues
+    from exactly the weights the optimiser was updating."""
+    has_master = optimizer is not None and getattr(optimizer, "master", None) is not None
+    ckpt = {"model": master_state_dict(model, optimizer) if has_master else model.state_dict()}
     if optimizer is not None:
         ckpt["optimizer"] = optimizer.state_dict()
     if epoch is not None:

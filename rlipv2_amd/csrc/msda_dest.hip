@@ -656,13 +656,13 @@ void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *wor
     hipLaunchKernelGGL(bin_kernel, dim3(p.N * pl.Ts * p.M), dim3(256), pl.Td * 32, p.stream, pl, p.starts,
                        (const float *)p.loc, p.M, p.Lq, masks);
     constexpr int TH = kDestTH, kThreads = Geo<TH>::kThreads;
-    static const int per_cu = [] { const char *e = getenv("RLIPV2_DEST_WGS"); return e ? atoi(e) : 2; }();
-    static const bool waves8 = [] { const char *e = getenv("RLIPV2_DEST_WAVES"); return e && atoi(e) == 8; }();
+    static const int per_cu = ablation_env("RLIPV2_DEST_WGS", 2);
+    static const int waves = ablation_env("RLIPV2_DEST_WAVES", 4);
     const int grid = pl.items < 256 * per_cu ? pl.items : 256 * per_cu;
 #define MSDA_LAUNCH_DEST(VT, OT)                                                                                     \
     do {                                                                                                             \
         const int lds_bytes = DestLds<VT, TH>::bytes(pl.Ts);                                                         \
-        auto kern = waves8 ? dest_kernel<VT, OT, TH, 8> : dest_kernel<VT, OT, TH, 4>;                                \
+        auto kern = waves == 8 ? dest_kernel<VT, OT, TH, 8> : waves == 6 ? dest_kernel<VT, OT, TH, 6> : dest_kernel<VT, OT, TH, 4>; \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, p.stream, pl, p.starts, (const float *)p.loc, \
                            (const float *)p.aw, (const VT *)p.grad_out, masks, counter, (OT *)p.g_value, partials,  \
                            p.N, p.S, p.M, p.Lq);                                                                     \

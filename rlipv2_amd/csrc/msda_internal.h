@@ -6,6 +6,23 @@
 
 #include "../../include/rlipv2_msda.h"
 
+// Ablation / tuning switches (environment variables read by the launchers, `dbg` bits inside kernels that skip
+// work and produce WRONG results) exist only in builds with -DMSDA_ABLATION (make -C rlipv2_amd/csrc ablation ->
+// librlipv2_msda_ablation.so, loaded through RLIPV2_LIB_PATH by the tools/ scripts).  The shipped library reads no
+// environment and its kernels contain none of those branches: MSDA_DBG(x) folds to 0.
+#ifdef MSDA_ABLATION
+#include <cstdlib>
+#define MSDA_DBG(x) (x)
+namespace msda {
+inline int ablation_env(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+}
+#else
+#define MSDA_DBG(x) 0
+namespace msda {
+constexpr int ablation_env(const char *, int dflt) { return dflt; }
+}
+#endif
+
 namespace msda {
 
 struct Problem {

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_forward_kernel(
     int row_bytes = M * kD * (int)sizeof(VT);
     const unsigned lane_byte = (unsigned)n * (unsigned)S * (unsigned)row_bytes
                                + (unsigned)(m * kD + sub * 8) * (unsigned)sizeof(VT);
-    if (dbg & 1) row_bytes = 0;      // ablation: every gather hits the head's first rows (cache-resident)
+    if (MSDA_DBG(dbg) & 1) row_bytes = 0;      // ablation: every gather hits the head's first rows (cache-resident)
     const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)value, 0, value_bytes, 0x00020000);
     // quad lane j loads the 4 points of level j: (x,y) x 4 and 4 weights
     const float4 *loc4 = reinterpret_cast<const float4 *>(loc) + (long)qm * 8 + sub * 2;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kTileW *TH * 4, WAVES) void tile_forward_kernel(
         // ---- bounding boxes: quad lane j covers level j's 4 points --------------------------------------
         if (tid < 16) box[tid] = 0x3fffffff;
         __syncthreads();
-        if (live && !(dbg & 64)) {
+        if (live && !(MSDA_DBG(dbg) & 64)) {
             int mnx = 0x3fffffff, mny = 0x3fffffff, mxx = -0x3fffffff, mxy = -0x3fffffff;
             const float px[4] = {la.x, la.z, lb.x, lb.z}, py[4] = {la.y, la.w, lb.y, lb.w};
 #pragma unroll
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kTileW *TH * 4, WAVES) void tile_forward_kernel(
             const int npx = any[l] ? ww[l] * (by1 - by0[l] + 1) : 0;
             staged[l] = npx > 0 && used + npx <= MAXPX;
             wbase[l] = kZeroSlot + used * ROWB;
-            if (staged[l] && !(dbg & 16)) {
+            if (staged[l] && !(MSDA_DBG(dbg) & 16)) {
                 // window image: pixel-major, piece-minor -> piece i lands at byte 16 i of the stretch: exactly
                 // the lane-linear layout an LDS-DMA instruction writes
                 const int W = (int)shapes[2 * l + 1], start = (int)starts[l];
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kTileW *TH * 4, WAVES) void tile_forward_kernel(
         for (int l = 0; l < kL; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
             // (scheduling fences: the compiler otherwise hoists all 16 corner reads of a level and spills)
-            if (dbg & 32) {
+            if (MSDA_DBG(dbg) & 32) {
             } else if (staged[l]) {
                 tile_sample<VT>(win, wbase[l], quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, bx0[l], by0[l], ww[l], sub, acc);
                 __builtin_amdgcn_sched_barrier(0);
@@ -680,13 +680,12 @@ bool quad_supports(const Problem &p)
 
 void launch_quad_forward(const Problem &p)
 {
-    const char *e = getenv("RLIPV2_MSDA_DEBUG");       // ablation switch, profiling only
-    const int dbg = e ? atoi(e) : 0;
+    const int dbg = ablation_env("RLIPV2_MSDA_DEBUG", 0);       // ablation builds only
     const int total_qm = p.N * p.Lq * p.M;
     const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
     // geometry-sharing variant: measured 231 vs 268 us for float32 (model-like encoder input), no gain for bf16
     // (162 vs 165 us model-like, 296 vs 274 us uniform: that kernel is bound by the gather path, not by VALU)
-    static const int shared = [] { const char *v = getenv("RLIPV2_MSDA_FWD_SHARED"); return v ? atoi(v) : -1; }();
+    static const int shared = ablation_env("RLIPV2_MSDA_FWD_SHARED", -1);
     if ((shared == 1 || (shared == -1 && p.dtype == MSDA_F32)) && !dbg) {
         if (p.dtype == MSDA_F32)
             hipLaunchKernelGGL((quad_forward_shared_kernel<float, 6>), dim3(grid), dim3(kBlock), 0, p.stream,
@@ -705,7 +704,7 @@ void launch_quad_forward(const Problem &p)
     else {
         // register budget = 512 / waves per SIMD: 4 (128 VGPRs, no spills) 147 us, 5 (96 VGPRs, 16 bytes spilled) 155-163 us,
         // 6 / 8 spill into the gather loop (415 / 823 us); 2-3 change nothing (the kernel needs ~110)
-        static const int waves = [] { const char *v = getenv("RLIPV2_MSDA_FWD_WAVES"); return v ? atoi(v) : 4; }();
+        static const int waves = ablation_env("RLIPV2_MSDA_FWD_WAVES", 4);
 #define MSDA_FWD_BF16(W)                                                                                           \
         hipLaunchKernelGGL((quad_forward_kernel<bf16_t, W, 2>), dim3(grid), dim3(kBlock), 0, p.stream,             \
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, \
@@ -719,13 +718,12 @@ void launch_quad_forward(const Problem &p)
 // window-staged forward (encoder self-attention shapes); see tile_forward_kernel
 void launch_tile_forward(const Problem &p)
 {
-    static const int th = [] { const char *e = getenv("RLIPV2_MSDA_TILE_H"); return e ? atoi(e) : 8; }();
-    const char *de = getenv("RLIPV2_MSDA_DEBUG");       // ablation switches, profiling only
-    const int dbg = de ? atoi(de) : 0;
-    const char *g = getenv("RLIPV2_MSDA_GRID");
+    static const int th = ablation_env("RLIPV2_MSDA_TILE_H", 8);
+    const int dbg = ablation_env("RLIPV2_MSDA_DEBUG", 0);       // ablation builds only
+    const int g = ablation_env("RLIPV2_MSDA_GRID", 0);
     const int lds = kWinBytes + 64;
 #define MSDA_LAUNCH_TILE(VT, TH, WAVES, BLOCKS_PER_CU)                                                              \
-    hipLaunchKernelGGL((tile_forward_kernel<VT, TH, WAVES>), dim3(g ? atoi(g) : 256 * BLOCKS_PER_CU),               \
+    hipLaunchKernelGGL((tile_forward_kernel<VT, TH, WAVES>), dim3(g ? g : 256 * BLOCKS_PER_CU),               \
                        dim3(kTileW * TH * 4), lds, p.stream, (const VT *)p.value, p.shapes, p.starts,              \
                        (const float *)p.loc, (const float *)p.aw, p.N, p.S, p.M, p.Lq, value_bytes(p), (VT *)p.out, dbg)
     if (p.dtype == MSDA_F32) {
@@ -758,7 +756,7 @@ void launch_quad_backward_reduce(const Problem &p)
 {
     const int total_qm = p.N * p.Lq * p.M;
     const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
-    static const int shared = [] { const char *v = getenv("RLIPV2_MSDA_K1_SHARED"); return v ? atoi(v) : 1; }();
+    static const int shared = ablation_env("RLIPV2_MSDA_K1_SHARED", 1);
     if (shared) {
         if (p.dtype == MSDA_F32)
             hipLaunchKernelGGL((quad_backward_shared_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, p.stream,
@@ -766,7 +764,7 @@ void launch_quad_backward_reduce(const Problem &p)
                                (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_loc,
                                (float *)p.g_aw);
         else {
-            static const int waves = [] { const char *v = getenv("RLIPV2_MSDA_K1_WAVES"); return v ? atoi(v) : 4; }();
+            static const int waves = ablation_env("RLIPV2_MSDA_K1_WAVES", 4);
 #define MSDA_K1_BF16(W)                                                                                                \
             hipLaunchKernelGGL((quad_backward_shared_kernel<bf16_t, W>), dim3(grid), dim3(kBlock), 0, p.stream,        \
                                (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, \

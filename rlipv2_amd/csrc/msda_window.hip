@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
         K2TS(1);
 
         // ---- counting sort by bucket: equal targets become adjacent records ----------------------------
-        if (!(dbg & 16)) {
+        if (!(MSDA_DBG(dbg) & 16)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (cw[k] != 0.f) atomicAdd(&cnt[bkt[k]], 1);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
             if (nrec_real > 0 && tid < nrec - nrec_real) rec[nrec_real + tid] = make_uint2(rec[nrec_real - 1].x, 0u);
             __syncthreads();
         }
-        if (!(dbg & 4)) {
+        if (!(MSDA_DBG(dbg) & 4)) {
             const int ch = tid & 31;
             const unsigned ch_byte = (unsigned)ch * 4u;
             const unsigned row_bytes = (unsigned)row * 4u;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
             // atomics (893 -> 772 us once the walk itself was no longer the limit).  Now ONE visit per half-wave, sized to
             // the item (a multiple of the 16-record group): full tiles get 128, partly filled ones stay balanced
             // (780 -> 771 us against a fixed 64; RLIPV2_MSDA_DEBUG bit 32 restores the fixed size)
-            const int kChunk = (dbg >> 8) ? (dbg >> 8) : ((dbg & 32) ? 64 : max(16, (((nrec + 31) / 32) + 15) & ~15));        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8; multiple of 16)
+            const int kChunk = (MSDA_DBG(dbg) >> 8) ? (MSDA_DBG(dbg) >> 8) : ((MSDA_DBG(dbg) & 32) ? 64 : max(16, (((nrec + 31) / 32) + 15) & ~15));        // (profiling: RLIPV2_MSDA_DEBUG = chunk << 8; multiple of 16)
             // Records reach the 32 lanes of a half-wave through the registers, not through 32-fold broadcast reads:
             // every row of 16 lanes loads 16 consecutive records with ONE ds_read_b64 (lane j: record j) and record i
             // is handed to the row by DPP row_newbcast:i -- the key with a v_mov_dpp, the weight as the DPP operand of
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
                     {                                                                                                \
                         const unsigned px = key[I] >> 15;                                                            \
                         if (K2_BOUNDARY(px)) {                  /* the run of cur_px is complete */                  \
-                            if (!(dbg & 2))                                                                          \
+                            if (!(MSDA_DBG(dbg) & 2))                                                                          \
                                 atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc); \
                             acc = 0.f;                                                                               \
                             asm volatile("" : "+v"(acc));       /* keep the reset inside the branch */               \
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
 #undef K2_STEP
 #undef K2_BOUNDARY
                 }
-                if (!(dbg & 2)) atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc);
+                if (!(MSDA_DBG(dbg) & 2)) atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc);
             }
         }
         K2TS(8);
@@ -376,10 +376,9 @@ void launch_window_backward(const Problem &p)
     // K1: grad_sampling_loc / grad_attn_weight (no scatter)
     launch_quad_backward_reduce(p);
     // K2: grad_value.  Persistent grid: 2 blocks of 1024 threads per CU (LDS- and wave-limited).
-    const char *e = getenv("RLIPV2_MSDA_DEBUG");       // ablation switches, profiling only
-    const int dbg = e ? atoi(e) : 0;
-    const char *g = getenv("RLIPV2_MSDA_GRID");
-    const int grid = g ? atoi(g) : 256 * 2;
+    const int dbg = ablation_env("RLIPV2_MSDA_DEBUG", 0);       // ablation builds only
+    const int g = ablation_env("RLIPV2_MSDA_GRID", 0);
+    const int grid = g ? g : 256 * 2;
     const bool tiled = p.Lq == p.S;                    // encoder self-attention: queries are the pixels
 #define MSDA_LAUNCH_SCATTER(VT, TILED)                                                                         \
     hipLaunchKernelGGL((scatter_kernel<VT, TILED>), dim3(grid), dim3(kThreads), kLdsBytes, p.stream, p.shapes, \

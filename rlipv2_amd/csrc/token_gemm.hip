@@ -31,6 +31,7 @@
 
 #include "../../include/rlipv2_linear.h"
 #include "../../include/rlipv2_msda.h"
+#include "msda_internal.h"
 
 namespace {
 
@@ -360,10 +361,10 @@ bool make_plan(int T, int M, int K, Plan &pl)
     pl.tiles = (M / BM) * (K / BN);
     pl.steps_total = T / BK;                                   // whole 32-token steps; the rest is the tail
     // two workgroups per CU in flight (a third fits, but its extra partial sums cost more than it hides)
-    static int target = [] { const char *e = getenv("RLIPV2_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();   // measured: 512 beats 768 (fewer partials) and 256
+    static int target = msda::ablation_env("RLIPV2_WGRAD_BLOCKS", 512);   // measured: 512 beats 768 (fewer partials) and 256
     int chunks = (target + pl.tiles - 1) / pl.tiles;
     // a workgroup that runs only a step or two pays the pipeline prologue and a partial-sum slot for nothing
-    static int min_steps = [] { const char *e = getenv("RLIPV2_WGRAD_MINSTEPS"); return e ? atoi(e) : 8; }();   // measured (tools/wgrad_small.py): 8 beats 1-4 and 16 on the 256-1200-token shapes
+    static int min_steps = msda::ablation_env("RLIPV2_WGRAD_MINSTEPS", 8);   // measured (tools/wgrad_small.py): 8 beats 1-4 and 16 on the 256-1200-token shapes
     if (chunks > pl.steps_total / min_steps) chunks = pl.steps_total / min_steps;
     if (chunks < 1) chunks = 1;
     pl.steps_per_chunk = pl.steps_total ? (pl.steps_total + chunks - 1) / chunks : 0;
@@ -418,7 +419,7 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
     if (pl.chunks > 0) {
         const int total = pl.chunks * pl.tiles;
         const int grid = ((total + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
-        static int dbg = getenv("RLIPV2_WGRAD_DBG") ? atoi(getenv("RLIPV2_WGRAD_DBG")) : 0;
+        static int dbg = msda::ablation_env("RLIPV2_WGRAD_DBG", 0);      // ablation builds only (skips work)
 #define LAUNCH(D) hipLaunchKernelGGL(wgrad_kernel<D>, dim3(grid), dim3(THREADS), LDS_BYTES, stream, dy16, x16, M, K, \
                                      pl.steps_total, pl.steps_per_chunk, pl.chunks, partial, db ? bias_partial : nullptr)
         switch (dbg) {

@@ -79,8 +79,15 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        # (the reference asserts sum(H*W) == Len_in on the device, a host sync per call
-        #  (ms_deform_attn.py:96); the HIP library validates shapes without one)
+        # reference ms_deform_attn.py:96 asserts sum(H*W) == Len_in with a device read-back on every call; here
+        # the check uses the host copy of the shapes (attached where the pyramid is built, else read back once
+        # per shapes tensor; skipped only while a HIP graph is being captured with nothing cached)
+        if input_spatial_shapes.is_cuda:
+            hs = msda.host_shapes(input_spatial_shapes)
+            if hs is not None:
+                assert sum(hs[2 * k] * hs[2 * k + 1] for k in range(len(hs) // 2)) == Len_in
+        else:
+            assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == Len_in
 
         value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:

@@ -30,6 +30,8 @@ _DTYPES = {torch.float32: _lib.MSDA_F32, torch.float64: _lib.MSDA_F64, torch.bfl
 # kernel override for benchmarks / tests ("auto" in product use)
 _variant_fwd = _lib.VARIANT_AUTO
 _variant_bwd = _lib.VARIANT_AUTO
+# name of the kernel variant the last call of each direction ran (read by bench.py's roofline line)
+last_variant = {}
 
 
 def set_variant(forward: str, backward: str = None) -> None:
@@ -116,11 +118,13 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
                                N, S, M, D, nL, Lq, P, out.data_ptr(), stream)
     if st:
         _raise(st)
+    last_variant["fwd"] = L.msda_variant_name(
+        _variant_fwd or L.msda_pick_variant(0, _DTYPES[value.dtype], N, S, M, D, nL, Lq, P)).decode()
     return out
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                            im2col_step):
+                            im2col_step, host=None):
     """Reference: ms_deform_attn_backward (vision.cpp:15) -> [grad_value, grad_sampling_loc, grad_attn_weight].
 
     With a host copy of the level shapes available (``host_shapes``) the library runs its destination-stationary
@@ -139,7 +143,9 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     go = grad_output if grad_output.dtype == value.dtype else grad_output.to(value.dtype)
     g_loc = torch.empty(sampling_loc.shape, dtype=aux, device=value.device)
     g_aw = torch.empty(attn_weight.shape, dtype=aux, device=value.device)
-    hs = host_shapes(spatial_shapes) if _variant_bwd in (_lib.VARIANT_AUTO, _lib.VARIANT_DEST) else None
+    hs = None
+    if _variant_bwd in (_lib.VARIANT_AUTO, _lib.VARIANT_DEST):
+        hs = host if host is not None else host_shapes(spatial_shapes)
     ws_bytes = 0
     if hs is not None:
         hs_arr = (ctypes.c_int64 * len(hs))(*hs)
@@ -167,6 +173,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                                     stream)
     if st:
         _raise(st)
+    last_variant["bwd"] = "dest" if ws_bytes else L.msda_variant_name(
+        _variant_bwd or L.msda_pick_variant(1, _DTYPES[value.dtype], N, S, M, D, nL, Lq, P)).decode()
     if g_value.dtype != value.dtype:
         g_value = g_value.to(value.dtype)
     if g_loc.dtype != sampling_loc.dtype:
@@ -187,6 +195,7 @@ class MSDeformAttnFunction(Function):
                                         attention_weights, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                               attention_weights)
+        ctx.host_shapes = host_shapes(value_spatial_shapes) if value.is_cuda else None
         return output
 
     @staticmethod
@@ -194,7 +203,7 @@ class MSDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, starts, loc, aw = ctx.saved_tensors
         g_value, g_loc, g_aw = ms_deform_attn_backward(value, shapes, starts, loc, aw, grad_output.contiguous(),
-                                                       ctx.im2col_step)
+                                                       ctx.im2col_step, host=ctx.host_shapes)
         return g_value, None, None, g_loc, g_aw, None
 
 
@@ -235,10 +244,11 @@ class SamplingGeometryFunction(Function):
         g_qproj = torch.empty_like(qproj)
         need_ref = ctx.needs_input_grad[1]
         g_ref = torch.empty_like(ref) if need_ref else None
+        gl, ga = g_loc.float().contiguous(), g_aw.float().contiguous()      # kept alive across the launch
         with torch.cuda.device(qproj.device):
             st = lib.msda_prepare_backward(_DTYPES[qproj.dtype], qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
                                            spatial_shapes.data_ptr(), aw.data_ptr(),
-                                           g_loc.float().contiguous().data_ptr(), g_aw.float().contiguous().data_ptr(),
+                                           gl.data_ptr(), ga.data_ptr(),
                                            N * Lq, M, L, P, g_qproj.data_ptr(),
                                            g_ref.data_ptr() if need_ref else None,
                                            torch.cuda.current_stream().cuda_stream)

@@ -27,6 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import normal_
 
+from .msda import attach_host_shapes
 from .alif import RLIPv2_VLFuse, RobertaLayer
 from .blocks import (MLP, FeatureResizer, MultiBranchFusion, NestedTensor, inverse_sigmoid,
                      nested_tensor_from_tensor_list)
@@ -148,6 +149,7 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
             cache = self.__dict__.setdefault("_shape_cache", {})
             if key not in cache:
                 sp = torch.as_tensor(shapes_list, dtype=torch.long, device=src_flatten.device)
+                attach_host_shapes(sp, shapes_list)      # the MSDA op sizes grids / checks sum(H*W) from the host copy
                 cache[key] = (sp, torch.cat((sp.new_zeros((1,)), sp.prod(1).cumsum(0)[:-1])))
             spatial_shapes, level_start_index = cache[key]
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)

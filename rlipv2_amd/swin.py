@@ -90,14 +90,15 @@ class WindowAttention(nn.Module):
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
     def bias(self, dtype):
-        """[heads, N, N] relative-position bias; cached while the (frozen) table is unchanged"""
+        """[heads, N, N] relative-position bias.  Cached ONLY for a frozen table (requires_grad False): a trainable
+        table is rewritten by the fused optimiser through raw pointers and by HIP-graph replays, neither of which
+        bumps `_version`, so a version-keyed cache would serve a stale bias to a later eval pass."""
         t = self.relative_position_bias_table
-        key = (t._version, t.data_ptr(), dtype, t.requires_grad and torch.is_grad_enabled())
-        if key[-1]:                                               # trainable table: no caching, keep the graph
-            n = self.ws * self.ws
+        n = self.ws * self.ws
+        if t.requires_grad:
             return t[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1).to(dtype)
+        key = (t._version, t.data_ptr(), dtype)
         if getattr(self, "_bias_key", None) != key:
-            n = self.ws * self.ws
             with torch.no_grad():
                 self._bias = t[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1).contiguous().to(dtype)
             self._bias_key = key

@@ -426,6 +426,7 @@ class MasterWeightAdamW:
 
     def __init__(self, model, lr=1.41e-4, lr_backbone=1.41e-5, text_encoder_lr=1.41e-5, weight_decay=1e-4):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
         self.master = [p.detach().float().clone().requires_grad_(True) for p in self.params]
         self.gbuf = [torch.zeros_like(m) for m in self.master]
@@ -456,6 +457,18 @@ class MasterWeightAdamW:
         if max_norm > 0:
             torch.nn.utils.clip_grad_norm_(self.master, max_norm, foreach=True)
         self.opt.step()
+        torch._foreach_copy_(self.params, self.master)
+
+    def state_dict(self):
+        return {"names": list(self.names), "master": [m.detach() for m in self.master], "opt": self.opt.state_dict()}
+
+    @torch.no_grad()
+    def load_state_dict(self, state):
+        if list(state["names"]) != self.names:
+            raise ValueError("optimizer state belongs to a different parameter set")
+        for m, s in zip(self.master, state["master"]):
+            m.copy_(s)
+        self.opt.load_state_dict(state["opt"])
         torch._foreach_copy_(self.params, self.master)
 
 

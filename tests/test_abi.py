@@ -133,3 +133,31 @@ def test_linear_wgrad_plan_and_cpu_behaviour():
     torch.testing.assert_close(linear.token_linear(x, w, None), torch.nn.functional.linear(x, w))
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         linear.linear_wgrad(torch.zeros(4, 128), torch.zeros(4, 128))
+
+
+def test_compat_shim_registers_reference_import_paths():
+    """The names unmodified reference code imports (ms_deform_attn_func.py:22, ParSetransformer.py:27,
+    dab_deformable/deformable_transformer.py:28) resolve to this package after compat.install()."""
+    import importlib
+    import sys
+    import rlipv2_amd.compat as compat
+    from rlipv2_amd import deform_attn
+    saved = {k: v for k, v in sys.modules.items() if k == "MultiScaleDeformableAttention" or k.startswith("models")}
+    try:
+        for k in saved:
+            del sys.modules[k]
+        compat.install()
+        MSDA = importlib.import_module("MultiScaleDeformableAttention")
+        assert MSDA.ms_deform_attn_forward is msda.ms_deform_attn_forward
+        assert MSDA.ms_deform_attn_backward is msda.ms_deform_attn_backward
+        for root in ("models.ops", "models.dab_deformable.ops"):
+            f = importlib.import_module(root + ".functions")
+            assert f.MSDeformAttnFunction is msda.MSDeformAttnFunction
+            m = importlib.import_module(root + ".modules")
+            assert m.MSDeformAttn is deform_attn.MSDeformAttn
+        with pytest.raises(RuntimeError, match="Not implemented on the CPU"):     # ms_deform_attn.h:54
+            MSDA.ms_deform_attn_forward(*_cpu_inputs(), 64)
+    finally:
+        for k in [k for k in sys.modules if k == "MultiScaleDeformableAttention" or k.startswith("models")]:
+            del sys.modules[k]
+        sys.modules.update(saved)

@@ -524,3 +524,41 @@ def test_swin_backbone_matches_reference():
     assert frozen and all(("norm" in n) or ("relative_position_bias_table" in n) for n in frozen)
     assert all(p.requires_grad for n, p in bb.body.named_parameters()
                if "norm" not in n and "relative_position_bias_table" not in n)
+
+
+def test_master_weight_checkpoint_resumes_bit_exactly(tmp_path):
+    """save -> resume with the master-weight optimiser: 'model' holds the float32 masters (the reference's
+    checkpoints are float32, main.py:599-629) and one more step after the resume equals one more step without it."""
+    from rlipv2_amd import checkpoint as CK, train
+    torch.manual_seed(0)
+
+    def make():
+        torch.manual_seed(1)
+        m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4)).to(torch.bfloat16)
+        return m, train.MasterWeightAdamW(m, lr=1e-2)
+
+    x, y = torch.randn(32, 8).bfloat16(), torch.randn(32, 4).bfloat16()
+
+    def step(m, opt):
+        opt.zero_grad()
+        ((m(x) - y).float() ** 2).mean().backward()
+        opt.step(0.1)
+
+    m1, o1 = make()
+    for _ in range(3):
+        step(m1, o1)
+    path = str(tmp_path / "ck.pth")
+    CK.save_checkpoint(path, m1, o1, epoch=1)
+    ck = torch.load(path, weights_only=False)
+    assert all(v.dtype == torch.float32 for v in ck["model"].values())
+    for n, mm in zip(o1.names, o1.master):
+        assert torch.equal(ck["model"][n], mm.detach())
+    step(m1, o1)
+    m2, o2 = make()
+    m2.load_state_dict({k: v.to(torch.bfloat16) for k, v in ck["model"].items()})
+    o2.load_state_dict(ck["optimizer"])
+    step(m2, o2)
+    for a, b in zip(o1.master, o2.master):
+        assert torch.equal(a, b)
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(a, b)

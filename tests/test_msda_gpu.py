@@ -451,3 +451,75 @@ def test_full_size_single_image_vs_oracle(dtype):
     close32(ga.cpu().numpy(), ref_ga)
     keep = ~kink_samples(dict(loc=loc, shapes=shapes))
     close32(gl.cpu().numpy()[keep], ref_gl[keep])
+
+
+@pytest.mark.parametrize("N", [2, 8])
+def test_full_size_other_batch_shapes(N):
+    """BASELINE configs 3 (batch 8 per GPU) and 4 (batch 2 per GPU) at the 800x1333 pyramid: product kernels against
+    the generic kernel, plus the adjoint identity <grad_out, J v> == <J^T grad_out, v> (size-independent)."""
+    from tools.msda_inputs import make_inputs
+    inp = make_inputs(N, mode="model", dtype=torch.bfloat16, device=DEV, seed=20 + N)
+    a = (inp["value"], inp["shapes"], inp["starts"], inp["loc"], inp["aw"])
+    out = msda.ms_deform_attn_forward(*a, 64).float()
+    gv, gl, ga = [t.float() for t in msda.ms_deform_attn_backward(*a, inp["grad_out"], 64)]
+    msda.set_variant("generic")
+    try:
+        out_g = msda.ms_deform_attn_forward(*a, 64).float()
+        gv_g, gl_g, ga_g = [t.float() for t in msda.ms_deform_attn_backward(*a, inp["grad_out"], 64)]
+    finally:
+        msda.set_variant("auto")
+    for name, x, y, tol in (("out", out, out_g, 2e-2), ("g_value", gv, gv_g, 4e-3), ("g_loc", gl, gl_g, 1e-4),
+                            ("g_aw", ga, ga_g, 1e-4)):
+        err = (x - y).abs().max().item() / max(1e-6, y.abs().max().item())
+        assert err <= tol, (name, err)
+    v2 = torch.randn_like(inp["value"])
+    lhs = (inp["grad_out"].double() * msda.ms_deform_attn_forward(v2, *a[1:], 64).double()).sum().item()
+    rhs = (gv.double() * v2.double()).sum().item()
+    assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1.0)          # bf16 outputs on both sides
+
+
+def test_reference_test_recipe_through_the_compat_shim():
+    """models/ops/test.py:25-64 (N1 M2 D2 Lq2 L2 P2, shapes (6,4),(3,2), value = rand * 0.01), run through the
+    import paths unmodified reference code uses: `MultiScaleDeformableAttention` and
+    `models.ops.functions.MSDeformAttnFunction`, against the oracle in double and float."""
+    import importlib
+    import sys
+    import rlipv2_amd.compat as compat
+    saved = {k: v for k, v in sys.modules.items() if k == "MultiScaleDeformableAttention" or k.startswith("models")}
+    try:
+        for k in saved:
+            del sys.modules[k]
+        compat.install()
+        F = importlib.import_module("models.ops.functions").MSDeformAttnFunction
+        MSDA = importlib.import_module("MultiScaleDeformableAttention")
+        torch.manual_seed(3)
+        N, M, D, Lq, L, P = 1, 2, 2, 2, 2, 2
+        shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long, device=DEV)
+        starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+        S = int(shapes.prod(1).sum())
+        value = torch.rand(N, S, M, D, device=DEV) * 0.01
+        loc = torch.rand(N, Lq, M, L, P, 2, device=DEV)
+        aw = torch.rand(N, Lq, M, L, P, device=DEV) + 1e-5
+        aw /= aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        for dt, tol in ((torch.float64, dict(rtol=1e-5, atol=1e-8)), (torch.float32, dict(rtol=1e-2, atol=1e-3))):
+            ref = O.forward_numpy(value.double().cpu().numpy(), shapes.cpu().numpy(), starts.cpu().numpy(),
+                                  loc.double().cpu().numpy(), aw.double().cpu().numpy())
+            got = F.apply(value.to(dt), shapes, starts, loc.to(dt), aw.to(dt), 2)
+            np.testing.assert_allclose(got.double().cpu().numpy(), ref, **tol)           # test.py:44 / :60
+            raw = MSDA.ms_deform_attn_forward(value.to(dt), shapes, starts, loc.to(dt), aw.to(dt), 2)
+            assert torch.equal(raw, got)
+    finally:
+        for k in [k for k in sys.modules if k == "MultiScaleDeformableAttention" or k.startswith("models")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_shapes_that_do_not_sum_to_len_in_are_rejected():
+    """reference ms_deform_attn.py:96 asserts sum(H*W) == Len_in; the op checks the host copy of the shapes."""
+    rng = np.random.default_rng(9)
+    value, shapes, starts, loc, aw, go = random_problem(rng, 1, [(8, 8), (4, 4), (2, 2), (1, 1)], 8, 32, 10, 4)
+    bad = shapes.copy()
+    bad[0, 0] = 9
+    v, l, a, g = _to_dev(value), _to_dev(loc), _to_dev(aw), _to_dev(go)
+    with pytest.raises(RuntimeError, match=r"sum\(H\*W\)"):
+        msda.ms_deform_attn_backward(v, _to_dev(bad), _to_dev(starts), l, a, g, 64)

@@ -148,12 +148,48 @@ def cpu_baseline(calls, scope="msda_step"):
             t_total += time.perf_counter() - t0
             del a, go
         images += 1
-    return {"value": round(images / t_total, 4), "unit": "images/s", "cores": O.threads(True), "kind": "port",
+    torch_path = cpu_baseline_torch(calls)
+    return {"torch_grid_sample": torch_path,
+            "value": round(images / t_total, 4), "unit": "images/s", "cores": O.threads(True), "kind": "port",
             "sample": "%d image(s) through all 12 fwd + 12 bwd MSDA calls of one step, float32, "
                       "oracle/msda_oracle.c built with OpenMP; %.1f s of CPU work%s" % (
                           images, t_total, "" if scope == "msda_step" else
                           "; covers ONLY the MSDeformAttn calls of the train step (the oracle restates that op; the "
                           "reference's dense blocks have no CPU port here), i.e. an upper bound on a CPU step rate")}
+
+
+def cpu_baseline_torch(calls):
+    """The reference's own CPU formulation (per-level F.grid_sample + autograd, ms_deform_attn_func.py:45-65), restated
+    in oracle/msda_oracle.py::forward_torch, timed on the host cores: forward + backward of ONE call of each kind
+    (encoder, ho-decoder, verb-decoder; one image, float32), weighted by the number of such calls in a step."""
+    from oracle import msda_oracle as O
+    nthreads = torch.get_num_threads()
+    kinds, t_kind, t_total = {}, {}, 0.0
+    for c in calls:
+        kinds.setdefault(c.name.rstrip("0123456789"), []).append(c)
+    for kind, cs in kinds.items():
+        i = cs[0].inp
+        shapes = [tuple(int(v) for v in hw) for hw in i["shapes"].cpu().tolist()]
+        best = None
+        for _ in range(2):                                   # second run: warm allocator / thread pool
+            value = i["value"][:1].float().cpu().requires_grad_(True)
+            loc = i["loc"][:1].float().cpu().requires_grad_(True)
+            aw = i["aw"][:1].float().cpu().requires_grad_(True)
+            go = i["grad_out"][:1].float().cpu()
+            t0 = time.perf_counter()
+            out = O.forward_torch(value, shapes, loc, aw)
+            out.backward(go.reshape(out.shape))
+            dt = time.perf_counter() - t0
+            t_total += dt
+            best = dt if best is None else min(best, dt)
+        t_kind[kind] = best
+    step_s = sum(t_kind[k] * len(cs) for k, cs in kinds.items())
+    return {"value": round(1.0 / step_s, 4), "unit": "images/s", "cores": nthreads, "kind": "port",
+            "sample": "forward + autograd backward of one call of each kind for ONE image (float32, per-level "
+                      "F.grid_sample restatement of the reference's CPU path, %d torch threads), weighted by the calls "
+                      "per step (%s); seconds per call: %s; %.1f s of CPU work" % (
+                          nthreads, ", ".join(f"{len(cs)} x {k}" for k, cs in kinds.items()),
+                          {k: round(v, 3) for k, v in t_kind.items()}, t_total)}
 
 
 class KernelTimer:
@@ -289,7 +325,16 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         torch.cuda.synchronize()
         timer.enabled = False
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    return elapsed, timer.summary(), float(loss), n_params, graphed
+    # step-level roofline: algorithmic bytes / matrix FLOPs of one eager step of the same model + batch
+    step_roofline = None
+    if rank == 0:
+        from rlipv2_amd import roofline
+        try:
+            step_roofline = roofline.probe(
+                lambda: train.train_step(eager_step, criterion, optimizer, batch, autocast_dtype=dtype))
+        except Exception as e:                                  # noqa: BLE001 -- accounting only, never fatal
+            print(f"[bench] step roofline probe failed: {type(e).__name__}: {e}", file=sys.stderr)
+    return elapsed, timer.summary(), float(loss), n_params, graphed, step_roofline
 
 
 def pmc_traffic(kernel_key, args):
@@ -302,7 +347,8 @@ def pmc_traffic(kernel_key, args):
     return json.load(open(path))["traffic_bytes_per_launch"].get(kernel_key)
 
 
-def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None):
+def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None,
+         step_roofline=None):
     probe_steps = args.steps if probe_steps is None else probe_steps
     dominant = max(kern, key=lambda n: kern[n]["ms"])
     kd = kern[dominant]
@@ -349,6 +395,21 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
                             for n, k in sorted(kern.items())},
         },
     }
+    if step_roofline is not None:
+        t_mem, t_mfma = step_roofline["T_mem_s"], step_roofline["T_mfma_s"]
+        step_s = elapsed / args.steps
+        line["step_roofline"] = {
+            "T_mem_ms": round(t_mem * 1e3, 3), "T_mfma_ms": round(t_mfma * 1e3, 3),
+            "bound": "hbm" if t_mem >= t_mfma else "mfma",
+            "achieved_frac_of_max": round(max(t_mem, t_mfma) / step_s, 4),
+            "algorithmic_GB_per_step": round(step_roofline["bytes"] / 1e9, 3),
+            "matrix_TFLOP_per_step": round(step_roofline["flops"] / 1e12, 3),
+            "achieved_TFLOPs": round(step_roofline["flops"] / step_s / 1e12, 1),
+            "peaks": {"hbm_GBps": HBM_PEAK_GBPS, "mfma_bf16_TFLOPs": 2500.0},
+            "note": "one eager step of the same model/batch under rlipv2_amd.roofline (ATen dispatch byte counter + "
+                    "FlopCounterMode + the library kernels' own operand accounting): inputs + outputs of every op "
+                    "once, in the step's dtypes; frac = max(T_mem, T_mfma) / measured ms_per_step",
+        }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
     print(json.dumps(line), flush=True)
@@ -399,7 +460,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     lib = _lib.lib()
     if args.workload == "train_step":
-        elapsed, kern, loss, n_params, graphed = run_train_step_bench(args, world, rank, local_rank, device)
+        elapsed, kern, loss, n_params, graphed, step_roofline = run_train_step_bench(args, world, rank, local_rank, device)
         if rank == 0:
             emit(args, world, elapsed, kern, lib, workload_text=(
                 "train_step: RLIP_ParSeDA_v2 " + {"resnet50": "R50", "swin_large": "Swin-L", "swin_tiny": "Swin-T"}[args.backbone]
@@ -417,7 +478,7 @@ def main():
                  probe_steps=2 if graphed else None,
                  probe_note=("HIP events around every MSDA call in 2 eager steps of the same train step run right after "
                              "the timed region (the timed steps replay HIP graphs, whose kernels cannot be bracketed)")
-                 if graphed else None)
+                 if graphed else None, step_roofline=step_roofline)
         if world > 1:
             dist.destroy_process_group()
         return

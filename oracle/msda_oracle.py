@@ -194,3 +194,31 @@ def backward_numpy(value, shapes, starts, loc, aw, grad_out):
             contrib = np.where(ok[k][..., None], (w[k] * a)[..., None] * go, 0)
             np.add.at(g_value, (n_i, idx[k], m_i), contrib)
     return g_value, g_loc, g_aw
+
+
+# --------------------------------------------------------------------------------------
+# PyTorch-CPU restatement: per-level grid_sample, the formulation of the reference's own CPU
+# path (models/ops/functions/ms_deform_attn_func.py:45-65).  Differentiable through autograd;
+# BASELINE.json asks for this path's time on the host cores as the CPU baseline.  It keeps a
+# zero-weight corner's location gradient at the exclusion boundary (tests/conftest.py), so
+# it is the timed baseline, the C port above stays the parity checker.
+# --------------------------------------------------------------------------------------
+def forward_torch(value, shapes, loc, aw):
+    """value [N,S,M,D], shapes [(H,W)...], loc [N,Lq,M,L,P,2] in [0,1], aw [N,Lq,M,L,P] (torch CPU tensors)
+    -> [N, Lq, M*D].  One bilinear, zero-padded, align_corners=False grid_sample per level."""
+    import torch
+    import torch.nn.functional as F
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    sizes = [int(h) * int(w) for h, w in shapes]
+    grid_all = loc * 2.0 - 1.0                                   # grid_sample's [-1, 1] convention
+    per_level = []
+    for lvl, (chunk, (H, W)) in enumerate(zip(value.split(sizes, dim=1), shapes)):
+        H, W = int(H), int(W)
+        img = chunk.permute(0, 2, 3, 1).reshape(N * M, D, H, W)                      # one image per (n, head)
+        grid = grid_all[:, :, :, lvl].permute(0, 2, 1, 3, 4).reshape(N * M, Lq, P, 2)
+        per_level.append(F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False))
+    sampled = torch.stack(per_level, dim=3).reshape(N * M, D, Lq, L * P)            # [N*M, D, Lq, L*P]
+    weights = aw.permute(0, 2, 1, 3, 4).reshape(N * M, 1, Lq, L * P)
+    out = (sampled * weights).sum(-1).reshape(N, M * D, Lq)
+    return out.transpose(1, 2).contiguous()

@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, roofline
 
 # rows below this go to the library (its weight-gradient GEMM is fine when the reduction is short)
 MIN_ROWS = 256
@@ -85,6 +85,7 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True, out_
                              torch.cuda.current_stream(dy.device).cuda_stream)
     if st:
         raise RuntimeError("linear_wgrad: " + _lib.strerror(st))
+    roofline.add(roofline.tensor_bytes(dy, x, dw, db), 2 * T * M * K)
     return dw, db
 
 
@@ -122,6 +123,7 @@ def expand_gemm(a: torch.Tensor, b: torch.Tensor, bias=None, mask=None, relu: bo
                                        torch.cuda.current_stream(a.device).cuda_stream)
     if st:
         raise RuntimeError(f"expand_gemm: {_lib.strerror(st)} (T={T} N={N} K={K})")
+    roofline.add(roofline.tensor_bytes(a2, b, bias, mask, c), 2 * T * N * K)
     return c.view(*a.shape[:-1], N)
 
 

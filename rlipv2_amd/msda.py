@@ -23,7 +23,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import _lib
+from . import _lib, roofline
 
 _DTYPES = {torch.float32: _lib.MSDA_F32, torch.float64: _lib.MSDA_F64, torch.bfloat16: _lib.MSDA_BF16}
 
@@ -118,6 +118,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
                                N, S, M, D, nL, Lq, P, out.data_ptr(), stream)
     if st:
         _raise(st)
+    roofline.add(_lib.algorithmic_bytes(_DTYPES[value.dtype], False, N, S, M, D, nL, Lq, P))
     last_variant["fwd"] = L.msda_variant_name(
         _variant_fwd or L.msda_pick_variant(0, _DTYPES[value.dtype], N, S, M, D, nL, Lq, P)).decode()
     return out
@@ -173,6 +174,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                                     stream)
     if st:
         _raise(st)
+    roofline.add(_lib.algorithmic_bytes(_DTYPES[value.dtype], True, N, S, M, D, nL, Lq, P)
+                 - (N * S * M * D * 2 if g_value.dtype == torch.bfloat16 else 0))
     last_variant["bwd"] = "dest" if ws_bytes else L.msda_variant_name(
         _variant_bwd or L.msda_pick_variant(1, _DTYPES[value.dtype], N, S, M, D, nL, Lq, P)).decode()
     if g_value.dtype != value.dtype:
@@ -229,6 +232,7 @@ class SamplingGeometryFunction(Function):
                                           torch.cuda.current_stream().cuda_stream)
         if st:
             _raise(st)
+        roofline.add(roofline.tensor_bytes(qproj, ref, loc, aw))
         ctx.save_for_backward(qproj, ref, spatial_shapes, aw)
         ctx.dims = (M, L, P)
         ctx.ref_dtype = reference_points.dtype
@@ -254,4 +258,5 @@ class SamplingGeometryFunction(Function):
                                            torch.cuda.current_stream().cuda_stream)
         if st:
             _raise(st)
+        roofline.add(roofline.tensor_bytes(qproj, ref, aw, gl, ga, g_qproj, g_ref))
         return g_qproj, (g_ref.to(ctx.ref_dtype) if need_ref else None), None, None, None, None

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, roofline
 
 MIN_ROWS = 4096
 enabled = True
@@ -61,6 +61,7 @@ class AddLayerNormFunction(torch.autograd.Function):
                                             bias.data_ptr(), rows, C, float(eps), y.data_ptr(), mean.data_ptr(),
                                             rstd.data_ptr(), torch.cuda.current_stream(a.device).cuda_stream),
                "add_layernorm_forward")
+        roofline.add(roofline.tensor_bytes(a, b, weight, bias, y, mean, rstd))
         ctx.save_for_backward(a, b, weight, mean, rstd)
         return y
 
@@ -81,6 +82,7 @@ class AddLayerNormFunction(torch.autograd.Function):
                                              dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
                                              ws.numel(), torch.cuda.current_stream(a.device).cuda_stream),
                "add_layernorm_backward")
+        roofline.add(roofline.tensor_bytes(dy, a, b, weight, mean, rstd, dx, dgamma, dbeta))
         return dx, (dx if b is not None else None), dgamma, dbeta, None
 
 

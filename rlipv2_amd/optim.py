@@ -10,7 +10,7 @@ import math
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, roofline
 
 
 def _same_layout(a, b):
@@ -133,6 +133,9 @@ class FusedMasterAdamW:
                                float(max_norm) if clip else 0.0, groups, len(pairs), stream)
         if st:
             raise RuntimeError("adamw_step: " + _lib.strerror(st))
+        # gradient (bf16) read twice (norm + update), master / two moments read + written (f32), bf16 parameter written
+        n = sum(self.params[i].numel() for i in idx)
+        roofline.add(n * (2 * (2 if clip else 1) + 3 * 8 + 2))
 
     def grad_norm(self):
         """sqrt of the squared-norm buffer of the last step (device tensor; no sync)."""

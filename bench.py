@@ -241,11 +241,21 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         torch.backends.cudnn.benchmark = True       # MIOpen Find on first use of every convolution shape
     torch.manual_seed(0 + rank)                                       # reference main.py:505
     model, criterion = train.build_training(margs, device=device, with_text_encoder=True, backbone_name=args.backbone)
-    batch = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=8, device=device, seed=rank)
+    sizes = [(800, 1333), (736, 1100)] if args.padded else None
     master = args.dtype == "bf16" and args.precision == "master"
     if master:      # bf16 parameters / activations / gradients, float32 master weights in the optimiser
         train.to_bf16(model)
-        batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def make_batch(triplets, seed):
+        b = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=triplets, device=device,
+                                  seed=seed, sizes=sizes)
+        if master:
+            b[0].tensors = b[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        return b
+
+    batch = make_batch(8, rank)
+    # variable-target variant: the batches of the timed loop rotate through three target counts
+    rotation = [batch] + ([make_batch(6, rank + 100), make_batch(11, rank + 200)] if args.var_targets else [])
     step_module = train.ParSeDATrainStep(model)
     model.train()
     dtype = torch.bfloat16 if (args.dtype == "bf16" and not master) else None
@@ -267,8 +277,13 @@ def run_train_step_bench(args, world, rank, local_rank, device):
                 train.freeze_parameters_without_gradient(step_module, criterion, batch)
             else:
                 synchronizer = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
-            step_module = train.graph_step_module(step_module, model, batch, synchronizer,
-                                                  criterion=criterion if args.graph_criterion else None)
+            if args.var_targets:
+                step_module = train.GraphedStepCache(step_module, model, synchronizer, criterion=criterion)
+                for b in rotation:
+                    step_module.get(b)                          # capture every bucket before the timed region
+            else:
+                step_module = train.graph_step_module(step_module, model, batch, synchronizer,
+                                                      criterion=criterion if args.graph_criterion else None)
             graphed = True
         except Exception as e:                                  # noqa: BLE001 -- fall back to eager, say so
             import traceback
@@ -291,8 +306,9 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         eager_step = step_module
     optimizer = train.FusedMasterAdamW(model) if master else train.build_optimizer(model)
     timer = KernelTimer()
-    for _ in range(args.warmup):
-        train.train_step(step_module, criterion, optimizer, batch, autocast_dtype=dtype)
+    guard = train.NonFiniteGuard()                       # engine.py:123-128, without a sync of its own
+    for k in range(args.warmup):
+        train.train_step(step_module, criterion, optimizer, rotation[k % len(rotation)], autocast_dtype=dtype, guard=guard)
 
     def barrier():
         if world > 1:
@@ -302,10 +318,12 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     barrier()
     timer.enabled = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train.train_step(step_module, criterion, optimizer, batch, autocast_dtype=dtype)
+    for k in range(args.steps):
+        loss = train.train_step(step_module, criterion, optimizer, rotation[k % len(rotation)], autocast_dtype=dtype,
+                                guard=guard)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    guard.check(wait=True)
     timer.enabled = False
     barrier()
     if world > 1:
@@ -433,6 +451,10 @@ def main():
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--padded", action="store_true",
+                    help="non-best-case variant: images of (800,1333) and (736,1100) padded into one batch, mask path live")
+    ap.add_argument("--var-targets", action="store_true",
+                    help="non-best-case variant: 6 / 8 / 11 triplets per image in rotation (one graph capture per bucket)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -470,7 +492,10 @@ def main():
                 "final loss %.4f" % (args.queries, args.batch,
                                      ("bf16 parameters/activations/gradients with float32 master weights" if args.precision == "master"
                                       else "bf16 autocast over float32 weights") if args.dtype == "bf16" else "float32",
-                                     n_params / 1e6, loss)),
+                                     n_params / 1e6, loss)
+                + ("; VARIANT padded batch: images of 800x1333 and 736x1100 padded together, padding masks live" if args.padded else "")
+                + ("; VARIANT variable targets: 8 / 6 / 11 triplets per image in rotation, one graph capture per bucket" if args.var_targets else "")
+                + ("; VARIANT eager launches (no HIP graphs)" if not args.graph else "")),
                  parallelism=(f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
                               "model forward/backward replayed as HIP graphs" if graphed else
                               f"dp{world} (DDP: bucketed RCCL gradient all-reduce overlapped with backward); eager launches"),

@@ -250,6 +250,83 @@ class GraphedStep:
         return self.loss_dict, self.total
 
 
+class GraphedStepCache:
+    """One GraphedStep per batch bucket.  A capture is specific to the image tensor's shape, the padding hint and the
+    number of targets per image (the matched-index tensor's shape); the reference pads every batch to its own maximum
+    and has a variable number of triplets per image (util/misc.py:299-320, datasets/vg.py), so a training run meets a
+    handful of buckets.  A batch of a new bucket is captured on first sight (a few eager warm-up steps + two
+    captures), afterwards replayed; `max_buckets` bounds the memory held by captures (least recently used goes)."""
+
+    def __init__(self, step_module, model, synchronizer=None, criterion=None, max_buckets=8):
+        self.step_module, self.model = step_module, model
+        self.synchronizer, self.criterion = synchronizer, criterion
+        self.max_buckets = max_buckets
+        self.graphs = {}                    # key -> GraphedStep (insertion order = recency)
+        self.captures = 0
+
+    @staticmethod
+    def bucket(batch):
+        samples, text, targets = batch
+        return (tuple(samples.tensors.shape), str(samples.tensors.dtype), bool(getattr(samples, "no_padding", False)),
+                tuple(text["input_ids"].shape), tuple(len(t["obj_labels"]) for t in targets))
+
+    def get(self, batch):
+        key = self.bucket(batch)
+        g = self.graphs.pop(key, None)
+        if g is None:
+            if len(self.graphs) >= self.max_buckets:
+                self.graphs.pop(next(iter(self.graphs)))
+            g = GraphedStep(self.step_module, self.model, batch, synchronizer=self.synchronizer,
+                            criterion=self.criterion)
+            self.captures += 1
+        self.graphs[key] = g
+        return g
+
+    def parameters(self):
+        return self.step_module.parameters()
+
+
+class NonFiniteLoss(FloatingPointError):
+    pass
+
+
+class NonFiniteGuard:
+    """The reference stops training on a non-finite loss (engine.py:123-128: `if not math.isfinite(loss_value)`:
+    print the loss dict, exit) -- with a `.item()` sync every step.  Here the check rides along without a sync of its
+    own: each step enqueues `isfinite(loss)` into a pinned byte (asynchronous copy + event); the NEXT step, whose
+    matcher copy has synchronised the stream anyway, reads the byte and raises NonFiniteLoss.  Detection is one step
+    late; the optimiser update of the bad step has then been applied, exactly as in the reference's ordering the
+    update is skipped only because the process exits."""
+
+    def __init__(self):
+        self.flag = None
+        self.event = None
+        self.step = 0
+
+    def submit(self, loss):
+        self.check()
+        if loss.is_cuda:
+            if self.flag is None:
+                self.flag = torch.ones(1, dtype=torch.uint8, pin_memory=True)
+                self.event = torch.cuda.Event()
+            self.flag.copy_(torch.isfinite(loss.detach()).reshape(1).to(torch.uint8), non_blocking=True)
+            self.event.record()
+            self.pending = True
+        else:
+            if not bool(torch.isfinite(loss.detach()).all()):
+                raise NonFiniteLoss(f"loss is {float(loss)} at step {self.step}, stopping training")
+        self.step += 1
+
+    def check(self, wait=False):
+        if getattr(self, "pending", False):
+            if wait:
+                self.event.synchronize()
+            if self.event.query():
+                self.pending = False
+                if int(self.flag[0]) == 0:
+                    raise NonFiniteLoss(f"loss was not finite at step {self.step - 1}, stopping training")
+
+
 def graph_step_module(step_module, model, batch, synchronizer=None, criterion=None):
     """Capture `step_module` (both model phases, forward and backward) for the shapes of `batch`; returns a
     GraphedStep.  Raises if capture is not possible.  `synchronizer`: a GradientSynchronizer for data-parallel
@@ -481,7 +558,7 @@ def to_bf16(model):
 
 
 def synthetic_batch(batch, height=800, width=1333, n_obj=43, n_verb=21, triplets=8, token_len=5, device="cuda:0",
-                    seed=0):
+                    seed=0, sizes=None):
     """images ~ N(0,1) (post-normalisation), no padding; 43 object labels (last = "no
     objects") + 21 relation labels = 64 texts as seeded token ids of length 5; 8 triplets per image."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -500,19 +577,33 @@ def synthetic_batch(batch, height=800, width=1333, n_obj=43, n_verb=21, triplets
         wh2 = torch.rand(triplets, 2, generator=g) * 0.35 + 0.05
         verbs = torch.zeros(triplets, n_verb)
         verbs[torch.arange(triplets), torch.randint(0, n_verb, (triplets,), generator=g)] = 1
-        verbs[torch.arange(0, triplets, 2), torch.randint(0, n_verb, (triplets // 2,), generator=g)] = 1
+        verbs[torch.arange(0, triplets, 2), torch.randint(0, n_verb, ((triplets + 1) // 2,), generator=g)] = 1
         targets.append({"sub_labels": torch.randint(0, n_obj - 1, (triplets,), generator=g).to(device),
                         "obj_labels": torch.randint(0, n_obj - 1, (triplets,), generator=g).to(device),
                         "verb_labels": verbs.to(device),
                         "sub_boxes": torch.cat([c, wh], 1).to(device), "obj_boxes": torch.cat([c2, wh2], 1).to(device)})
+    if sizes is not None:
+        # padded variant (sizes (800,1333) and (736,1100) in one batch): image k has size
+        # sizes[k % len(sizes)], zero-padded to (height, width), mask True on the padding -- the reference's
+        # nested_tensor_from_tensor_list (util/misc.py:299-320)
+        for k in range(batch):
+            h, w = sizes[k % len(sizes)]
+            images[k, :, h:, :] = 0
+            images[k, :, :, w:] = 0
+            mask[k, h:, :] = True
+            mask[k, :, w:] = True
+        return NestedTensor(images, mask, no_padding=all(tuple(s) == (height, width) for s in sizes)), text, targets
     return NestedTensor(images, mask, no_padding=True), text, targets
 
 
-def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_dtype=torch.bfloat16):
+def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_dtype=torch.bfloat16, guard=None):
     """One optimisation step; returns the (device) loss.  No host synchronisation except the
     matcher's single device->host copy of the cost matrices.  `autocast_dtype=None` runs the model
-    in whatever dtype its parameters have (float32, or bfloat16 with MasterWeightAdamW)."""
+    in whatever dtype its parameters have (float32, or bfloat16 with MasterWeightAdamW).  `guard`: a
+    NonFiniteGuard (raises NonFiniteLoss one step after a non-finite loss, engine.py:123-128)."""
     samples, text, targets = batch
+    if isinstance(step_module, GraphedStepCache):
+        step_module = step_module.get(batch)                # capture on first sight of a bucket, replay afterwards
     if isinstance(step_module, GraphedStep) and step_module.criterion is not None:
         optimizer.zero_grad(set_to_none=True)
         _, loss = step_module.run(samples, text, targets)
@@ -532,4 +623,6 @@ def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_
             params = [p for g in optimizer.param_groups for p in g["params"]]
             torch.nn.utils.clip_grad_norm_(params, max_norm, foreach=True)
         optimizer.step()
+    if guard is not None:
+        guard.submit(loss)
     return loss.detach()

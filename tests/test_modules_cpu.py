@@ -562,3 +562,15 @@ def test_master_weight_checkpoint_resumes_bit_exactly(tmp_path):
         assert torch.equal(a, b)
     for a, b in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(a, b)
+
+
+def test_non_finite_loss_stops_training():
+    """engine.py:123-128: a non-finite loss ends the run.  CPU tensors are checked at once; device tensors one step
+    late through a pinned flag (tests/test_modules_gpu.py)."""
+    from rlipv2_amd import train
+    guard = train.NonFiniteGuard()
+    guard.submit(torch.tensor(1.5))
+    with pytest.raises(train.NonFiniteLoss):
+        guard.submit(torch.tensor(float("nan")))
+    with pytest.raises(train.NonFiniteLoss):
+        train.NonFiniteGuard().submit(torch.tensor(float("inf")))

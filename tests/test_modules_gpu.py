@@ -392,3 +392,52 @@ def test_swin_large_small_train_step_smoke():
             if k in n and float(p.grad.abs().max()) > 0:
                 seen[k] += 1
     assert all(v > 0 for v in seen.values()), seen
+
+
+def test_non_finite_guard_raises_one_step_late_without_sync():
+    from rlipv2_amd import train
+    guard = train.NonFiniteGuard()
+    guard.submit(torch.tensor(2.0, device=DEV))
+    guard.submit(torch.tensor(float("nan"), device=DEV))     # the previous (finite) step is checked here
+    torch.cuda.synchronize()
+    with pytest.raises(train.NonFiniteLoss):
+        guard.submit(torch.tensor(1.0, device=DEV))
+    with pytest.raises(train.NonFiniteLoss):
+        g2 = train.NonFiniteGuard()
+        g2.submit(torch.tensor(float("inf"), device=DEV))
+        g2.check(wait=True)
+
+
+def test_graphed_step_cache_recaptures_per_bucket():
+    """A second bucket (other target counts, padded batch) is captured on first sight instead of raising; replays of
+    either bucket give the loss of the eager step on the same batch."""
+    from rlipv2_amd import train
+    torch.manual_seed(0)
+    margs = parseda.default_args(num_queries=40)
+    model, criterion = train.build_training(margs, device=DEV, with_text_encoder=True)
+    train.to_bf16(model)
+    step = train.ParSeDATrainStep(model)
+    model.train()
+    for mod in model.modules():                                  # dropout off: eager and replay must agree
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+
+    def make(triplets, pad, seed):
+        b = train.synthetic_batch(2, 256, 320, n_obj=13, n_verb=7, triplets=triplets, device=DEV, seed=seed)
+        b[0].tensors = b[0].tensors.to(torch.bfloat16)
+        if pad:
+            b[0].mask[1, :, 280:] = True
+            b[0].tensors[1, :, :, 280:] = 0
+            b[0].no_padding = False
+        return b
+
+    train.freeze_parameters_without_gradient(step, criterion, make(3, False, 0))
+    cache = train.GraphedStepCache(step, model, criterion=criterion)
+    for batch in (make(3, False, 0), make(5, True, 1), make(3, False, 2), make(5, True, 3)):
+        with torch.no_grad():
+            eager = criterion.weighted_sum(criterion(step(*batch), batch[2])).float()
+        torch.cuda.synchronize()
+        g = cache.get(batch)
+        _, total = g.run(*batch)
+        torch.testing.assert_close(total.float(), eager, rtol=3e-2, atol=3e-2)
+    assert cache.captures == 2 and len(cache.graphs) == 2

@@ -127,6 +127,29 @@ def run_step(calls, lib, stream, timed):
         c.backward(lib, stream, timed)
 
 
+def b0_signature_kernels(batch, dtype, device, iters=10):
+    """The B0-signature kernels (float32 sampling_loc / attn_weight operands, msda_forward / msda_backward_ws) at the
+    encoder shape on synthetic model-like inputs: HIP events on the launch stream, mean of `iters` launches.  Reported
+    next to the fused kernels the train step actually runs (both lines)."""
+    lib = _lib.lib()
+    call = MsdaCall("enc", batch, None, "model", dtype, 7, device)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        call.forward(lib, stream, False)
+        call.backward(lib, stream, False)
+    for _ in range(iters):
+        call.forward(lib, stream, True)
+    for _ in range(iters):
+        call.backward(lib, stream, True)
+    torch.cuda.synchronize()
+    res = {}
+    for d, nbytes in (("fwd", call.bytes_fwd), ("bwd", call.bytes_bwd)):
+        us = sum(a.elapsed_time(b) for a, b in call.ev[d]) / len(call.ev[d]) * 1e3
+        res[f"enc_{d}"] = {"mean_us": round(us, 2), "algorithmic_bytes_per_launch": nbytes,
+                           "GBps": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4)}
+    return res
+
+
 def cpu_baseline(calls, scope="msda_step"):
     """Oracle (OpenMP C port) on whole images through all 24 MSDA calls of a step."""
     import numpy as np
@@ -203,6 +226,31 @@ class KernelTimer:
         self._fwd, self._bwd = msda.ms_deform_attn_forward, msda.ms_deform_attn_backward
         msda.ms_deform_attn_forward = self._wrap(self._fwd, "fwd")
         msda.ms_deform_attn_backward = self._wrap(self._bwd, "bwd")
+        # the fused geometry + sampling entry points (what the module calls when the reference points need no gradient)
+        msda.ms_deform_attn_fused_forward = self._wrap_fused(msda.ms_deform_attn_fused_forward, "fwd")
+        msda.ms_deform_attn_fused_backward = self._wrap_fused(msda.ms_deform_attn_fused_backward, "bwd")
+
+    def _wrap_fused(self, fn, direction):
+        def timed(value, shapes, starts, *rest):
+            if not self.enabled:
+                return fn(value, shapes, starts, *rest)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(value, shapes, starts, *rest)
+            b.record()
+            N, S, M, D = value.shape
+            code = _lib.MSDA_BF16 if value.dtype == torch.bfloat16 else _lib.MSDA_F32
+            if direction == "fwd":       # (value, shapes, starts, qproj, ref, save) -> (out, loc, aw)
+                Lq = rest[0].shape[1]
+                moved = [value, rest[0], rest[1], *[t for t in out if t is not None]]
+            else:                        # (value, shapes, starts, loc, aw, ref, grad_out, host) -> [g_value, g_qproj]
+                Lq = rest[0].shape[1]
+                moved = [value, rest[0], rest[1], rest[2], rest[3], *out]
+            nbytes = sum(t.numel() * t.element_size() for t in moved)
+            dims = (N, S, M, D, shapes.shape[0], Lq, 4)
+            self.records.append((direction, dims, code, a, b, nbytes, self.msda.last_variant.get(direction), True))
+            return out
+        return timed
 
     def _wrap(self, fn, direction):
         def timed(value, shapes, starts, loc, aw, *rest, **kw):
@@ -218,17 +266,20 @@ class KernelTimer:
             # grad_value written directly as bfloat16 (destination-stationary backward): 2 bytes per element less
             # than the float32 grad_value msda_algorithmic_bytes assumes
             saved = N * S * M * D * 2 if (direction == "bwd" and out[0].dtype == torch.bfloat16) else 0
-            self.records.append((direction, dims, code, a, b, saved, self.msda.last_variant.get(direction)))
+            self.records.append((direction, dims, code, a, b, saved, self.msda.last_variant.get(direction), False))
             return out
         return timed
 
     def summary(self):
         kern = {}
-        for direction, dims, code, a, b, saved, variant in self.records:
+        for direction, dims, code, a, b, saved, variant, fused in self.records:
             kind = "enc" if dims[5] == dims[1] else f"dec{dims[5]}"
-            k = kern.setdefault(f"{kind}_{direction}", {"ms": 0.0, "n": 0, "dims": dims, "code": code,
-                                                         "bwd": direction == "bwd", "variant": variant,
-                                                         "bytes": _lib.algorithmic_bytes(code, direction == "bwd", *dims) - saved})
+            # B0-signature calls: algorithmic bytes of SURVEY.md 8d; fused calls: the operands they actually take
+            # (raw projection rows instead of float32 locations / weights), each tensor once
+            nbytes = saved if fused else _lib.algorithmic_bytes(code, direction == "bwd", *dims) - saved
+            k = kern.setdefault(f"{kind}_{direction}" + ("_fused" if fused else ""),
+                                {"ms": 0.0, "n": 0, "dims": dims, "code": code, "bwd": direction == "bwd",
+                                 "variant": variant, "bytes": nbytes})
             k["ms"] += a.elapsed_time(b)
             k["n"] += 1
         return kern
@@ -366,7 +417,7 @@ def pmc_traffic(kernel_key, args):
 
 
 def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None,
-         step_roofline=None):
+         step_roofline=None, b0=None):
     probe_steps = args.steps if probe_steps is None else probe_steps
     dominant = max(kern, key=lambda n: kern[n]["ms"])
     kd = kern[dominant]
@@ -413,6 +464,8 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
                             for n, k in sorted(kern.items())},
         },
     }
+    if b0 is not None:
+        line["roofline"]["b0_signature_kernels"] = b0
     if step_roofline is not None:
         t_mem, t_mfma = step_roofline["T_mem_s"], step_roofline["T_mfma_s"]
         step_s = elapsed / args.steps
@@ -503,7 +556,8 @@ def main():
                  probe_steps=2 if graphed else None,
                  probe_note=("HIP events around every MSDA call in 2 eager steps of the same train step run right after "
                              "the timed region (the timed steps replay HIP graphs, whose kernels cannot be bracketed)")
-                 if graphed else None, step_roofline=step_roofline)
+                 if graphed else None, step_roofline=step_roofline,
+                 b0=b0_signature_kernels(args.batch, dtype, device) if args.backbone == "resnet50" else None)
         if world > 1:
             dist.destroy_process_group()
         return

@@ -152,6 +152,32 @@ int msda_prepare_backward(int qdtype, const void *qproj, const float *ref, int r
                           const float *attn_weight, const float *grad_sampling_loc, const float *grad_attn_weight,
                           int R, int M, int L, int P, void *grad_qproj, float *grad_ref, void *stream);
 
+/* MSDeformAttn's sampling geometry AND the sampling + aggregation in one launch each way (reference
+ * models/ops/modules/ms_deform_attn.py:101-117: the view / softmax / normalise / add chain feeding
+ * MSDeformAttnFunction.apply): the forward reads the raw projection rows qproj [N*Lq, M*L*P*3] (value's dtype;
+ * offsets then logits, the layout of msda_prepare_forward) and ref [N*Lq, L, refdim] instead of float32
+ * sampling_loc / attn_weight; loc_save / aw_save (both or neither) receive the float32 locations / weights for a
+ * later backward pass.  The backward takes those two tensors back and writes grad_value and the gradient of qproj
+ * (value's dtype) -- grad_sampling_loc / grad_attn_weight never reach memory; the reference points get no gradient
+ * here (callers that need one use msda_prepare_backward).  D = 32, L = P = 4, MSDA_F32 / MSDA_BF16.
+ * msda_fused_supported: 0 = no, 1 = forward only, 2 = forward and backward (needs the host copy of the shapes:
+ * grad_value comes from the destination-stationary pass, workspace of msda_backward_workspace_bytes). */
+int msda_fused_supported(int dtype, const int64_t *spatial_shapes_host, int refdim,
+                         int N, int S, int M, int D, int L, int Lq, int P);
+int msda_fused_forward(int dtype,
+                       const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                       const void *qproj, const float *ref, int refdim,
+                       int N, int S, int M, int D, int L, int Lq, int P,
+                       void *out, float *loc_save, float *aw_save, void *stream);
+int msda_fused_backward_ws(int flags, int dtype,
+                           const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                           const int64_t *spatial_shapes_host,
+                           const void *sampling_loc, const void *attn_weight, const float *ref, int refdim,
+                           const void *grad_out,
+                           int N, int S, int M, int D, int L, int Lq, int P,
+                           void *grad_value, void *grad_qproj,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* The reference's batch-chunking precondition (cuda/ms_deform_attn_cuda.cu:50-52). */
 int msda_check_im2col_step(int batch, int im2col_step);
 

@@ -267,6 +267,69 @@ int msda_backward_ws(int variant, int dtype, const void *value, const int64_t *s
                             M, D, L, Lq, P, grad_value, grad_sampling_loc, grad_attn_weight, stream);
 }
 
+int msda_fused_supported(int dtype, const int64_t *spatial_shapes_host, int refdim, int N, int S, int M, int D, int L,
+                         int Lq, int P)
+{
+    if (validate(dtype, N, S, M, D, L, Lq, P) != MSDA_OK) return 0;
+    if (dtype != MSDA_F32 && dtype != MSDA_BF16) return 0;
+    if (refdim != 2 && refdim != 4) return 0;
+    if ((long)N * S * M * D == 0 || (long)N * Lq * M * L * P == 0) return 0;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    if (!quad_supports(p)) return 0;
+    if (!spatial_shapes_host) return 1;                     // forward only
+    return dest_supports(p, spatial_shapes_host) ? 2 : 1;   // 2: the fused backward is available as well
+}
+
+int msda_fused_forward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                       const void *qproj, const float *ref, int refdim, int N, int S, int M, int D, int L, int Lq, int P,
+                       void *out, float *loc_save, float *aw_save, void *stream)
+{
+    if (!msda_fused_supported(dtype, nullptr, refdim, N, S, M, D, L, Lq, P)) return MSDA_ERR_BAD_VARIANT;
+    if (!value || !spatial_shapes || !level_start || !qproj || !ref || !out) return MSDA_ERR_NULL_POINTER;
+    if ((loc_save == nullptr) != (aw_save == nullptr)) return MSDA_ERR_NULL_POINTER;
+    if ((long)N * Lq * M >= (1L << 31) / 64) return MSDA_ERR_BAD_SHAPE;
+    if (!(aligned16(value) && aligned16(qproj) && aligned16(ref) && aligned16(out) && aligned16(loc_save) &&
+          aligned16(aw_save)))
+        return MSDA_ERR_ALIGNMENT;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.out = out; p.stream = (hipStream_t)stream;
+    Fused f{};
+    f.qproj = qproj; f.ref = ref; f.refdim = refdim; f.loc_save = loc_save; f.aw_save = aw_save;
+    (void)hipGetLastError();
+    launch_quad_forward_fused(p, f);
+    return finish_launch();
+}
+
+int msda_fused_backward_ws(int flags, int dtype, const void *value, const int64_t *spatial_shapes,
+                           const int64_t *level_start, const int64_t *spatial_shapes_host, const void *sampling_loc,
+                           const void *attn_weight, const float *ref, int refdim, const void *grad_out, int N, int S,
+                           int M, int D, int L, int Lq, int P, void *grad_value, void *grad_qproj, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
+    if (msda_fused_supported(dtype, spatial_shapes_host, refdim, N, S, M, D, L, Lq, P) != 2) return MSDA_ERR_BAD_VARIANT;
+    const bool out_bf16 = (flags & MSDA_FLAG_GRAD_VALUE_BF16) != 0;
+    if (out_bf16 && dtype != MSDA_BF16) return MSDA_ERR_BAD_VARIANT;
+    if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !ref || !grad_out || !grad_value ||
+        !grad_qproj || !workspace)
+        return MSDA_ERR_NULL_POINTER;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.loc = sampling_loc; p.aw = attn_weight;
+    p.grad_out = grad_out; p.g_value = grad_value; p.stream = (hipStream_t)stream;
+    if (workspace_bytes < dest_workspace_bytes(p, spatial_shapes_host)) return MSDA_ERR_BAD_SHAPE;
+    if (!(aligned16(value) && aligned16(sampling_loc) && aligned16(attn_weight) && aligned16(grad_out) &&
+          aligned16(grad_value) && aligned16(grad_qproj) && aligned16(ref) && aligned16(workspace)))
+        return MSDA_ERR_ALIGNMENT;
+    Fused f{};
+    f.ref = ref; f.refdim = refdim; f.g_qproj = grad_qproj;
+    (void)hipGetLastError();
+    launch_quad_backward_reduce_fused(p, f);                            // grad of the projection row
+    launch_dest_scatter(p, spatial_shapes_host, workspace, out_bf16);   // grad_value, every row written once
+    return finish_launch();
+}
+
 int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
                  const void *sampling_loc, const void *attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
                  void *out, void *stream)

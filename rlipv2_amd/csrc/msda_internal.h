@@ -43,6 +43,16 @@ struct Problem {
     hipStream_t stream;
 };
 
+// operands of the fused sampling-geometry entry points (msda_fused_forward / msda_fused_backward_ws)
+struct Fused {
+    const void *qproj;      // [N*Lq, M*L*P*3] in value's dtype: offsets then logits
+    const float *ref;       // [N*Lq, L, refdim]
+    int refdim;             // 2 or 4
+    float *loc_save;        // forward: float32 sampling_loc / attn_weight written for the backward pass (or NULL)
+    float *aw_save;
+    void *g_qproj;          // backward: gradient of qproj
+};
+
 // each launcher enqueues on p.stream and returns; the caller checks hipGetLastError()
 void launch_generic_forward(const Problem &p);
 void launch_generic_backward(const Problem &p);
@@ -52,6 +62,8 @@ void launch_quad_forward(const Problem &p);
 void launch_quad_backward(const Problem &p);
 void launch_quad_backward_reduce(const Problem &p);   // grad_loc / grad_aw only (no grad_value)
 void launch_tile_forward(const Problem &p);           // window-staged forward (Lq == S)
+void launch_quad_forward_fused(const Problem &p, const Fused &f);
+void launch_quad_backward_reduce_fused(const Problem &p, const Fused &f);   // writes f.g_qproj instead of g_loc / g_aw
 
 bool window_supports(const Problem &p, bool backward);
 void launch_window_forward(const Problem &p);

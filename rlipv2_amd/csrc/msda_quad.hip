@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "msda_device.h"
+#include "msda_geometry.h"
 #include "msda_internal.h"
 
 namespace msda {
@@ -189,6 +190,53 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_forward_kernel(
         if (FENCE <= 2) __builtin_amdgcn_sched_barrier(0);
         fwd_sample<VT>(vr, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, row_bytes, lane_byte, acc);
         if (FENCE == 1) __builtin_amdgcn_sched_barrier(0);
+        fwd_sample<VT>(vr, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, row_bytes, lane_byte, acc);
+        quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
+    }
+    if (live) Vec8<VT>::store(out + (long)qm * kD + sub * 8, acc);
+}
+
+// The direct-gather forward with the module's sampling geometry as its prologue (ms_deform_attn.py:101-112 +
+// :116-117 in one launch): reads the raw projection row [offsets | logits] (48 values per head, in value's
+// dtype) and the reference points instead of float32 sampling_loc / attn_weight -- 96 B instead of 192 B per
+// (query, head) for bfloat16 -- and, when a backward pass will follow (SAVE), writes the float32 locations /
+// weights it computed for that pass.  Quad lane j = level j in both the geometry and the gather loop.
+template <typename VT, int REFDIM, bool SAVE, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void quad_forward_fused_kernel(
+    const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const VT *__restrict__ qproj, const float *__restrict__ ref, int total_qm, int S, int M, int Lq,
+    unsigned value_bytes, VT *__restrict__ out, float *__restrict__ loc_save, float *__restrict__ aw_save)
+{
+    const int t = xcd_block_id() * kBlock + threadIdx.x;
+    int qm = t >> 2;
+    const int sub = t & 3;
+    const bool live = qm < total_qm;
+    qm = live ? qm : total_qm - 1;   // keep whole quads converged for the DPP broadcasts
+    const int m = qm % M;
+    const int row = qm / M;          // n * Lq + q
+    const int n = row / Lq;
+    const int row_bytes = M * kD * (int)sizeof(VT);
+    const unsigned lane_byte = (unsigned)n * (unsigned)S * (unsigned)row_bytes
+                               + (unsigned)(m * kD + sub * 8) * (unsigned)sizeof(VT);
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)value, 0, value_bytes, 0x00020000);
+    float o[8], w[4];
+    geom::forward<VT, REFDIM>(qproj + (long)row * (M * 48), ref + (long)row * (kL * REFDIM), shapes, m, M, sub, o, w);
+    float4 la = make_float4(o[0], o[1], o[2], o[3]), lb = make_float4(o[4], o[5], o[6], o[7]);
+    float4 wa = make_float4(w[0], w[1], w[2], w[3]);
+    if (SAVE && live) {
+        float4 *loc4 = reinterpret_cast<float4 *>(loc_save) + (long)qm * 8 + sub * 2;
+        loc4[0] = la;
+        loc4[1] = lb;
+        reinterpret_cast<float4 *>(aw_save)[(long)qm * 4 + sub] = wa;
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int l = 0; l < kL; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
+        fwd_sample<VT>(vr, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start, row_bytes, lane_byte, acc);
+        fwd_sample<VT>(vr, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start, row_bytes, lane_byte, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        fwd_sample<VT>(vr, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, row_bytes, lane_byte, acc);
         fwd_sample<VT>(vr, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, row_bytes, lane_byte, acc);
         quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
     }
@@ -584,11 +632,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_kernel(
 // with DPP broadcasts, all four lanes take part in the channel dot products (8 channels each + quad reduction),
 // and lane p turns the four reduced dots of ITS sample into (g_x, g_y, g_aw).  PMC on the kernel above: VALU
 // busy 75 % of the kernel time with ~45 of ~150 instructions per sample being the replicated geometry.
-template <typename VT, int WAVES>
+//
+// REFDIM != 0: the backward of the module's sampling geometry runs as the epilogue (softmax backward over the quad,
+// offset scaling; msda_geometry.h) and the kernel writes the gradient of the raw projection row [offsets | logits]
+// in value's dtype -- grad_sampling_loc / grad_attn_weight (192 B per (query, head), float32) never reach memory.
+template <typename VT, int WAVES, int REFDIM>
 __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_shared_kernel(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ aw, const VT *__restrict__ grad_out, int total_qm,
-    int S, int M, int Lq, unsigned value_bytes, float *__restrict__ g_loc, float *__restrict__ g_aw)
+    int S, int M, int Lq, unsigned value_bytes, float *__restrict__ g_loc, float *__restrict__ g_aw,
+    const float *__restrict__ ref, VT *__restrict__ g_qproj)
 {
     const int t = xcd_block_id() * kBlock + threadIdx.x;
     int qm = t >> 2;
@@ -650,11 +703,20 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_shared_kernel(
         if (sub == l) { gla = ra; glb = rb; ga = rw; }
         quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
     }
-    if (live) {
-        float4 *gl4 = reinterpret_cast<float4 *>(g_loc) + (long)qm * 8 + sub * 2;
-        gl4[0] = gla;
-        gl4[1] = glb;
-        reinterpret_cast<float4 *>(g_aw)[(long)qm * 4 + sub] = ga;
+    if (REFDIM == 0) {
+        if (live) {
+            float4 *gl4 = reinterpret_cast<float4 *>(g_loc) + (long)qm * 8 + sub * 2;
+            gl4[0] = gla;
+            gl4[1] = glb;
+            reinterpret_cast<float4 *>(g_aw)[(long)qm * 4 + sub] = ga;
+        }
+    } else if (live) {          // (a quad is live or dead as a whole; after 4 rotations wa is this lane's level again)
+        constexpr int RD = REFDIM == 0 ? 2 : REFDIM;
+        const long row = qm / M;
+        const float a[4] = {wa.x, wa.y, wa.z, wa.w};
+        float g[4] = {ga.x, ga.y, ga.z, ga.w};
+        const float gl[8] = {gla.x, gla.y, gla.z, gla.w, glb.x, glb.y, glb.z, glb.w};
+        geom::backward<VT, RD>(g_qproj + row * (M * 48), ref + row * (kL * RD), shapes, m, M, sub, a, g, gl);
     }
 }
 
@@ -759,17 +821,17 @@ void launch_quad_backward_reduce(const Problem &p)
     static const int shared = ablation_env("RLIPV2_MSDA_K1_SHARED", 1);
     if (shared) {
         if (p.dtype == MSDA_F32)
-            hipLaunchKernelGGL((quad_backward_shared_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, p.stream,
+            hipLaunchKernelGGL((quad_backward_shared_kernel<float, 4, 0>), dim3(grid), dim3(kBlock), 0, p.stream,
                                (const float *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                                (const float *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_loc,
-                               (float *)p.g_aw);
+                               (float *)p.g_aw, (const float *)nullptr, (float *)nullptr);
         else {
             static const int waves = ablation_env("RLIPV2_MSDA_K1_WAVES", 4);
 #define MSDA_K1_BF16(W)                                                                                                \
-            hipLaunchKernelGGL((quad_backward_shared_kernel<bf16_t, W>), dim3(grid), dim3(kBlock), 0, p.stream,        \
+            hipLaunchKernelGGL((quad_backward_shared_kernel<bf16_t, W, 0>), dim3(grid), dim3(kBlock), 0, p.stream,     \
                                (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, \
                                (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_loc, \
-                               (float *)p.g_aw)
+                               (float *)p.g_aw, (const float *)nullptr, (bf16_t *)nullptr)
             if (waves == 5) MSDA_K1_BF16(5); else if (waves == 3) MSDA_K1_BF16(3);
             else MSDA_K1_BF16(4);     // (4: 763 us whole backward, 5: 778, 6: 944, 8: 1194 -- spills)
 #undef MSDA_K1_BF16
@@ -786,6 +848,41 @@ void launch_quad_backward_reduce(const Problem &p)
                            (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
                            (const bf16_t *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)p.g_value,
                            (float *)p.g_loc, (float *)p.g_aw);
+}
+
+// ---- fused sampling geometry (msda_fused_forward / msda_fused_backward_ws) ---------------------------------------------
+void launch_quad_forward_fused(const Problem &p, const Fused &f)
+{
+    const int total_qm = p.N * p.Lq * p.M;
+    const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
+    const bool save = f.loc_save != nullptr;
+#define MSDA_FWD_FUSED(VT, RD, SAVE, W)                                                                                \
+    hipLaunchKernelGGL((quad_forward_fused_kernel<VT, RD, SAVE, W>), dim3(grid), dim3(kBlock), 0, p.stream,           \
+                       (const VT *)p.value, p.shapes, p.starts, (const VT *)f.qproj, f.ref, total_qm, p.S, p.M, p.Lq, \
+                       value_bytes(p), (VT *)p.out, f.loc_save, f.aw_save)
+#define MSDA_FWD_FUSED_T(VT, W)                                                                                        \
+    do {                                                                                                               \
+        if (f.refdim == 2) { if (save) MSDA_FWD_FUSED(VT, 2, true, W); else MSDA_FWD_FUSED(VT, 2, false, W); }         \
+        else { if (save) MSDA_FWD_FUSED(VT, 4, true, W); else MSDA_FWD_FUSED(VT, 4, false, W); }                       \
+    } while (0)
+    if (p.dtype == MSDA_F32) MSDA_FWD_FUSED_T(float, 3);
+    else MSDA_FWD_FUSED_T(bf16_t, 4);
+#undef MSDA_FWD_FUSED_T
+#undef MSDA_FWD_FUSED
+}
+
+void launch_quad_backward_reduce_fused(const Problem &p, const Fused &f)
+{
+    const int total_qm = p.N * p.Lq * p.M;
+    const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
+#define MSDA_K1_FUSED(VT, RD)                                                                                          \
+    hipLaunchKernelGGL((quad_backward_shared_kernel<VT, 4, RD>), dim3(grid), dim3(kBlock), 0, p.stream,               \
+                       (const VT *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,            \
+                       (const VT *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), (float *)nullptr,            \
+                       (float *)nullptr, f.ref, (VT *)f.g_qproj)
+    if (p.dtype == MSDA_F32) { if (f.refdim == 2) MSDA_K1_FUSED(float, 2); else MSDA_K1_FUSED(float, 4); }
+    else { if (f.refdim == 2) MSDA_K1_FUSED(bf16_t, 2); else MSDA_K1_FUSED(bf16_t, 4); }
+#undef MSDA_K1_FUSED
 }
 
 }  // namespace msda

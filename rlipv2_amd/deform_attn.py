@@ -25,6 +25,9 @@ from .linear import token_linear
 msda_function = msda.MSDeformAttnFunction
 # use the fused sampling-geometry kernel on the GPU (tests switch it off to compare both routes)
 fused_geometry = True
+# fold that geometry into the sampling kernels themselves (msda.FusedMSDeformAttnFunction) when the reference points
+# need no gradient
+fused_sampling = True
 
 
 def _is_power_of_2(n):
@@ -100,6 +103,15 @@ class MSDeformAttn(nn.Module):
                              torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
         if (qproj.is_cuda and fused_geometry and L == 4 and P == 4 and reference_points.shape[-1] in (2, 4)
                 and qproj.dtype in (torch.float32, torch.bfloat16)):
+            if (fused_sampling and msda_function is msda.MSDeformAttnFunction and qproj.dtype == value.dtype
+                    and not reference_points.requires_grad
+                    and msda.fused_supported(value, input_spatial_shapes, reference_points, Len_q, L, P,
+                                             torch.is_grad_enabled() and (value.requires_grad or qproj.requires_grad))):
+                # geometry + sampling + aggregation in one launch each way: the float32 locations / weights are
+                # written once for the backward pass and never read in the forward, their gradients never exist
+                output = msda.FusedMSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                                              qproj, reference_points, self.im2col_step)
+                return token_linear(output, self.output_proj.weight, self.output_proj.bias)
             # one HIP kernel instead of view + softmax + divide + add (+ their backward passes)
             locations, weights = msda.SamplingGeometryFunction.apply(qproj, reference_points, input_spatial_shapes,
                                                                      M, L, P)

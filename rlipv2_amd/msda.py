@@ -210,6 +210,103 @@ class MSDeformAttnFunction(Function):
         return g_value, None, None, g_loc, g_aw, None
 
 
+def fused_supported(value, spatial_shapes, reference_points, Lq, L, P, need_backward):
+    """Can the fused geometry + sampling kernels (msda_fused_forward / msda_fused_backward_ws) take this call?"""
+    if not value.is_cuda or value.dtype not in (torch.float32, torch.bfloat16) or value.dim() != 4:
+        return False
+    hs = host_shapes(spatial_shapes) if need_backward else None
+    if need_backward and hs is None:
+        return False
+    N, S, M, D = value.shape
+    arr = (ctypes.c_int64 * len(hs))(*hs) if hs is not None else None
+    level = _lib.lib().msda_fused_supported(_DTYPES[value.dtype], arr, reference_points.shape[-1], N, S, M, D, L, Lq, P)
+    return level >= (2 if need_backward else 1)
+
+
+def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj, ref, save):
+    """value [N, S, M, D], qproj [N, Lq, M*L*P*3] (value's dtype), ref [N, Lq, L, 2|4] float32 ->
+    (out [N, Lq, M*D], sampling_loc | None, attn_weight | None): ms_deform_attn.py:101-117 in one launch."""
+    L = _lib.lib()
+    N, S, M, D = value.shape
+    nL, Lq = spatial_shapes.shape[0], qproj.shape[1]
+    P = qproj.shape[2] // (M * nL * 3)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    loc = torch.empty((N, Lq, M, nL, P, 2), dtype=torch.float32, device=value.device) if save else None
+    aw = torch.empty((N, Lq, M, nL, P), dtype=torch.float32, device=value.device) if save else None
+    with torch.cuda.device(value.device):
+        st = L.msda_fused_forward(_DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                                  level_start_index.data_ptr(), qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
+                                  N, S, M, D, nL, Lq, P, out.data_ptr(), loc.data_ptr() if save else None,
+                                  aw.data_ptr() if save else None, torch.cuda.current_stream().cuda_stream)
+    if st:
+        _raise(st)
+    roofline.add(roofline.tensor_bytes(value, qproj, ref, out, loc, aw))
+    last_variant["fwd"] = "quad+geometry"
+    return out, loc, aw
+
+
+def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, loc, aw, ref, grad_output, host):
+    """-> [grad_value (value's dtype), grad_qproj (value's dtype)]; needs the host copy of the level shapes."""
+    L = _lib.lib()
+    N, S, M, D = value.shape
+    nL, Lq, P = spatial_shapes.shape[0], loc.shape[1], loc.shape[4]
+    hs_arr = (ctypes.c_int64 * len(host))(*host)
+    if sum(host[0::2][k] * host[1::2][k] for k in range(len(host) // 2)) != S:
+        raise RuntimeError("ms_deform_attn: sum(H*W) of spatial_shapes != value.shape[1]")   # ms_deform_attn.py:96
+    ws_bytes = int(L.msda_backward_workspace_bytes(_DTYPES[value.dtype], hs_arr, N, S, M, D, nL, Lq, P))
+    go = grad_output if grad_output.dtype == value.dtype else grad_output.to(value.dtype)
+    g_value = torch.empty(value.shape, dtype=value.dtype, device=value.device)
+    g_qproj = torch.empty((N, Lq, M * nL * P * 3), dtype=value.dtype, device=value.device)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+    flags = _lib.FLAG_GRAD_VALUE_BF16 if value.dtype == torch.bfloat16 else 0
+    with torch.cuda.device(value.device):
+        st = L.msda_fused_backward_ws(flags, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                                      level_start_index.data_ptr(), hs_arr, loc.data_ptr(), aw.data_ptr(),
+                                      ref.data_ptr(), ref.shape[-1], go.data_ptr(), N, S, M, D, nL, Lq, P,
+                                      g_value.data_ptr(), g_qproj.data_ptr(), ws.data_ptr(), ws_bytes,
+                                      torch.cuda.current_stream().cuda_stream)
+    if st:
+        _raise(st)
+    roofline.add(roofline.tensor_bytes(value, loc, aw, ref, go, g_value, g_qproj))
+    last_variant["bwd"] = "dest+geometry"
+    return [g_value, g_qproj]
+
+
+class FusedMSDeformAttnFunction(Function):
+    """(value, spatial_shapes, level_start_index, qproj, reference_points) -> out: the module's sampling geometry
+    (ms_deform_attn.py:101-112) and MSDeformAttnFunction (ms_deform_attn_func.py:25-42) as ONE kernel each way
+    (csrc/msda_quad.hip: quad_forward_fused_kernel, quad_backward_shared_kernel<.., REFDIM>).  The forward reads the
+    raw projection rows; float32 sampling_loc / attn_weight are written only when a backward pass will need them, and
+    their gradients never exist in memory.  No gradient for the reference points (the caller checks)."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, qproj, reference_points, im2col_step):
+        if not value.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")                 # ms_deform_attn.h:54
+        for name, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index)):
+            if not t.is_contiguous():
+                raise RuntimeError(f"{name} tensor has to be contiguous")
+        st = _lib.lib().msda_check_im2col_step(value.shape[0], int(im2col_step))
+        if st:
+            _raise(st)
+        qproj = qproj.contiguous()
+        ref = reference_points.float().contiguous()
+        save = ctx.needs_input_grad[0] or ctx.needs_input_grad[3]
+        out, loc, aw = ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj, ref, save)
+        if save:
+            ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, aw, ref)
+            ctx.host_shapes = host_shapes(spatial_shapes)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, loc, aw, ref = ctx.saved_tensors
+        g_value, g_qproj = ms_deform_attn_fused_backward(value, shapes, starts, loc, aw, ref, grad_output.contiguous(),
+                                                         ctx.host_shapes)
+        return g_value, None, None, g_qproj, None, None
+
+
 class SamplingGeometryFunction(Function):
     """qproj [N, Lq, M*L*P*3] (offsets then logits), reference_points [N, Lq, L, 2|4] ->
     (sampling_locations [N, Lq, M, L, P, 2], attention_weights [N, Lq, M, L, P]), both float32 -- the

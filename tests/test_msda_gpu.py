@@ -523,3 +523,92 @@ def test_shapes_that_do_not_sum_to_len_in_are_rejected():
     v, l, a, g = _to_dev(value), _to_dev(loc), _to_dev(aw), _to_dev(go)
     with pytest.raises(RuntimeError, match=r"sum\(H\*W\)"):
         msda.ms_deform_attn_backward(v, _to_dev(bad), _to_dev(starts), l, a, g, 64)
+
+
+# ---- fused sampling geometry + sampling (msda_fused_forward / msda_fused_backward_ws) -----------------------------------
+def _fused_inputs(dtype, refdim, N=2, Lq=None, pyramid=((25, 34), (13, 17), (7, 9), (4, 5)), seed=3):
+    """Raw projection rows + reference points of a small encoder-like (Lq = S, 2-d) or decoder-like (4-d) call."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    shapes = torch.tensor(pyramid, dtype=torch.long, device=DEV)
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    Lq = S if Lq is None else Lq
+    M, D, L, P = 8, 32, 4, 4
+    value = (torch.randn(N, S, M, D, device=DEV, generator=g) * 0.5).to(dtype)
+    qproj = torch.randn(N, Lq, M * L * P * 3, device=DEV, generator=g)
+    qproj[..., :M * L * P * 2] *= 3.0                                   # offsets of a few pixels / a fraction of the box
+    qproj = qproj.to(dtype)
+    if refdim == 2:
+        ref = torch.rand(N, Lq, L, 2, device=DEV, generator=g)
+    else:
+        ref = torch.cat([torch.rand(N, Lq, L, 2, device=DEV, generator=g) * 0.8 + 0.1,
+                         torch.rand(N, Lq, L, 2, device=DEV, generator=g) * 0.4 + 0.05], -1)
+    grad_out = torch.randn(N, Lq, M * D, device=DEV, generator=g).to(dtype)
+    msda.attach_host_shapes(shapes, pyramid)
+    return value, shapes, starts, qproj, ref, grad_out, (M, L, P)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("refdim,Lq", [(2, None), (4, 150), (2, 37)])
+def test_fused_geometry_route_equals_the_two_step_route(dtype, refdim, Lq):
+    """FusedMSDeformAttnFunction == MSDeformAttnFunction(SamplingGeometryFunction(.)): the same geometry instructions
+    (msda_geometry.h) and the same gather / scatter kernels underneath, so the comparison is exact for bfloat16 (same
+    forward kernel structure) and to float32 rounding where the two-step route picks another forward kernel."""
+    value, shapes, starts, qproj, ref, grad_out, (M, L, P) = _fused_inputs(dtype, refdim, Lq=Lq)
+    res = []
+    for fused in (True, False):
+        v = value.clone().requires_grad_(True)
+        q = qproj.clone().requires_grad_(True)
+        if fused:
+            assert msda.fused_supported(v, shapes, ref, q.shape[1], L, P, True)
+            out = msda.FusedMSDeformAttnFunction.apply(v, shapes, starts, q, ref, 64)
+        else:
+            loc, aw = msda.SamplingGeometryFunction.apply(q, ref, shapes, M, L, P)
+            out = msda.MSDeformAttnFunction.apply(v, shapes, starts, loc, aw, 64)
+        out.backward(grad_out)
+        res.append((out.detach().float(), v.grad.float(), q.grad.float()))
+    torch.cuda.synchronize()
+    (o1, gv1, gq1), (o2, gv2, gq2) = res
+    if dtype == torch.bfloat16:
+        assert torch.equal(o1, o2)
+    else:
+        assert torch.allclose(o1, o2, rtol=1e-5, atol=1e-6 * float(o2.abs().max()))
+    assert torch.equal(gv1, gv2)            # same destination-stationary pass on the same locations / weights
+    assert torch.equal(gq1, gq2)            # same K1 arithmetic, same geometry backward
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_geometry_route_vs_oracle(dtype):
+    """The fused route against the CPU oracle fed with locations / weights computed in float64 from the same rows."""
+    value, shapes, starts, qproj, ref, grad_out, (M, L, P) = _fused_inputs(dtype, 2, N=1)
+    N, Lq = qproj.shape[:2]
+    v = value.clone().requires_grad_(True)
+    q = qproj.clone().requires_grad_(True)
+    out = msda.FusedMSDeformAttnFunction.apply(v, shapes, starts, q, ref, 64)
+    out.backward(grad_out)
+    torch.cuda.synchronize()
+    # float64 restatement of ms_deform_attn.py:101-109 on the CPU
+    qd = qproj.double().cpu()
+    off = qd[..., :M * L * P * 2].reshape(N, Lq, M, L, P, 2)
+    aw = torch.softmax(qd[..., M * L * P * 2:].reshape(N, Lq, M, L * P), -1).reshape(N, Lq, M, L, P)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).double().cpu()
+    loc = ref.double().cpu()[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    a = [value.double().cpu().numpy(), shapes.cpu().numpy(), starts.cpu().numpy(), loc.numpy(), aw.numpy()]
+    ref_out = O.forward(*a)
+    ref_gv, ref_gl, ref_ga = O.backward(*a, grad_out.double().cpu().numpy())
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 1e-4
+    got = out.detach().float().cpu().numpy()
+    assert np.abs(got - ref_out).max() <= tol * np.abs(ref_out).max()
+    gv = v.grad.float().cpu().numpy()
+    assert np.abs(gv - ref_gv).max() <= tol * np.abs(ref_gv).max()
+    # chain rule of the geometry in float64: offsets scale by 1 / (W, H); softmax backward
+    g_off = torch.from_numpy(ref_gl) / norm[None, None, None, :, None, :]
+    ga = torch.from_numpy(ref_ga)
+    g_logit = aw * (ga - (aw * ga).sum((-1, -2), keepdim=True))
+    ref_gq = torch.cat([g_off.reshape(N, Lq, -1), g_logit.reshape(N, Lq, -1)], -1).numpy()
+    gq = q.grad.float().cpu().numpy()
+    # the location gradient jumps where a sample crosses a pixel centre: compare away from those samples
+    keep = np.broadcast_to(~kink_samples({"loc": a[3], "shapes": a[1]}, 1e-3)[..., None], ref_gl.shape).reshape(N, Lq, -1)
+    keep = np.concatenate([keep, np.ones((N, Lq, M * L * P), dtype=bool)], -1)
+    err = np.abs(gq - ref_gq)[keep].max()
+    assert err <= (2 ** -6 if dtype == torch.bfloat16 else 1e-3) * np.abs(ref_gq).max()

@@ -549,7 +549,12 @@ def main():
                 + ("; VARIANT padded batch: images of 800x1333 and 736x1100 padded together, padding masks live" if args.padded else "")
                 + ("; VARIANT variable targets: 8 / 6 / 11 triplets per image in rotation, one graph capture per bucket" if args.var_targets else "")
                 + ("; VARIANT eager launches (no HIP graphs)" if not args.graph else "")),
-                 parallelism=(f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
+                 parallelism=(f"dp{world} (bf16 RCCL gradient all-reduce in buckets of arrival order, captured inside the "
+                              "backward graph on a communication stream: bucket k travels while autograd computes the "
+                              "earlier layers); model forward/backward replayed as HIP graphs"
+                              if graphed and (world > 1 or os.environ.get("RLIPV2_FORCE_DP") == "1")
+                              and os.environ.get("RLIPV2_DP_OVERLAP", "1") != "0" else
+                              f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
                               "model forward/backward replayed as HIP graphs" if graphed else
                               f"dp{world} (DDP: bucketed RCCL gradient all-reduce overlapped with backward); eager launches"),
                  cpu_calls=lambda: build_msda_step(1, torch.float32, device, 0),

@@ -314,10 +314,16 @@ class RLIP_ParSeDA(nn.Module):
                 and overlap_text_encoder):
             cur = torch.cuda.current_stream()
             side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=samples.tensors.device))
-            side.wait_stream(cur)
+            fork = cur.record_event()
+        features, pos = self.backbone(samples)
+        if encoded_text is None and 'fork' in locals():
+            # Issued AFTER the backbone, forked from BEFORE it (the event): the two still run side by side, but the
+            # text encoder's autograd nodes are now the younger ones, so the backward pass runs the text encoder
+            # BEFORE the backbone -- its gradients (60 % of the all-reduce bytes) are complete while the backbone's
+            # backward still computes, and the data-parallel step reduces them underneath it (train.GradientSynchronizer)
+            side.wait_event(fork)
             with torch.cuda.stream(side):
                 encoded_text = tr._encode_text(text, samples.tensors.shape[0], samples.tensors.device)
-        features, pos = self.backbone(samples)
         srcs, masks = [], []
         for l, feat in enumerate(features):
             src, mask = feat.decompose()

@@ -17,6 +17,7 @@ DistributedDataParallel.  Two departures from the reference, neither changes the
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -120,10 +121,17 @@ class GraphedStep:
     runs on them eagerly; `loss.backward()` fills their `.grad`; `step.backward()` replays the model's
     backward graph from those."""
 
-    def __init__(self, step_module, model, batch, warmup=3, synchronizer=None, criterion=None):
+    def __init__(self, step_module, model, batch, warmup=3, synchronizer=None, criterion=None, overlap=None):
+        """`overlap` (default: on with a synchronizer, RLIPV2_DP_OVERLAP=0 switches it off): the gradient all-reduce is
+        bucketed and captured INSIDE the backward graph on a communication stream, each bucket starting as soon as its
+        last gradient exists (GradientSynchronizer.hooked) -- averaging overlapped with the rest of the backward pass
+        (reference main.py:515-517).  Off: one flat all-reduce after the backward replay."""
         samples, text, targets = batch
         self.synchronizer = synchronizer
         self.criterion = criterion
+        if overlap is None:
+            overlap = os.environ.get("RLIPV2_DP_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and synchronizer is not None
         self.wrapper = GraphedTrainForward(step_module, text["obj_pred_names_sums"],
                                            model.transformer.ho_decoder.num_layers, model.pseudo_verb)
         self.wrapper.no_padding = bool(getattr(samples, "no_padding", False))      # baked into the capture
@@ -146,29 +154,52 @@ class GraphedStep:
                 state = criterion.prepare(self.wrapper.unflatten(outs), self.static_targets)
             return outs, state
 
-        def loss_and_grads(outs, state, index, num):
+        def backward_of(outputs, grad_outputs, mode):
+            """mode "plain": gradients as autograd returns them; "record": additionally note their arrival order;
+            "sync": deliver them through the synchronizer (bucketed + overlapped, or packed for the flat schedule)"""
+            if mode == "record":
+                with synchronizer.recording() as rec:
+                    grads = torch.autograd.grad(outputs, self.params, grad_outputs, allow_unused=True)
+                self.arrival = rec.order
+                return grads
+            if mode == "sync" and self.overlap:
+                with synchronizer.hooked():
+                    torch.autograd.grad(outputs, self.params, grad_outputs, allow_unused=True)
+                return synchronizer.views
+            grads = torch.autograd.grad(outputs, self.params, grad_outputs, allow_unused=True)
+            return synchronizer.pack(grads) if (mode == "sync" and synchronizer is not None) else grads
+
+        def loss_and_grads(outs, state, index, num, mode="plain"):
             if criterion is None:
                 need = [o for o in outs if o.requires_grad]
-                return None, None, torch.autograd.grad(need, self.params, [torch.ones_like(o) for o in need],
-                                                       allow_unused=True)
+                return None, None, backward_of(need, [torch.ones_like(o) for o in need], mode)
             ld = criterion.losses(state, index, num)
             total = criterion.weighted_sum(ld)
-            return ld, total, torch.autograd.grad(total, self.params, allow_unused=True)
+            return ld, total, backward_of(total, None, mode)
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
+            for it in range(warmup):
+                wmode = "record" if (self.overlap and it == warmup - 1) else "plain"
                 outs, state = forward_part()
                 if criterion is not None:
                     index = criterion.assign(state).to(samples.tensors.device)
                     num = criterion._num_interactions(self.sizes, samples.tensors.device).reshape(1)
-                    loss_and_grads(outs, state, index, num[0])
+                    loss_and_grads(outs, state, index, num[0], wmode)
                 else:
-                    loss_and_grads(outs, None, None, None)
+                    loss_and_grads(outs, None, None, None, wmode)
             del outs, state
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.overlap:
+            # buckets in the order the gradients arrive; rank 0's order for everybody (the schedule of collectives
+            # has to be the same on all ranks)
+            import torch.distributed as dist
+            order = [list(self.arrival)]
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(synchronizer.group) > 1:
+                dist.broadcast_object_list(order, src=0, group=synchronizer.group)
+            synchronizer.plan_buckets(order[0])
         pool = torch.cuda.graph_pool_handle()
         # "thread_local": other threads of the process may call HIP while we capture -- with a process group
         # alive, RCCL's watchdog thread polls events, which in the default "global" mode invalidates the capture
@@ -182,10 +213,8 @@ class GraphedStep:
             self.diff = [i for i, o in enumerate(self.static_out) if o.requires_grad]
             self.static_gout = [torch.zeros_like(self.static_out[i]) for i in self.diff]
             with torch.cuda.graph(self.bwd_graph, pool=pool, capture_error_mode=mode):
-                grads = torch.autograd.grad([self.static_out[i] for i in self.diff], self.params, self.static_gout,
-                                            allow_unused=True)
-                if synchronizer is not None:
-                    grads = synchronizer.pack(grads)          # the packing copy is part of the backward graph
+                # (with a synchronizer the packing copies -- and, overlapped, the collectives -- are graph nodes)
+                grads = backward_of([self.static_out[i] for i in self.diff], self.static_gout, "sync")
             self.static_grads = grads
             return
         self.static_index = index.clone()                      # [2, K * matched pairs]: shape fixed by `sizes`
@@ -193,9 +222,7 @@ class GraphedStep:
         self.pinned_index = torch.empty(index.shape, dtype=index.dtype, pin_memory=True)
         with torch.cuda.graph(self.bwd_graph, pool=pool, capture_error_mode=mode):
             self.loss_dict, self.total, grads = loss_and_grads(self.static_out, self.state, self.static_index,
-                                                                self.static_num[0])
-            if synchronizer is not None:
-                grads = synchronizer.pack(grads)
+                                                                self.static_num[0], "sync")
         self.static_grads = grads
 
     def _load_inputs(self, samples, text, targets):
@@ -226,7 +253,7 @@ class GraphedStep:
         self.leaves = None
 
     def _deliver(self):
-        if self.synchronizer is not None:
+        if self.synchronizer is not None and not self.overlap:
             self.synchronizer.all_reduce()
         for p, g in zip(self.params, self.static_grads):
             p.grad = g
@@ -344,28 +371,77 @@ def broadcast_parameters(module, src=0):
 
 
 class GradientSynchronizer:
-    """Data-parallel gradient averaging without DistributedDataParallel, for the graphed step: the backward
-    replay leaves the gradients in static buffers; they are packed into ONE flat bf16 buffer (a single
-    multi-tensor copy), averaged with ONE RCCL all-reduce (ReduceOp.AVG) and handed to the optimiser as views
-    of that buffer.  xGMI is point-to-point, so one 425 MB ring all-reduce per step uses the links better
-    than DDP's 64 MB buckets; it is not overlapped with the backward graph (a monolithic replay)."""
+    """Data-parallel gradient averaging without DistributedDataParallel, for the graphed step.
 
-    def __init__(self, params, group=None):
+    The gradients live in ONE flat buffer (bf16 in the master-weight mode, 425 MB for 212.7 M parameters); the
+    optimiser reads them as views of it, in the parameters' own memory layouts.  Two schedules:
+
+    * bucketed and overlapped (`plan_buckets` + `hooked`, the default of GraphedStep): the flat buffer is cut into
+      buckets in the order the gradients become available during the backward pass (recorded in the eager warm-up);
+      a tensor hook on every parameter copies its gradient into the buffer as soon as autograd has it, and the hook
+      that completes a bucket starts that bucket's all-reduce on a communication stream -- while autograd goes on
+      with the earlier layers.  Under HIP-graph capture hooks, copies and collectives are all captured: the backward
+      graph then holds the RCCL all-reduces on a forked branch, joined before the graph ends.  This is what
+      DistributedDataParallel's reducer does for an eager backward (reference main.py:515-517), in a form that can
+      be replayed.  xGMI is point-to-point, a ring all-reduce is per-link bound: few, large buckets (96 MB default).
+    * flat (`pack` + `all_reduce`): one copy, ONE all-reduce after the backward pass, nothing overlapped.
+
+    `reduce_dtype=torch.float32`: the reduction runs on a float32 copy of each bucket (the reference's DDP reduces
+    float32 gradients) instead of in the gradients' own bfloat16."""
+
+    def __init__(self, params, group=None, reduce_dtype=None, bucket_bytes=96 << 20):
         self.params = list(params)
         self.group = group
+        self.reduce_dtype = reduce_dtype
+        self.bucket_bytes = bucket_bytes
         self._avg = None
-        total = sum(p.numel() for p in self.params)
+        total = sum((p.numel() + 7) // 8 * 8 for p in self.params)     # every view starts on a 16-byte boundary
         p0 = self.params[0]
         self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
-        self.views, off = [], 0
-        for p in self.params:
-            n = p.numel()
-            v = self.flat[off:off + n]
-            # keep the parameter's memory layout (channels-last convolution weights) so that the fused
-            # optimiser sees gradient and parameter in the same element order
-            self.views.append(v.as_strided(p.shape, p.stride()) if p.is_contiguous() or _dense(p) else v.view(p.shape))
-            off += n
+        self.views = [None] * len(self.params)
+        self.comm = torch.cuda.Stream(device=p0.device) if p0.is_cuda else None
+        self.pending = []
+        self.set_buckets([list(range(len(self.params)))])
 
+    # ---- layout ---------------------------------------------------------------------------------------------------
+    def set_buckets(self, buckets):
+        """Partition of the parameter indices into buckets, each one contiguous stretch of the flat buffer."""
+        assert sorted(i for b in buckets for i in b) == list(range(len(self.params)))
+        self.buckets = [list(b) for b in buckets]
+        self.bucket_of = [0] * len(self.params)
+        self.ranges, off = [], 0
+        for k, b in enumerate(self.buckets):
+            start = off
+            for i in b:
+                p = self.params[i]
+                n = p.numel()
+                v = self.flat[off:off + n]
+                # keep the parameter's memory layout (channels-last convolution weights) so that the fused
+                # optimiser sees gradient and parameter in the same element order
+                self.views[i] = v.as_strided(p.shape, p.stride()) if p.is_contiguous() or _dense(p) else v.view(p.shape)
+                self.bucket_of[i] = k
+                off += (n + 7) // 8 * 8
+            self.ranges.append((start, off))
+        self._stage = [None] * len(self.buckets)
+
+    def plan_buckets(self, order):
+        """`order`: parameter indices in the order their gradients arrive in the backward pass (every rank must pass
+        the same order; parameters missing from it go last).  Greedy buckets of ~bucket_bytes in that order."""
+        seen = set(order)
+        order = list(order) + [i for i in range(len(self.params)) if i not in seen]
+        buckets, cur, size = [], [], 0
+        for i in order:
+            cur.append(i)
+            size += self.params[i].numel() * self.flat.element_size()
+            if size >= self.bucket_bytes:
+                buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            buckets.append(cur)
+        self.set_buckets(buckets)
+        return buckets
+
+    # ---- flat schedule --------------------------------------------------------------------------------------------
     def pack(self, grads):
         """copy one gradient (or None = zero) per parameter into the flat buffer; returns the views"""
         have = [(v, g) for v, g in zip(self.views, grads) if g is not None]
@@ -409,6 +485,138 @@ class GradientSynchronizer:
         self.pack(grads)
         self.all_reduce()
         return self.views
+
+    # ---- bucketed, overlapped schedule ----------------------------------------------------------------------------
+    def recording(self):
+        """context: records the order in which the parameters' gradients arrive (`.order` afterwards)"""
+        return _GradHooks(self, record_only=True)
+
+    def hooked(self):
+        """context around the backward pass (`torch.autograd.grad(loss, params)` or `loss.backward()`): every
+        parameter's gradient is copied into its view the moment autograd has it, a complete bucket is handed to the
+        collective at once.  On exit the parameters that received no gradient are zero-filled, the remaining buckets
+        launched and the current stream made to wait for all of them: the views hold the averaged gradients."""
+        return _GradHooks(self, record_only=False)
+
+    def launch_bucket(self, k, streams=()):
+        """Average bucket k on the communication stream, ordered after the work of `streams` (default: the current
+        stream); returns at once, `finish()` joins.  The collective is a SUM followed by a scale on the same stream:
+        ReduceOp.AVG captured into a HIP graph came back as garbage on replay (RCCL 2.26, measured on a 1-rank group;
+        SUM replays correctly), and gloo has no AVG at all."""
+        import torch.distributed as dist
+        a, b = self.ranges[k]
+        if a == b:
+            return
+        part = self.flat[a:b]
+        world = dist.get_world_size(self.group)
+        if self.comm is not None:
+            for st in (streams or [torch.cuda.current_stream(self.flat.device)]):
+                if st != self.comm:
+                    self.comm.wait_stream(st)
+        with (torch.cuda.stream(self.comm) if self.comm is not None else _nullcontext()):
+            buf = part
+            if self.reduce_dtype is not None and self.reduce_dtype != part.dtype:
+                if self._stage[k] is None:
+                    self._stage[k] = torch.empty(b - a, dtype=self.reduce_dtype, device=part.device)
+                buf = self._stage[k]
+                buf.copy_(part)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # (waiting for the work on the communication stream right here, inside the autograd hook, segfaulted in
+        #  hipGraphInstantiate at the end of the capture: the join and the 1/world scale happen in finish())
+        self.pending.append((work, part, buf, world))
+
+    @staticmethod
+    def _scale_back(part, buf, world):
+        if buf is not part:
+            part.copy_(buf if world == 1 else buf / world)
+        elif world > 1:
+            part.mul_(1.0 / world)
+
+    def finish(self):
+        """the current stream waits for every launched bucket; the averaged gradients are then in the views"""
+        if self.comm is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+        for work, part, buf, world in self.pending:
+            work.wait()
+        if self.pending:
+            world = self.pending[0][3]
+            if all(buf is part for _, part, buf, _ in self.pending):
+                if world > 1:                    # one pass over the flat buffer: SUM -> mean
+                    lo, hi = min(self.ranges)[0], max(self.ranges)[1]
+                    self.flat[lo:hi].mul_(1.0 / world)
+            else:
+                for _, part, buf, _ in self.pending:
+                    self._scale_back(part, buf, world)
+        self.pending = []
+
+
+class _GradHooks:
+    """tensor hooks of GradientSynchronizer.recording() / .hooked()"""
+
+    def __init__(self, sync, record_only):
+        self.sync, self.record_only = sync, record_only
+        self.order = []
+
+    def __enter__(self):
+        import threading
+        s = self.sync
+        self.lock = threading.Lock()
+        self.left = [len(b) for b in s.buckets]
+        self.streams = [[] for _ in s.buckets]
+        self.got = [False] * len(s.params)
+        self.handles = [p.register_hook(lambda g, i=i: self._arrived(i, g)) for i, p in enumerate(s.params)]
+        return self
+
+    def _arrived(self, i, g):
+        s = self.sync
+        with self.lock:                       # (autograd may run hooks from its device thread)
+            if self.got[i]:
+                return None
+            self.got[i] = True
+            self.order.append(i)
+            if self.record_only:
+                return None
+            # copied at once, on the stream autograd hands the gradient over on (the gradient is valid there and its
+            # memory is released in that stream's order -- no cross-stream lifetime to manage, nothing is kept alive)
+            s.views[i].copy_(g)
+            k = s.bucket_of[i]
+            if s.comm is not None:
+                cur = torch.cuda.current_stream(s.flat.device)
+                if all(cur != st for st in self.streams[k]):
+                    self.streams[k].append(cur)
+            self.left[k] -= 1
+            if self.left[k] == 0:
+                s.launch_bucket(k, self.streams[k])
+        return None
+
+    def __exit__(self, *exc):
+        s = self.sync
+        for h in self.handles:
+            h.remove()
+        if self.record_only or exc[0] is not None:
+            return False
+        missing = [i for i, got in enumerate(self.got) if not got]
+        if missing:
+            torch._foreach_zero_([s.views[i] for i in missing])
+        for k in sorted({s.bucket_of[i] for i in missing}):
+            self.left[k] -= sum(1 for i in missing if s.bucket_of[i] == k)
+            if s.comm is not None:
+                cur = torch.cuda.current_stream(s.flat.device)
+                if all(cur != st for st in self.streams[k]):
+                    self.streams[k].append(cur)          # (the zero-fill above ran on this stream)
+            if self.left[k] == 0:
+                s.launch_bucket(k, self.streams[k])
+        assert all(n == 0 for n in self.left), self.left
+        s.finish()
+        return False
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
 
 
 def _dense(t):

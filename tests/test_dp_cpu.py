@@ -153,3 +153,69 @@ def test_gradient_synchronizer_and_broadcast_two_ranks():
         gb = torch.zeros_like(x) if g1[i] is None else g1[i]
         torch.testing.assert_close(x, (ga + gb) / 2)
         assert x.stride() == p0[i].stride()
+
+
+def _overlap_worker(rank, world, port, out_dir, wide):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    model, crit, train = _build()
+    batch = _batch(train, 2, seed=100 + rank)                            # this rank's image shard
+    step = train.ParSeDATrainStep(model)
+    train.freeze_parameters_without_gradient(step, crit, batch)
+    params = [p for p in step.parameters() if p.requires_grad]
+    # wide: the reduction runs on a wider copy of each bucket (the switchable reduction dtype of the bf16 train step)
+    sync = train.GradientSynchronizer(params, reduce_dtype=torch.float64 if wide else None, bucket_bytes=1 << 20)
+    launched = []
+    real_launch = sync.launch_bucket
+    sync.launch_bucket = lambda k, streams=(): (launched.append(k), real_launch(k, streams))[1]
+    for attempt in range(2):                # first pass records the arrival order, second one runs bucketed
+        outputs = step(*batch)
+        total = crit.weighted_sum(crit(outputs, batch[2]))
+        if attempt == 0:
+            with sync.recording() as rec:
+                torch.autograd.grad(total, params, allow_unused=True)
+            order = [rec.order]
+            dist.broadcast_object_list(order, src=0)
+            sync.plan_buckets(order[0])
+            continue
+        with sync.hooked():
+            torch.autograd.grad(total, params, allow_unused=True)
+    if rank == 0:
+        names = [n for n, p in step.named_parameters() if p.requires_grad]
+        torch.save({"grads": {n: v.clone() for n, v in zip(names, sync.views)}, "launched": launched,
+                    "buckets": [len(b) for b in sync.buckets], "first": [names[i] for i in sync.buckets[0][:3]]},
+                   os.path.join(out_dir, "overlap_grads.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_bucketed_overlapped_all_reduce_two_ranks(tmp_path, wide):
+    """GradientSynchronizer.hooked(): tensor hooks copy every gradient into the flat buffer as autograd produces it and
+    the hook completing a bucket starts that bucket's (asynchronous) all-reduce -- the schedule the graphed
+    data-parallel step captures into its backward graph.  2 gloo ranks: the averaged gradients equal the single-process
+    gradients of the global batch; the buckets go out in arrival order, the decoders' / heads' gradients first."""
+    port = 29500 + os.getpid() % 1000 + 5 + int(wide)
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path), wide), nprocs=2, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "overlap_grads.pt"))
+    dp = res["grads"]
+    assert len(res["buckets"]) >= 3 and res["launched"] == sorted(res["launched"]) and len(res["launched"]) == len(res["buckets"])
+    assert all("backbone" not in n and "encoder" not in n for n in res["first"]), res["first"]
+
+    model, crit, train = _build()
+    from rlipv2_amd.blocks import NestedTensor
+    parts = [_batch(train, 2, seed=100 + r) for r in range(2)]
+    samples = NestedTensor(torch.cat([p[0].tensors for p in parts]), torch.cat([p[0].mask for p in parts]))
+    mem = parts[0][1][1][:, :1].repeat(1, 4, 1)
+    text = (~(mem.sum(-1) > 0), mem, torch.tensor([[6, 4]]))
+    targets = parts[0][2] + parts[1][2]
+    step = train.ParSeDATrainStep(model)
+    train.freeze_parameters_without_gradient(step, crit, (samples, text, targets))
+    outputs = step(samples, text, targets)
+    crit.weighted_sum(crit(outputs, targets)).backward()
+    ref = {n: p.grad.clone() for n, p in step.named_parameters() if p.grad is not None}
+    assert set(ref) == set(dp)
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    worst = max(float((ref[n] - dp[n]).abs().max()) / max(1e-3 * gmax, float(ref[n].abs().max())) for n in ref)
+    assert worst < 2e-3, worst

@@ -311,6 +311,63 @@ def test_graphed_data_parallel_step_on_one_rank_rccl():
             dist.destroy_process_group()
 
 
+def test_overlapped_bucketed_all_reduce_inside_the_backward_graph():
+    """GraphedStep(overlap=True): tensor hooks + bucketed RCCL all-reduces captured INSIDE the backward graph on a
+    communication stream (GradientSynchronizer.hooked) against the flat schedule (one all-reduce after the replay), on
+    a 1-rank RCCL group in eval mode.  Same autograd pass, only the delivery of the gradients differs (exactness of
+    the schedule itself: tests/test_dp_cpu.py on 2 gloo ranks); on the device two runs of the SAME step already differ
+    by the atomics of the decoders' attention backward, so the comparison is over all gradients together."""
+    import torch.distributed as dist
+    from rlipv2_amd import parseda, train
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        torch.manual_seed(0)
+        margs = parseda.default_args(num_queries=40, enc_layers=4, dec_layers=2)
+        model, criterion = train.build_training(margs, device=DEV, with_text_encoder=True)
+        train.to_bf16(model)
+        batch = train.synthetic_batch(2, 256, 320, device=DEV, triplets=3)
+        batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        step = train.ParSeDATrainStep(model)
+        model.eval()
+        train.freeze_parameters_without_gradient(step, criterion, batch)
+        params = [p for p in step.parameters() if p.requires_grad]
+        names = [n for n, p in step.named_parameters() if p.requires_grad]
+        got = {}
+        for overlap in (False, "again", True):
+            sync = train.GradientSynchronizer(params, bucket_bytes=32 << 20)
+            graphed = train.GraphedStep(step, model, batch, synchronizer=sync, criterion=criterion, overlap=overlap is True)
+            assert graphed.overlap == (overlap is True)
+            for _ in range(3):
+                _, total = graphed.run(*batch)
+            torch.cuda.synchronize()
+            got[overlap] = ([p.grad.detach().float().clone() for p in params], float(total))
+            if overlap is True:
+                assert len(sync.buckets) >= 4, [len(b) for b in sync.buckets]
+                # arrival order: heads / decoders first; the text encoder (issued after the backbone in the forward
+                # pass, so that its backward comes first) before the backbone, whose first convolution is last
+                assert not any("backbone" in names[i] or "text_encoder" in names[i] for i in sync.buckets[0])
+                first_text = min(k for k, b in enumerate(sync.buckets) if any("text_encoder" in names[i] for i in b))
+                first_bb = min(k for k, b in enumerate(sync.buckets) if any("backbone" in names[i] for i in b))
+                assert first_text <= first_bb and "backbone" in names[sync.buckets[-1][-1]]
+                lo, hi = sync.flat.data_ptr(), sync.flat.data_ptr() + sync.flat.numel() * 2
+                assert all(lo <= p.grad.data_ptr() < hi and p.grad.data_ptr() % 16 == 0 for p in params)
+        assert abs(got[True][1] - got[False][1]) <= 1e-3 * abs(got[False][1])
+        def distance(x, y):
+            num = sum(float((a - b).pow(2).sum()) for a, b in zip(x, y))
+            return (num / sum(float(b.pow(2).sum()) for b in y)) ** 0.5
+
+        noise = distance(got["again"][0], got[False][0])        # a second capture of the SAME flat schedule
+        assert distance(got[True][0], got[False][0]) < max(2e-2, 2.0 * noise), (distance(got[True][0], got[False][0]), noise)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_criterion_and_matcher_match_reference_on_gpu():
     """The stacked, stage-split criterion that the bench captures (prepare -> assign -> losses, criterion.py) on
     the GPU against the reference-generated golden: every loss entry, the weighted total and the gradients of

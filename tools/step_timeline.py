@@ -14,12 +14,16 @@ step_module = train.ParSeDATrainStep(model)
 opt = MasterWeightAdamW(model)
 model.train()
 sync = None
-if os.environ.get("STEP_DP") in ("1", "2", "3"):                     # 1-rank RCCL group: the data-parallel flavour of the step
+if os.environ.get("STEP_DP") in ("1", "2", "3", "4", "5"):                     # 1-rank RCCL group: the data-parallel flavour of the step
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29579")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     train.freeze_parameters_without_gradient(step_module, criterion, batch)
     sync = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
+    if os.environ["STEP_DP"] == "5":
+        sync.comm = None                                        # ablation: bucket copies + collectives on the compute streams
+    if os.environ["STEP_DP"] == "4":
+        sync.launch_bucket = lambda k, streams=(): None        # ablation: hooks + copies into the flat buffer, no collective
     if os.environ["STEP_DP"] in ("2", "3"):
         sync.all_reduce = lambda: None                     # ablation: no collective
     if os.environ["STEP_DP"] == "3":
@@ -54,3 +58,11 @@ print(f"{'phase':44s} {'GPU timeline ms':>16s} {'host issue ms':>14s}")
 for k in range(4):
     print(f"{names[k]:44s} {acc_gpu[k]:16.2f} {acc_host[k]:14.2f}")
 print(f"{'sum':44s} {sum(acc_gpu):16.2f} {sum(acc_host):14.2f}")
+if sync is not None:
+    import torch.distributed as dist
+    print(f"\ndata-parallel schedule: {'bucketed all-reduce captured inside the backward graph (overlapped)' if graphed.overlap else 'one flat all-reduce after the backward replay'}"
+          f"; world size {dist.get_world_size()}")
+    names = [n for n, p in step_module.named_parameters() if p.requires_grad]
+    for k, b in enumerate(sync.buckets):
+        a, e = sync.ranges[k]
+        print(f"  bucket {k}: {len(b):4d} tensors {(e - a) * sync.flat.element_size() / 1e6:7.1f} MB  first: {names[b[0]][:60]:60s} last: {names[b[-1]][:60]}")

@@ -328,6 +328,11 @@ def run_train_step_bench(args, world, rank, local_rank, device):
                 train.freeze_parameters_without_gradient(step_module, criterion, batch)
             else:
                 synchronizer = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
+                if os.environ.get("RLIPV2_DP_OVERLAP", "1") != "0" and not train.captured_collective_selftest(device):
+                    # (all ranks agree on the verdict) captured collectives do not replay here: flat schedule
+                    print("[bench] captured all-reduce self-test failed: one flat all-reduce after the backward graph",
+                          file=sys.stderr)
+                    os.environ["RLIPV2_DP_OVERLAP"] = "0"
             if args.var_targets:
                 step_module = train.GraphedStepCache(step_module, model, synchronizer, criterion=criterion)
                 for b in rotation:

@@ -362,6 +362,40 @@ def graph_step_module(step_module, model, batch, synchronizer=None, criterion=No
     return GraphedStep(step_module, model, batch, synchronizer=synchronizer, criterion=criterion)
 
 
+def captured_collective_selftest(device, group=None):
+    """Can this process group's all-reduce be captured into a HIP graph on a side stream and replayed?  A tiny graph
+    (fork to a communication stream, SUM all-reduce, join) is captured, replayed twice and checked; every rank gets the
+    same answer (the verdicts are combined with a MIN all-reduce), so all ranks pick the same schedule."""
+    import torch.distributed as dist
+    ok = 1
+    try:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        x = torch.zeros(1024, device=device)
+        comm = torch.cuda.Stream(device=device)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            y = x * 2.0
+            comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm):
+                work = dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            torch.cuda.current_stream().wait_stream(comm)
+            work.wait()
+            z = y + 1.0
+        for k in (1, 2):
+            x.fill_(float(rank + k))
+            g.replay()
+            torch.cuda.synchronize()
+            expect = 2.0 * sum(r + k for r in range(world)) + 1.0
+            if not bool(torch.all(z == expect)):
+                ok = 0
+    except Exception:                                       # noqa: BLE001 -- any failure means "do not use it"
+        ok = 0
+    flag = torch.tensor([ok], device=device, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
 def broadcast_parameters(module, src=0):
     """Rank `src`'s parameters and buffers to every rank (what DistributedDataParallel does when it wraps)."""
     import torch.distributed as dist

@@ -75,8 +75,10 @@ typedef enum msda_variant {
     MSDA_VARIANT_GENERIC = 1,   /* any M, D, L, P; f32 / f64 / bf16: one wave per (n, q, m) */
     MSDA_VARIANT_QUAD = 2,      /* D = 32, L*P = 16: four lanes per (n, q, m), direct gathers */
     MSDA_VARIANT_WINDOW = 3,    /* D = 32, L*P = 16: LDS-staged sampling windows per query tile */
-    MSDA_VARIANT_DEST = 4       /* backward only, D = 32, L*P = 16: destination-stationary grad_value (no float atomics,
+    MSDA_VARIANT_DEST = 4,      /* backward only, D = 32, L*P = 16: destination-stationary grad_value (no float atomics,
                                    deterministic); needs a workspace and a host copy of spatial_shapes: msda_backward_ws */
+    MSDA_VARIANT_COARSE = 5     /* forward only, bfloat16, D = 32, L*P = 16, Lq >= 4096: direct gathers for the fine levels,
+                                   the rows of the coarse levels resident in LDS per (image, head) workgroup */
 } msda_variant;
 
 /* Replaces ms_deform_attn_forward (reference models/ops/src/ms_deform_attn.h:36-53,

@@ -15,9 +15,9 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 # enum msda_dtype / msda_variant (include/rlipv2_msda.h)
 MSDA_F32, MSDA_F64, MSDA_BF16 = 0, 1, 2
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_QUAD, VARIANT_WINDOW, VARIANT_DEST = 0, 1, 2, 3, 4
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_QUAD, VARIANT_WINDOW, VARIANT_DEST, VARIANT_COARSE = 0, 1, 2, 3, 4, 5
 VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "quad": VARIANT_QUAD, "window": VARIANT_WINDOW,
-            "dest": VARIANT_DEST}
+            "dest": VARIANT_DEST, "coarse": VARIANT_COARSE}
 FLAG_GRAD_VALUE_ZEROED, FLAG_GRAD_VALUE_BF16 = 0x100, 0x200
 
 EXPORTS = (

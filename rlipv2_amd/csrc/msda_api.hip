@@ -42,6 +42,8 @@ int pick(bool backward, const Problem &p)
     // (164 vs 215 us: both are VALU-bound on the 32 unpack + 32 FMA per sample, and the tile kernel adds its
     // bounding-box / staging phases), see DESIGN.md section 4
     if (!backward && p.dtype == MSDA_F32 && window_supports(p, false)) return MSDA_VARIANT_WINDOW;
+    // (MSDA_VARIANT_COARSE -- the two coarsest levels resident in LDS -- is an explicit choice, not an automatic one:
+    //  measured at the encoder shape 160 vs 146 us on model-like locations, 176 vs 263 us on uniform ones)
     if (!backward && quad_supports(p)) return MSDA_VARIANT_QUAD;
     return MSDA_VARIANT_GENERIC;
 }
@@ -75,6 +77,7 @@ const char *msda_variant_name(int variant)
         case MSDA_VARIANT_QUAD: return "quad";
         case MSDA_VARIANT_WINDOW: return "window";
         case MSDA_VARIANT_DEST: return "dest";
+        case MSDA_VARIANT_COARSE: return "coarse";
         default: return "?";
     }
 }
@@ -141,6 +144,10 @@ int msda_forward_ex(int variant, int dtype, const void *value, const int64_t *sp
         case MSDA_VARIANT_WINDOW:
             if (!window_supports(p, false)) return MSDA_ERR_BAD_VARIANT;
             launch_window_forward(p);
+            break;
+        case MSDA_VARIANT_COARSE:
+            if (!coarse_forward_applies(p)) return MSDA_ERR_BAD_VARIANT;
+            launch_quad_forward_coarse(p);
             break;
         default: return MSDA_ERR_BAD_VARIANT;
     }

@@ -63,6 +63,8 @@ void launch_quad_backward(const Problem &p);
 void launch_quad_backward_reduce(const Problem &p);   // grad_loc / grad_aw only (no grad_value)
 void launch_tile_forward(const Problem &p);           // window-staged forward (Lq == S)
 void launch_quad_forward_fused(const Problem &p, const Fused &f);
+bool coarse_forward_applies(const Problem &p);        // bfloat16, many queries: coarse levels resident in LDS
+void launch_quad_forward_coarse(const Problem &p);
 void launch_quad_backward_reduce_fused(const Problem &p, const Fused &f);   // writes f.g_qproj instead of g_loc / g_aw
 
 bool window_supports(const Problem &p, bool backward);

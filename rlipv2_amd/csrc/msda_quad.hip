@@ -243,6 +243,180 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_forward_fused_kernel(
     if (live) Vec8<VT>::store(out + (long)qm * kD + sub * 8, acc);
 }
 
+// ------------------------------------------------------------------------------------------
+// forward with the coarse levels resident in LDS (bfloat16, many queries: the encoder's self-attention)
+// ------------------------------------------------------------------------------------------
+// The direct-gather kernels are bound by the texture path: 64 corner rows of 64 B per (query, head) = 2.9 GB per
+// batch-4 encoder call at ~64 B/clk/CU.  Half of those gathers hit the two coarsest levels, which are tiny: 1 050 + 273
+// pixels x 64 B = 85 KB per (image, head) at 800x1333.  Here a workgroup of 1 024 threads is bound to ONE (image, head)
+// for its whole life (256 / (N*M) workgroups per pair, each a contiguous range of queries), copies that pair's rows of
+// the trailing levels into LDS once, and samples them with ds_read_b128 (4x the texture path's bytes per clock);
+// levels 0 / 1 still go through the buffer loads.  Which levels are staged is decided at run time from the
+// device-resident shapes: the longest suffix of levels whose rows fit kCoarseBytes (none: everything is gathered).
+// A quad = one query (same head for the whole workgroup), quad lane j = level j of the geometry, as everywhere.
+constexpr int kCoarseBytes = 96 * 1024;
+constexpr int kCoarseBlock = 1024;
+constexpr int kCoarseZero = 128;             // bytes of zeros in front of the staged rows: where out-of-level corners read
+
+// one sample from the LDS-resident rows; `stage_pix0` = first staged pixel of the image, rows of 64 B (bfloat16)
+__device__ __forceinline__ void lds_sample_bf16(const unsigned char *rows, int stage_pix0, float x, float y, float w, int H,
+                                                int W, int start, int sub, float (&acc)[8])
+{
+    const float Hf = (float)H, Wf = (float)W;
+    float h = fmaf(y, Hf, -0.5f), v = fmaf(x, Wf, -0.5f);
+    h = fminf(fmaxf(h, -2.f), Hf + 1.f);
+    v = fminf(fmaxf(v, -2.f), Wf + 1.f);
+    const float hf = floorf(h), wf = floorf(v);
+    const float lh = h - hf, lw = v - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const int ih = (int)hf, iw = (int)wf;
+    const bool y0 = (unsigned)ih < (unsigned)H, y1 = (unsigned)(ih + 1) < (unsigned)H;
+    const bool x0 = (unsigned)iw < (unsigned)W, x1 = (unsigned)(iw + 1) < (unsigned)W;
+    const int lane = sub * 16;
+    const int base = kCoarseZero + (start - stage_pix0 + __mul24(ih, W) + iw) * 64 + lane;
+    const int a00 = (y0 && x0) ? base : lane;                       // invalid corner -> the zero slot
+    const int a01 = (y0 && x1) ? base + 64 : lane;
+    const int a10 = (y1 && x0) ? base + W * 64 : lane;
+    const int a11 = (y1 && x1) ? base + W * 64 + 64 : lane;
+    const uint4 r00 = *reinterpret_cast<const uint4 *>(rows + a00), r01 = *reinterpret_cast<const uint4 *>(rows + a01);
+    const uint4 r10 = *reinterpret_cast<const uint4 *>(rows + a10), r11 = *reinterpret_cast<const uint4 *>(rows + a11);
+    const float a = hh * w, b = lh * w;
+    Vec8<bf16_t>::fma(a * hw, r00, acc);
+    Vec8<bf16_t>::fma(a * lw, r01, acc);
+    Vec8<bf16_t>::fma(b * hw, r10, acc);
+    Vec8<bf16_t>::fma(b * lw, r11, acc);
+}
+
+// number of trailing levels whose rows fit the LDS budget (0..kL) and the first staged pixel
+__device__ __forceinline__ int coarse_levels(const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts, int S,
+                                             int &pix0)
+{
+    int n = 0;
+    pix0 = S;
+#pragma unroll
+    for (int l = kL - 1; l >= 0; --l) {
+        const int st = (int)starts[l];
+        if (n == kL - 1 - l && (S - st) * 64 + kCoarseZero <= kCoarseBytes) { n = kL - l; pix0 = st; }
+    }
+    return n;
+}
+
+// REFDIM = 0: float32 sampling_loc / attn_weight operands (the B0 signature); 2 / 4: the module's geometry as the
+// prologue (raw projection rows + reference points), SAVE: write the float32 locations / weights for the backward
+template <int REFDIM, bool SAVE, int BLOCK = kCoarseBlock>
+__global__ __launch_bounds__(BLOCK, 4) void quad_forward_coarse_kernel(
+    const bf16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const float *__restrict__ loc, const float *__restrict__ aw, const bf16_t *__restrict__ qproj,
+    const float *__restrict__ ref, int N, int S, int M, int Lq, int wgs_per_pair, unsigned value_bytes,
+    bf16_t *__restrict__ out, float *__restrict__ loc_save, float *__restrict__ aw_save, int max_staged)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char coarse_lds[];
+    const int tid = threadIdx.x;
+    // XCD-aware placement (hardware block b runs on XCD b % 8): all workgroups of one (image, head) pair on ONE XCD,
+    // so that an XCD's L2 holds the fine-level rows of pairs / 8 pairs only.  Bijective for any grid; speed only.
+    int pair, part;
+    {
+        const int pairs = N * M, b = blockIdx.x;
+        if ((pairs & 15) == 0 && (M & 1) == 0) {
+            // ... and the two heads sharing a 128-byte line of a value row ([S, M, 32] bfloat16: 64 B per head) on the
+            // SAME XCD, so that every line an L2 fetches is used whole
+            const int idx = b >> 3, k = idx / wgs_per_pair;
+            const int g = (b & 7) + 8 * (k >> 1);                 // (image, head pair) group
+            pair = (g / (M >> 1)) * M + 2 * (g % (M >> 1)) + (k & 1);
+            part = idx % wgs_per_pair;
+        } else if ((pairs & 7) == 0) {
+            const int idx = b >> 3;
+            pair = (b & 7) + 8 * (idx / wgs_per_pair);
+            part = idx % wgs_per_pair;
+        } else {
+            pair = b / wgs_per_pair;
+            part = b % wgs_per_pair;
+        }
+    }
+    const int n = pair / M, m = pair % M;
+    const int row_bytes = M * kD * 2;
+    int pix0;
+    int staged = coarse_levels(shapes, starts, S, pix0);             // levels kL - staged .. kL - 1 are in LDS
+    if (MSDA_DBG(1) && staged > max_staged) {                        // ablation builds: fewer (or no) staged levels
+        staged = max_staged;
+        pix0 = staged > 0 ? (int)starts[kL - staged] : S;
+    }
+    if (tid < kCoarseZero / 4) reinterpret_cast<int *>(coarse_lds)[tid] = 0;
+    {
+        const int pieces = (S - pix0) * 4;                            // 16-byte pieces of this head's 64-byte rows
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(value)
+                                   + ((size_t)n * S + pix0) * row_bytes + (size_t)m * 64;
+        for (int i = tid; i < pieces; i += BLOCK)
+            *reinterpret_cast<uint4 *>(coarse_lds + kCoarseZero + i * 16) =
+                *reinterpret_cast<const uint4 *>(src + (size_t)(i >> 2) * row_bytes + (i & 3) * 16);
+    }
+    __syncthreads();
+    const unsigned lane_base = (unsigned)n * (unsigned)S * (unsigned)row_bytes + (unsigned)(m * kD) * 2u;
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)value, 0, value_bytes, 0x00020000);
+    const int per = (Lq + wgs_per_pair - 1) / wgs_per_pair;
+    const int q_lo = part * per, q_hi = min(Lq, q_lo + per);
+    const int sub = tid & 3;
+    const unsigned lane_byte = lane_base + (unsigned)(sub * 16);
+    // (B0-signature operands: the next iteration's locations / weights travel while this one samples -- the 16 waves of
+    //  the workgroup start together and stay roughly in phase, nothing else would hide that latency)
+    float4 nla = make_float4(0.f, 0.f, 0.f, 0.f), nlb = nla, nwa = nla;
+    auto fetch = [&](int q0_) {
+        const int q_ = min(q0_ + (tid >> 2), q_hi - 1);
+        const long qm_ = ((long)n * Lq + q_) * M + m;
+        const float4 *loc4 = reinterpret_cast<const float4 *>(loc) + qm_ * 8 + sub * 2;
+        nla = loc4[0]; nlb = loc4[1];
+        nwa = reinterpret_cast<const float4 *>(aw)[qm_ * 4 + sub];
+    };
+    if (REFDIM == 0 && q_lo < q_hi) fetch(q_lo);
+    for (int q0 = q_lo; q0 < q_hi; q0 += BLOCK / 4) {
+        int q = q0 + (tid >> 2);
+        const bool live = q < q_hi;
+        q = live ? q : q_hi - 1;                                      // keep whole quads converged for the DPP broadcasts
+        const long rowi = (long)n * Lq + q;                           // (image, query)
+        const long qm = rowi * M + m;
+        float4 la, lb, wa;
+        if (REFDIM == 0) {
+            la = nla; lb = nlb; wa = nwa;
+            if (q0 + BLOCK / 4 < q_hi) fetch(q0 + BLOCK / 4);
+        } else {
+            constexpr int RD = REFDIM == 0 ? 2 : REFDIM;
+            float o[8], w[4];
+            geom::forward<bf16_t, RD>(qproj + rowi * (M * 48), ref + rowi * (kL * RD), shapes, m, M, sub, o, w);
+            la = make_float4(o[0], o[1], o[2], o[3]); lb = make_float4(o[4], o[5], o[6], o[7]);
+            wa = make_float4(w[0], w[1], w[2], w[3]);
+            if (SAVE && live) {
+                float4 *loc4 = reinterpret_cast<float4 *>(loc_save) + qm * 8 + sub * 2;
+                loc4[0] = la;
+                loc4[1] = lb;
+                reinterpret_cast<float4 *>(aw_save)[qm * 4 + sub] = wa;
+            }
+        }
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // (two loops, one code path each: a single loop with a branch keeps both paths' registers alive and spills)
+#pragma unroll 1
+        for (int l = 0; l < kL - staged; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
+            fwd_sample<bf16_t>(vr, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start, row_bytes, lane_byte, acc);
+            fwd_sample<bf16_t>(vr, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start, row_bytes, lane_byte, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            fwd_sample<bf16_t>(vr, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, row_bytes, lane_byte, acc);
+            fwd_sample<bf16_t>(vr, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, row_bytes, lane_byte, acc);
+            quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int l = kL - staged; l < kL; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], start = (int)starts[l];
+            lds_sample_bf16(coarse_lds, pix0, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, start, sub, acc);
+            lds_sample_bf16(coarse_lds, pix0, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, start, sub, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_sample_bf16(coarse_lds, pix0, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, start, sub, acc);
+            lds_sample_bf16(coarse_lds, pix0, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, start, sub, acc);
+            quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
+        }
+        if (live) Vec8<bf16_t>::store(out + qm * kD + sub * 8, acc);
+    }
+}
+
 // Geometry-sharing variant of the direct-gather forward.  In the kernel above every lane of a quad repeats
 // the same ~45 instructions of sample geometry (pixel coordinates, bounds, corner offsets, bilinear x
 // attention weights) for each of the 16 samples, although only the 8 channels differ between the lanes.
@@ -740,6 +914,48 @@ bool quad_supports(const Problem &p)
     return true;
 }
 
+// the coarse-levels-in-LDS forward pays once a workgroup's staging (<= 96 KB) is spread over thousands of queries
+bool coarse_forward_applies(const Problem &p)
+{
+    return p.dtype == MSDA_BF16 && quad_supports(p) && p.Lq >= 4096 && p.N * p.M <= 256;
+}
+
+static void launch_coarse_forward(const Problem &p, const Fused *f)
+{
+    const int pairs = p.N * p.M;
+    const int wgs = 256 / pairs > 0 ? 256 / pairs : 1;
+    const dim3 grid(pairs * wgs), block(kCoarseBlock);
+#define MSDA_COARSE(RD, SAVE)                                                                                         \
+    hipLaunchKernelGGL((quad_forward_coarse_kernel<RD, SAVE>), grid, block, kCoarseBytes, p.stream,                  \
+                       (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,       \
+                       (const bf16_t *)(f ? f->qproj : nullptr), f ? f->ref : nullptr, p.N, p.S, p.M, p.Lq, wgs,     \
+                       value_bytes(p), (bf16_t *)p.out, f ? f->loc_save : nullptr, f ? f->aw_save : nullptr,         \
+                       ablation_env("RLIPV2_COARSE_STAGED", kL))
+    static bool attr_set = false;
+    if (!attr_set) {      // more than 64 KB of dynamic LDS has to be asked for, once per kernel
+        (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
+        (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
+        (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
+        (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
+        (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
+        attr_set = true;
+    }
+    if (!f && ablation_env("RLIPV2_COARSE_BLOCK", 1024) == 256) {      // ablation: small one-shot workgroups, nothing staged
+        const int w256 = wgs * 4;
+        hipLaunchKernelGGL((quad_forward_coarse_kernel<0, false, 256>), dim3(pairs * w256), dim3(256), kCoarseBytes, p.stream,
+                           (const bf16_t *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,
+                           (const bf16_t *)nullptr, (const float *)nullptr, p.N, p.S, p.M, p.Lq, w256, value_bytes(p),
+                           (bf16_t *)p.out, (float *)nullptr, (float *)nullptr, 0);
+        return;
+    }
+    if (!f) MSDA_COARSE(0, false);
+    else if (f->refdim == 2) { if (f->loc_save) MSDA_COARSE(2, true); else MSDA_COARSE(2, false); }
+    else { if (f->loc_save) MSDA_COARSE(4, true); else MSDA_COARSE(4, false); }
+#undef MSDA_COARSE
+}
+
+void launch_quad_forward_coarse(const Problem &p) { launch_coarse_forward(p, nullptr); }
+
 void launch_quad_forward(const Problem &p)
 {
     const int dbg = ablation_env("RLIPV2_MSDA_DEBUG", 0);       // ablation builds only
@@ -853,6 +1069,10 @@ void launch_quad_backward_reduce(const Problem &p)
 // ---- fused sampling geometry (msda_fused_forward / msda_fused_backward_ws) ---------------------------------------------
 void launch_quad_forward_fused(const Problem &p, const Fused &f)
 {
+    if (coarse_forward_applies(p) && ablation_env("RLIPV2_MSDA_FWD_COARSE", 0)) {     // (ablation builds: see msda_api.hip pick())
+        launch_coarse_forward(p, &f);
+        return;
+    }
     const int total_qm = p.N * p.Lq * p.M;
     const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
     const bool save = f.loc_save != nullptr;

@@ -76,6 +76,8 @@ def variants_for(D, L, P, tdtype, S=0, Lq=-1):
         # "window" backward = reduce kernel + sorted scatter kernel; valid for any Lq
         v.append(("window" if (WINDOW_FWD and S == Lq) else "quad", "window" if WINDOW_BWD else "quad"))
         v.append(("quad", "dest"))       # destination-stationary grad_value (msda_dest.hip)
+        if tdtype == torch.bfloat16 and Lq >= 4096:
+            v.append(("coarse", "dest"))  # forward with the coarse levels resident in LDS (msda_quad.hip)
     v.append(("auto", "auto"))
     return v
 
@@ -612,3 +614,27 @@ def test_fused_geometry_route_vs_oracle(dtype):
     keep = np.concatenate([keep, np.ones((N, Lq, M * L * P), dtype=bool)], -1)
     err = np.abs(gq - ref_gq)[keep].max()
     assert err <= (2 ** -6 if dtype == torch.bfloat16 else 1e-3) * np.abs(ref_gq).max()
+
+
+def test_coarse_lds_forward_is_bit_identical_to_the_direct_gather_forward():
+    """quad_forward_coarse_kernel (rows of the trailing levels in LDS; an explicit variant, faster than the direct
+    gathers on spread-out locations, slower on model-like ones) does the same arithmetic in the same order as quad_forward_kernel: bit-identical outputs,
+    also for locations outside [0, 1], NaN locations, and a pyramid whose two coarse levels do NOT fit the LDS budget
+    together (only the last one is staged then)."""
+    for pyramid in (FULL, ((60, 70), (40, 50), (34, 40), (20, 24))):     # second: 1 360 + 480 rows: only level 3 staged
+        g = torch.Generator(device=DEV).manual_seed(5)
+        shapes = torch.tensor(pyramid, dtype=torch.long, device=DEV)
+        starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+        S = int(shapes.prod(1).sum())
+        N, M, D, L, P, Lq = 2, 8, 32, 4, 4, 5003
+        value = torch.randn(N, S, M, D, device=DEV, generator=g).bfloat16()
+        loc = torch.rand(N, Lq, M, L, P, 2, device=DEV, generator=g) * 1.3 - 0.15
+        loc[0, 17, 3, 2, 1, 0] = float("nan")
+        aw = torch.softmax(torch.randn(N, Lq, M, L * P, device=DEV, generator=g), -1).view(N, Lq, M, L, P)
+        outs = []
+        for variant in ("quad", "coarse"):
+            msda.set_variant(variant, "auto")
+            outs.append(msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64))
+        msda.set_variant("auto")
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1])

@@ -27,6 +27,80 @@ from .blocks import MultiBranchFusion
 
 GATINGS_SCALAR = ("VXAc", "Vtanh")
 
+# the fused HIP kernel of the attention core (csrc/alif_attention.hip); tests switch it off to compare both routes
+fused_attention = True
+
+
+class AlifAttentionFunction(torch.autograd.Function):
+    """(q, k, values_l_t, values_v_t) -> (out_v, out_l): the bi-directional attention core of
+    RLIPv2_BiMultiHeadAttention (fuse_helper.py:395-462) as one HIP launch (csrc/alif_attention.hip, C ABI
+    include/rlipv2_alif.h).  q [B, Tv, E] (scaled), k [B, Tl, E], values_l_t [B, E, 64], values_v_t [B, E, Tvp]
+    (value projections transposed, see the header).  The backward pass is written out with PyTorch matrix products on
+    the probabilities the kernel saved: 8 small batched GEMMs + 2 softmax-backward expressions."""
+
+    @staticmethod
+    def forward(ctx, q, k, vlt, vvt, H, p_drop, training):
+        from . import _lib
+        if not q.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        B, Tv, E = q.shape
+        Tl = k.shape[1]
+        L = _lib.lib()
+        q, k, vlt, vvt = q.contiguous(), k.contiguous(), vlt.contiguous(), vvt.contiguous()
+        out_v = torch.empty_like(q)
+        out_l = torch.empty_like(k)
+        probs_v = torch.empty((B, H, Tv, Tl), dtype=torch.bfloat16, device=q.device)
+        probs_l = torch.empty((B, H, Tl, Tv), dtype=torch.bfloat16, device=q.device)
+        drop = training and p_drop > 0
+        keep_v = keep_l = None
+        if drop:                                            # Q6: attention-probability dropout, both directions
+            keep_v = (torch.rand((B, H, Tv, Tl), device=q.device) >= p_drop).to(torch.uint8)
+            keep_l = (torch.rand((B, H, Tl, Tv), device=q.device) >= p_drop).to(torch.uint8)
+        scale = 1.0 / (1.0 - p_drop) if drop else 1.0
+        st = L.alif_attention_forward_bf16(q.data_ptr(), k.data_ptr(), vlt.data_ptr(), vvt.data_ptr(),
+                                           keep_v.data_ptr() if drop else None, keep_l.data_ptr() if drop else None,
+                                           scale, B, H, Tv, Tl, out_v.data_ptr(), out_l.data_ptr(), probs_v.data_ptr(),
+                                           probs_l.data_ptr(), torch.cuda.current_stream(q.device).cuda_stream)
+        if st:
+            raise RuntimeError("alif_attention_forward: " + _lib.strerror(st))
+        ctx.save_for_backward(q, k, vlt, vvt, probs_v, probs_l, keep_v, keep_l)
+        ctx.H, ctx.scale = H, scale
+        return out_v, out_l
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out_v, g_out_l):
+        q, k, vlt, vvt, pv, pl, keep_v, keep_l = ctx.saved_tensors
+        H = ctx.H
+        B, Tv, E = q.shape
+        Tl, hd = k.shape[1], E // H
+        heads = lambda t, T: t.reshape(B, T, H, hd).transpose(1, 2)                # [B, H, T, hd] views
+        g_ov, g_ol = heads(g_out_v, Tv), heads(g_out_l, Tl)
+        vl_t = vlt.view(B, H, hd, -1)[..., :Tl]                                    # [B, H, hd, Tl]
+        vv_t = vvt.view(B, H, hd, -1)[..., :Tv]                                    # [B, H, hd, Tv]
+        pv_d, pl_d = pv, pl
+        if keep_v is not None:
+            pv_d = pv * keep_v * ctx.scale
+            pl_d = pl * keep_l * ctx.scale
+        # value projections (transposed layout): d V^T = g_out^T P
+        g_vlt = torch.zeros_like(vlt).view(B, H, hd, -1)
+        g_vlt[..., :Tl] = torch.matmul(g_ov.transpose(-1, -2), pv_d)
+        g_vvt = torch.zeros_like(vvt).view(B, H, hd, -1)
+        g_vvt[..., :Tv] = torch.matmul(g_ol.transpose(-1, -2), pl_d)
+        # probabilities -> logits (float32)
+        d_pv = torch.matmul(g_ov, vl_t).float()                                    # [B, H, Tv, Tl]
+        d_pl = torch.matmul(g_ol, vv_t).float()                                    # [B, H, Tl, Tv]
+        if keep_v is not None:
+            d_pv = d_pv * keep_v * ctx.scale
+            d_pl = d_pl * keep_l * ctx.scale
+        pvf, plf = pv.float(), pl.float()
+        d_s = pvf * (d_pv - (pvf * d_pv).sum(-1, keepdim=True))
+        d_s = d_s + (plf * (d_pl - (plf * d_pl).sum(-1, keepdim=True))).transpose(-1, -2)
+        d_s = d_s.to(q.dtype)
+        g_q = torch.matmul(d_s, heads(k, Tl)).transpose(1, 2).reshape(B, Tv, E)
+        g_k = torch.matmul(d_s.transpose(-1, -2), heads(q, Tv)).transpose(1, 2).reshape(B, Tl, E)
+        return g_q, g_k, g_vlt.view_as(vlt), g_vvt.view_as(vvt), None, None, None
+
 
 class RLIPv2_BiMultiHeadAttention(nn.Module):
     """One set of logits q(v+pos) . k(l)^T feeds both directions: vision attends over language
@@ -69,7 +143,37 @@ class RLIPv2_BiMultiHeadAttention(nn.Module):
             x = torch.clamp(x, max=50000)
         return x
 
+    def _fused_ok(self, v, l):
+        from . import _lib
+        return (fused_attention and v.is_cuda and v.dtype == torch.bfloat16 and l.dtype == torch.bfloat16
+                and not (self.stable_softmax_2d or self.clamp_min_for_underflow or self.clamp_max_for_overflow)
+                and not torch.is_autocast_enabled()
+                and bool(_lib.lib().alif_attention_supported(v.shape[0], self.num_heads, v.shape[1], l.shape[1],
+                                                             self.head_dim)))
+
+    def _forward_fused(self, v, l, v_pos):
+        """The attention core on the HIP kernel.  Host side: the four projections as library GEMMs -- the two value
+        projections with swapped operands, i.e. written channel-major, which is the layout the kernel's P V products
+        read straight from memory -- one launch for the core, the two output projections."""
+        from . import _lib
+        B, Tv, _ = v.shape
+        Tl = l.shape[1]
+        q = self.v_proj(v if v_pos is None else v + v_pos) * self.scale
+        k = self.l_proj(l)
+        Tvp = _lib.lib().alif_attention_padded_tv(Tv)
+        l_pad = F.pad(l, (0, 0, 0, 64 - Tl)) if Tl < 64 else l          # padded tokens project to the bias: finite,
+        v_pad = F.pad(v, (0, 0, 0, Tvp - Tv)) if Tvp > Tv else v        # and their probabilities are zero
+        wl, wv = self.values_l_proj, self.values_v_proj
+        vlt = torch.baddbmm(wl.bias.view(1, -1, 1), wl.weight.unsqueeze(0).expand(B, -1, -1), l_pad.transpose(1, 2))
+        vvt = torch.baddbmm(wv.bias.view(1, -1, 1), wv.weight.unsqueeze(0).expand(B, -1, -1), v_pad.transpose(1, 2))
+        out_v, out_l = AlifAttentionFunction.apply(q, k, vlt, vvt, self.num_heads, self.dropout, self.training)
+        return self.out_v_proj(out_v), self.out_l_proj(out_l)
+
     def forward(self, v, l, v_pos=None, attention_mask_l=None, attention_mask_v=None):
+        # (Q1: bool masks only add a constant to every logit, which no softmax sees; other mask dtypes do mask)
+        if ((attention_mask_l is None or attention_mask_l.dtype == torch.bool)
+                and (attention_mask_v is None or attention_mask_v.dtype == torch.bool) and self._fused_ok(v, l)):
+            return self._forward_fused(v, l, v_pos)
         B, Tv, _ = v.shape
         Tl = l.shape[1]
         q = self._heads(self.v_proj(v if v_pos is None else v + v_pos) * self.scale)    # [B,H,Tv,hd]

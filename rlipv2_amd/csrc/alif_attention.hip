@@ -1,0 +1,268 @@
+// alif_attention.hip -- the bi-directional attention core of the ALIF fusion (RLIPv2_BiMultiHeadAttention, reference
+// models/fuse_helper.py:365-466) as ONE kernel for gfx950: both directions share the logits q k^T; the vision side
+// takes a softmax over the text tokens, the language side a softmax over the vision tokens of the transposed logits
+// minus their row maximum (:399-400), each followed by attention dropout and its value product.
+//
+//   S   = Q K^T                      [Tv, Tl]   (Q already scaled and carrying the positional term)
+//   P_v = softmax_j(S)               [Tv, Tl]   out_v = drop(P_v) V_l      [Tv, 256]
+//   P_l = softmax_i(S^T)             [Tl, Tv]   out_l = drop(P_l) V_v      [Tl, 256]
+//
+// (The reference adds a constant 1.0 to every logit when its bool masks arrive, SURVEY.md Q1: softmax is unchanged.
+//  The optional clamps / stable_softmax_2d are off in every RLIPv2 script; the host falls back to PyTorch for them.)
+//
+// One workgroup (4 waves) per (image, head): with `fusion_last_vis` the problem is Tv = 273 vision tokens of the last
+// level x Tl = 64 label texts x head_dim 256 -- 27 MFLOP, launch-bound as ~10 PyTorch launches.  All three products
+// run on v_mfma_f32_32x32x16_bf16 with operands loaded straight from global memory in fragment layout (16 B per
+// lane): Q / K rows are k-contiguous as they come out of the projections, and the host hands the value projections
+// over TRANSPOSED ([E, tokens], a GEMM with swapped operands), which makes them k-contiguous for P V as well -- no
+// LDS transposes.  The logits live in LDS as float32 (both softmaxes read them, row-wise and column-wise), the
+// probabilities as bfloat16 in the A-fragment layout of their product.  Probabilities BEFORE dropout are also written
+// to global memory for the backward pass.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rlipv2_alif.h"
+#include "../../include/rlipv2_msda.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int HD = 256;                 // head dimension (embed_dim 2048 / 8 heads)
+constexpr int TL = 64;                  // text tokens, padded
+constexpr int TV_MAX = 288;             // vision tokens, padded to a multiple of 32
+constexpr int THREADS = 256;
+constexpr int S_STRIDE = TL + 1;        // floats per row of the logits (odd: a thread per row reads conflict-free)
+constexpr int PV_STRIDE = TL + 8;       // bf16 per row of P_v  [Tv][Tl]
+constexpr int PL_STRIDE = TV_MAX + 8;   // bf16 per row of P_l  [Tl][Tv]
+constexpr int OFF_PV = TV_MAX * S_STRIDE * 4;
+constexpr int OFF_PL = OFF_PV + TV_MAX * PV_STRIDE * 2;
+constexpr int OFF_RED = OFF_PL + TL * PL_STRIDE * 2;          // float [2][4][TL]: partial max / sum of the column softmax
+constexpr int LDS_BYTES = OFF_RED + 2 * 4 * TL * 4;
+
+__device__ __forceinline__ float bf(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t rne(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+union Frag {
+    uint4 u;
+    bf16x8 v;
+};
+
+__device__ __forceinline__ Frag load_frag(const uint16_t *p, bool ok)
+{
+    Frag f;
+    f.u = ok ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0u, 0u, 0u, 0u);
+    return f;
+}
+
+// C/D layout of v_mfma_f32_32x32x16: lane -> column (lane & 31), register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <bool DROP>
+__global__ __launch_bounds__(THREADS) void alif_forward_kernel(
+    const uint16_t *__restrict__ q, const uint16_t *__restrict__ k, const uint16_t *__restrict__ vlT,
+    const uint16_t *__restrict__ vvT, const uint8_t *__restrict__ keep_v, const uint8_t *__restrict__ keep_l,
+    float keep_scale, int H, int Tv, int Tl, int Tvp, uint16_t *__restrict__ out_v, uint16_t *__restrict__ out_l,
+    uint16_t *__restrict__ p_v, uint16_t *__restrict__ p_l)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float *S = reinterpret_cast<float *>(lds);
+    uint16_t *Pv = reinterpret_cast<uint16_t *>(lds + OFF_PV);
+    uint16_t *Pl = reinterpret_cast<uint16_t *>(lds + OFF_PL);
+    float *red = reinterpret_cast<float *>(lds + OFF_RED);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = H * HD;
+    const int li = lane & 31, kg = (lane >> 5) * 8;
+    const int row_tiles = Tvp / 32;
+    const uint16_t *qb = q + (size_t)b * Tv * E + h * HD;
+    const uint16_t *kb = k + (size_t)b * Tl * E + h * HD;
+    const uint16_t *vlb = vlT + ((size_t)b * E + h * HD) * TL;
+    const uint16_t *vvb = vvT + ((size_t)b * E + h * HD) * Tvp;
+    const size_t bh = (size_t)b * H + h;
+
+    // ---- phase 1: S = Q K^T, a wave per 32-row tile, both 32-column tiles -----------------------------------------
+    for (int rt = wave; rt < row_tiles; rt += 4) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        const int i = rt * 32 + li;
+#pragma unroll 4
+        for (int ks = 0; ks < HD / 16; ++ks) {
+            const Frag a = load_frag(qb + (size_t)i * E + ks * 16 + kg, i < Tv);
+            const Frag b0 = load_frag(kb + (size_t)li * E + ks * 16 + kg, li < Tl);
+            const Frag b1 = load_frag(kb + (size_t)(32 + li) * E + ks * 16 + kg, 32 + li < Tl);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b0.v, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b1.v, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[(rt * 32 + acc_row(r, lane)) * S_STRIDE + c * 32 + li] = acc[c][r];
+    }
+    __syncthreads();
+
+    // ---- phase 2a: P_v = softmax over the text tokens, a thread per vision row --------------------------------------
+    for (int i = tid; i < Tvp; i += THREADS) {
+        uint16_t *prow = Pv + i * PV_STRIDE;
+        if (i < Tv) {
+            const float *srow = S + i * S_STRIDE;
+            float mx = -INFINITY;
+            for (int j = 0; j < Tl; ++j) mx = fmaxf(mx, srow[j]);
+            float sum = 0.f;
+            for (int j = 0; j < Tl; ++j) sum += __expf(srow[j] - mx);
+            const float inv = 1.f / sum;
+            uint16_t *g = p_v + (bh * Tv + i) * Tl;
+            const uint8_t *kp = DROP ? keep_v + (bh * Tv + i) * Tl : nullptr;
+            for (int j = 0; j < TL; ++j) {
+                uint16_t pb = 0;
+                if (j < Tl) {
+                    pb = rne(__expf(srow[j] - mx) * inv);          // the probability as bfloat16 (what the backward sees)
+                    g[j] = pb;
+                    if (DROP) pb = kp[j] ? rne(bf(pb) * keep_scale) : (uint16_t)0;
+                }
+                prow[j] = pb;
+            }
+        } else {
+            for (int j = 0; j < TL; ++j) prow[j] = 0;
+        }
+    }
+    // ---- phase 2b: P_l = softmax over the vision tokens of S^T (minus its row maximum: the softmax's own shift) -----
+    {
+        const int j = tid & 63, part = tid >> 6;
+        float mx = -INFINITY;
+        if (j < Tl)
+            for (int i = part; i < Tv; i += 4) mx = fmaxf(mx, S[i * S_STRIDE + j]);
+        red[part * TL + j] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[j], red[TL + j]), fmaxf(red[2 * TL + j], red[3 * TL + j]));
+        float sum = 0.f;
+        if (j < Tl)
+            for (int i = part; i < Tv; i += 4) sum += __expf(S[i * S_STRIDE + j] - mx);
+        red[(4 + part) * TL + j] = sum;
+        __syncthreads();
+        const float inv = 1.f / (red[4 * TL + j] + red[5 * TL + j] + red[6 * TL + j] + red[7 * TL + j]);
+        uint16_t *prow = Pl + j * PL_STRIDE;
+        for (int i = part; i < Tvp; i += 4) {
+            uint16_t pb = 0;
+            if (j < Tl && i < Tv) {
+                pb = rne(__expf(S[i * S_STRIDE + j] - mx) * inv);
+                p_l[(bh * Tl + j) * Tv + i] = pb;
+                if (DROP) pb = keep_l[(bh * Tl + j) * Tv + i] ? rne(bf(pb) * keep_scale) : (uint16_t)0;
+            }
+            prow[i] = pb;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: out_v = P_v V_l  (K = 64 text tokens), a wave per 32-row tile, 8 column tiles of 32 channels ------
+    for (int rt = wave; rt < row_tiles; rt += 4) {
+        Frag a[TL / 16];
+#pragma unroll
+        for (int ks = 0; ks < TL / 16; ++ks)
+            a[ks].u = *reinterpret_cast<const uint4 *>(Pv + (rt * 32 + li) * PV_STRIDE + ks * 16 + kg);
+#pragma unroll 2
+        for (int nt = 0; nt < HD / 32; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const uint16_t *vrow = vlb + (size_t)(nt * 32 + li) * TL;
+#pragma unroll
+            for (int ks = 0; ks < TL / 16; ++ks) {
+                const Frag bf_ = load_frag(vrow + ks * 16 + kg, true);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks].v, bf_.v, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = rt * 32 + acc_row(r, lane);
+                if (i < Tv) out_v[((size_t)b * Tv + i) * E + h * HD + nt * 32 + li] = rne(acc[r]);
+            }
+        }
+    }
+    // ---- phase 4: out_l = P_l V_v  (K = Tv vision tokens), wave w: channels [64 w, 64 w + 64), both text row tiles -----
+    {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jt][c][r] = 0.f;
+        const uint16_t *v0 = vvb + (size_t)(wave * 64 + li) * Tvp, *v1 = v0 + (size_t)32 * Tvp;
+#pragma unroll 2
+        for (int ks = 0; ks < Tvp / 16; ++ks) {
+            Frag a0, a1;
+            a0.u = *reinterpret_cast<const uint4 *>(Pl + li * PL_STRIDE + ks * 16 + kg);
+            a1.u = *reinterpret_cast<const uint4 *>(Pl + (32 + li) * PL_STRIDE + ks * 16 + kg);
+            const Frag b0 = load_frag(v0 + ks * 16 + kg, true), b1 = load_frag(v1 + ks * 16 + kg, true);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, b0.v, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, b1.v, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b0.v, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b1.v, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jt * 32 + acc_row(r, lane);
+                    if (j < Tl) out_l[((size_t)b * Tl + j) * E + h * HD + wave * 64 + c * 32 + li] = rne(acc[jt][c][r]);
+                }
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int alif_attention_supported(int B, int H, int Tv, int Tl, int head_dim)
+{
+    return B > 0 && H > 0 && head_dim == HD && Tl >= 1 && Tl <= TL && Tv >= 1 && Tv <= TV_MAX &&
+           (long)B * H < (1L << 20);
+}
+
+int alif_attention_padded_tv(int Tv) { return (Tv + 31) / 32 * 32; }
+
+int alif_attention_forward_bf16(const void *q, const void *k, const void *values_l_t, const void *values_v_t,
+                                const void *keep_v, const void *keep_l, float keep_scale, int B, int H, int Tv, int Tl,
+                                void *out_v, void *out_l, void *probs_v, void *probs_l, void *stream)
+{
+    if (!alif_attention_supported(B, H, Tv, Tl, HD)) return MSDA_ERR_BAD_SHAPE;
+    if (!q || !k || !values_l_t || !values_v_t || !out_v || !out_l || !probs_v || !probs_l) return MSDA_ERR_NULL_POINTER;
+    if ((keep_v == nullptr) != (keep_l == nullptr)) return MSDA_ERR_NULL_POINTER;
+    if (!(aligned16(q) && aligned16(k) && aligned16(values_l_t) && aligned16(values_v_t))) return MSDA_ERR_ALIGNMENT;
+    const int Tvp = alif_attention_padded_tv(Tv);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {      // more than 64 KB of dynamic LDS has to be asked for
+        (void)hipFuncSetAttribute((const void *)alif_forward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)alif_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    (void)hipGetLastError();
+    if (keep_v)
+        hipLaunchKernelGGL(alif_forward_kernel<true>, dim3(B * H), dim3(THREADS), LDS_BYTES, s, (const uint16_t *)q,
+                           (const uint16_t *)k, (const uint16_t *)values_l_t, (const uint16_t *)values_v_t,
+                           (const uint8_t *)keep_v, (const uint8_t *)keep_l, keep_scale, H, Tv, Tl, Tvp, (uint16_t *)out_v,
+                           (uint16_t *)out_l, (uint16_t *)probs_v, (uint16_t *)probs_l);
+    else
+        hipLaunchKernelGGL(alif_forward_kernel<false>, dim3(B * H), dim3(THREADS), LDS_BYTES, s, (const uint16_t *)q,
+                           (const uint16_t *)k, (const uint16_t *)values_l_t, (const uint16_t *)values_v_t,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, 1.f, H, Tv, Tl, Tvp, (uint16_t *)out_v,
+                           (uint16_t *)out_l, (uint16_t *)probs_v, (uint16_t *)probs_l);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -498,3 +498,90 @@ def test_graphed_step_cache_recaptures_per_bucket():
         _, total = g.run(*batch)
         torch.testing.assert_close(total.float(), eager, rtol=3e-2, atol=3e-2)
     assert cache.captures == 2 and len(cache.graphs) == 2
+
+
+# ---- ALIF attention core on the HIP kernel (csrc/alif_attention.hip) -----------------------------------------------------
+def _vlfuse_bf16(gating):
+    g = dev(C.load(f"vlfuse_{gating}"))
+    m = alif.RLIPv2_VLFuse(parseda.default_args(gating_mechanism=gating)).eval()
+    fill_closed_form(m)
+    return g, m.to(DEV).to(torch.bfloat16)
+
+
+def _run_vlfuse(m, g, fused):
+    alif.fused_attention = fused
+    try:
+        v = g["v"].to(torch.bfloat16).clone().requires_grad_(True)
+        l = g["l"].to(torch.bfloat16).clone().requires_grad_(True)
+        out = m({"visual": {"src": v, "padding_mask": g["vmask"], "pos": g["pos"].to(torch.bfloat16)},
+                 "lang": {"hidden": l, "masks": g["lmask"]}})
+        ov, ol = out["visual"]["src"], out["lang"]["hidden"]
+        (ov.float() * g["gv"]).sum().add((ol.float() * g["gl"]).sum()).backward()
+        grads = {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+        for p in m.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        return ov.float(), ol.float(), v.grad.float(), l.grad.float(), grads
+    finally:
+        alif.fused_attention = True
+
+
+@pytest.mark.parametrize("gating", ["VXAc", "XGating"])
+def test_alif_fused_attention_kernel_vs_reference_golden_and_pytorch_route(gating):
+    """RLIPv2_VLFuse in bfloat16 with the attention core on the HIP kernel (one launch: q k^T, both softmaxes, both
+    value products on MFMA) against (a) the reference-generated float32 golden (models/fuse_helper.py:983-1096) within
+    the bfloat16 band the PyTorch route itself keeps, and (b) the PyTorch route of the same bfloat16 module: outputs
+    and input / parameter gradients (the backward of the fused route is hand-written from the saved probabilities)."""
+    g, m = _vlfuse_bf16(gating)
+    assert m.b_attn.attn._fused_ok(g["v"].to(torch.bfloat16), g["l"].to(torch.bfloat16))
+    fo = _run_vlfuse(m, g, True)
+    po = _run_vlfuse(m, g, False)
+    refs = (g["out_v"], g["out_l"], g["g_v"], g["g_l"])
+    for name, a, b, ref in zip(("out_v", "out_l", "g_v", "g_l"), fo[:4], po[:4], refs):
+        scale = float(ref.abs().max())
+        err_f, err_p = float((a - ref).abs().max()) / scale, float((b - ref).abs().max()) / scale
+        assert err_f <= max(2.0 * err_p, 2e-2), (name, err_f, err_p)      # as close to the reference as bf16 PyTorch is
+        assert float((a - b).abs().max()) / scale <= 3e-2, (name, float((a - b).abs().max()) / scale)
+    # parameter gradients: every tensor the PyTorch route differentiates, same values to bf16 accuracy
+    assert set(fo[4]) == set(po[4])
+    gmax = max(float(t.abs().max()) for t in po[4].values())
+    for n in po[4]:
+        err = float((fo[4][n] - po[4][n]).abs().max())
+        # (per tensor, or -- for the scalar gates, whose gradient is one long cancelling bf16 sum -- on the global scale)
+        assert err <= max(4e-2 * float(po[4][n].abs().max()), 5e-3 * gmax), (n, err)
+
+
+def test_alif_fused_attention_kernel_direct_vs_float64_and_dropout():
+    """The kernel alone (C ABI through AlifAttentionFunction) at the train step's shape (B=4, H=8, Tv=273, Tl=64):
+    outputs against a float64 restatement of fuse_helper.py:395-462 on the same bfloat16 inputs; with dropout the kept
+    probabilities are scaled by 1 / (1 - p), the dropped ones contribute nothing (checked through the saved masks)."""
+    torch.manual_seed(3)
+    B, H, Tv, Tl, hd = 4, 8, 273, 64, 256
+    E = H * hd
+    q = (torch.randn(B, Tv, E, device=DEV) * 0.08).bfloat16()
+    k = torch.randn(B, Tl, E, device=DEV).bfloat16()
+    vl = torch.randn(B, Tl, E, device=DEV).bfloat16()
+    vv = torch.randn(B, Tv, E, device=DEV).bfloat16()
+    Tvp = (Tv + 31) // 32 * 32
+    vlt = vl.transpose(1, 2).contiguous()
+    vvt = torch.nn.functional.pad(vv, (0, 0, 0, Tvp - Tv), value=7.0).transpose(1, 2).contiguous()   # junk in the padding
+    heads = lambda t, T: t.double().view(B, T, H, hd).transpose(1, 2)
+    S = heads(q, Tv) @ heads(k, Tl).transpose(-1, -2)
+    pv, pl = S.softmax(-1), S.transpose(-1, -2).softmax(-1)
+    ref_v = (pv @ heads(vl, Tl)).transpose(1, 2).reshape(B, Tv, E)
+    ref_l = (pl @ heads(vv, Tv)).transpose(1, 2).reshape(B, Tl, E)
+    out_v, out_l = alif.AlifAttentionFunction.apply(q, k, vlt, vvt, H, 0.1, False)
+    torch.cuda.synchronize()
+    for got, ref in ((out_v, ref_v), (out_l, ref_l)):
+        assert float((got.double() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # dropout: reproduce the kernel's output from the probabilities and masks it saved
+    qg = q.clone().requires_grad_(True)
+    out_v, out_l = alif.AlifAttentionFunction.apply(qg, k, vlt, vvt, H, 0.5, True)
+    _, _, _, _, p_v, p_l, keep_v, keep_l = out_v.grad_fn.saved_tensors
+    assert 0.4 < float(keep_v.float().mean()) < 0.6 and 0.4 < float(keep_l.float().mean()) < 0.6
+    exp_v = ((p_v.double() * keep_v * 2.0) @ heads(vl, Tl)).transpose(1, 2).reshape(B, Tv, E)
+    exp_l = ((p_l.double() * keep_l * 2.0) @ heads(vv, Tv)).transpose(1, 2).reshape(B, Tl, E)
+    assert float((out_v.double() - exp_v).abs().max()) <= 2e-2 * float(exp_v.abs().max())
+    assert float((out_l.double() - exp_l).abs().max()) <= 2e-2 * float(exp_l.abs().max())
+    (out_v.float().sum() + out_l.float().sum()).backward()
+    assert torch.isfinite(qg.grad).all()

@@ -31,6 +31,15 @@ int alif_attention_forward_bf16(const void *q, const void *k, const void *values
                                 const void *keep_v, const void *keep_l, float keep_scale, int B, int H, int Tv, int Tl,
                                 void *out_v, void *out_l, void *probs_v, void *probs_l, void *stream);
 
+/* Backward of the two softmaxes + dropouts: gradient of the shared logits d_logits [B, H, Tv, Tl] (bf16) from the saved
+ * probabilities and the gradients of the dropped probabilities d_probs_v [B, H, Tv, Tl] / d_probs_l [B, H, Tl, Tv]
+ * (bf16); with keep masks also writes the dropped probabilities P * keep * keep_scale (the A operands of the
+ * value-projection gradients).  One launch instead of ~12 elementwise / reduction launches. */
+int alif_attention_softmax_backward_bf16(const void *probs_v, const void *probs_l, const void *d_probs_v,
+                                         const void *d_probs_l, const void *keep_v, const void *keep_l, float keep_scale,
+                                         int B, int H, int Tv, int Tl, void *d_logits, void *dropped_v, void *dropped_l,
+                                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,7 @@ EXPORTS = (
     "adamw_abi_sizes", "adamw_grad_sqnorm_bf16", "adamw_step_bf16",
     # include/rlipv2_alif.h
     "alif_attention_supported", "alif_attention_padded_tv", "alif_attention_forward_bf16",
+    "alif_attention_softmax_backward_bf16",
 )
 
 _lib = None
@@ -118,6 +119,8 @@ def lib() -> ctypes.CDLL:
     L.alif_attention_supported.argtypes = [i, i, i, i, i]
     L.alif_attention_padded_tv.argtypes = [i]
     L.alif_attention_forward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, f32, i, i, i, i, vp, vp, vp, vp, vp]
+    L.alif_attention_softmax_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, f32, i, i, i, i, vp, vp, vp, vp]
+    L.alif_attention_softmax_backward_bf16.restype = i
     L.alif_attention_supported.restype = L.alif_attention_padded_tv.restype = L.alif_attention_forward_bf16.restype = i
     _lib = L
     return L

@@ -18,6 +18,7 @@ Parity-critical behaviours reproduced on purpose:
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -28,7 +29,7 @@ from .blocks import MultiBranchFusion
 GATINGS_SCALAR = ("VXAc", "Vtanh")
 
 # the fused HIP kernel of the attention core (csrc/alif_attention.hip); tests switch it off to compare both routes
-fused_attention = True
+fused_attention = os.environ.get("RLIPV2_ALIF_FUSED", "1") != "0"
 
 
 class AlifAttentionFunction(torch.autograd.Function):
@@ -54,8 +55,8 @@ class AlifAttentionFunction(torch.autograd.Function):
         drop = training and p_drop > 0
         keep_v = keep_l = None
         if drop:                                            # Q6: attention-probability dropout, both directions
-            keep_v = (torch.rand((B, H, Tv, Tl), device=q.device) >= p_drop).to(torch.uint8)
-            keep_l = (torch.rand((B, H, Tl, Tv), device=q.device) >= p_drop).to(torch.uint8)
+            keep = torch.rand((2, B, H, Tv * Tl), device=q.device) >= p_drop       # bool = one byte per entry
+            keep_v, keep_l = keep[0].view(B, H, Tv, Tl), keep[1].view(B, H, Tl, Tv)
         scale = 1.0 / (1.0 - p_drop) if drop else 1.0
         st = L.alif_attention_forward_bf16(q.data_ptr(), k.data_ptr(), vlt.data_ptr(), vvt.data_ptr(),
                                            keep_v.data_ptr() if drop else None, keep_l.data_ptr() if drop else None,
@@ -70,6 +71,7 @@ class AlifAttentionFunction(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_out_v, g_out_l):
+        from . import _lib
         q, k, vlt, vvt, pv, pl, keep_v, keep_l = ctx.saved_tensors
         H = ctx.H
         B, Tv, E = q.shape
@@ -78,28 +80,30 @@ class AlifAttentionFunction(torch.autograd.Function):
         g_ov, g_ol = heads(g_out_v, Tv), heads(g_out_l, Tl)
         vl_t = vlt.view(B, H, hd, -1)[..., :Tl]                                    # [B, H, hd, Tl]
         vv_t = vvt.view(B, H, hd, -1)[..., :Tv]                                    # [B, H, hd, Tv]
-        pv_d, pl_d = pv, pl
-        if keep_v is not None:
-            pv_d = pv * keep_v * ctx.scale
-            pl_d = pl * keep_l * ctx.scale
-        # value projections (transposed layout): d V^T = g_out^T P
-        g_vlt = torch.zeros_like(vlt).view(B, H, hd, -1)
-        g_vlt[..., :Tl] = torch.matmul(g_ov.transpose(-1, -2), pv_d)
-        g_vvt = torch.zeros_like(vvt).view(B, H, hd, -1)
-        g_vvt[..., :Tv] = torch.matmul(g_ol.transpose(-1, -2), pl_d)
-        # probabilities -> logits (float32)
-        d_pv = torch.matmul(g_ov, vl_t).float()                                    # [B, H, Tv, Tl]
-        d_pl = torch.matmul(g_ol, vv_t).float()                                    # [B, H, Tl, Tv]
-        if keep_v is not None:
-            d_pv = d_pv * keep_v * ctx.scale
-            d_pl = d_pl * keep_l * ctx.scale
-        pvf, plf = pv.float(), pl.float()
-        d_s = pvf * (d_pv - (pvf * d_pv).sum(-1, keepdim=True))
-        d_s = d_s + (plf * (d_pl - (plf * d_pl).sum(-1, keepdim=True))).transpose(-1, -2)
-        d_s = d_s.to(q.dtype)
+        # gradients of the (dropped) probabilities, then ONE kernel for both softmax backward passes + dropout
+        d_pv = torch.matmul(g_ov, vl_t)                                            # [B, H, Tv, Tl]
+        d_pl = torch.matmul(g_ol, vv_t)                                            # [B, H, Tl, Tv]
+        d_s = torch.empty_like(pv)
+        drop = keep_v is not None
+        pv_d = torch.empty_like(pv) if drop else pv
+        pl_d = torch.empty_like(pl) if drop else pl
+        st = _lib.lib().alif_attention_softmax_backward_bf16(
+            pv.data_ptr(), pl.data_ptr(), d_pv.contiguous().data_ptr(), d_pl.contiguous().data_ptr(),
+            keep_v.data_ptr() if drop else None, keep_l.data_ptr() if drop else None, ctx.scale, B, H, Tv, Tl,
+            d_s.data_ptr(), pv_d.data_ptr() if drop else None, pl_d.data_ptr() if drop else None,
+            torch.cuda.current_stream(q.device).cuda_stream)
+        if st:
+            raise RuntimeError("alif_attention_softmax_backward: " + _lib.strerror(st))
+        # value projections (transposed layout): d V^T = g_out^T P_dropped, zero in the padding columns
+        g_vlt = torch.matmul(g_ov.transpose(-1, -2), pv_d)
+        g_vvt = torch.matmul(g_ol.transpose(-1, -2), pl_d)
+        if g_vlt.shape[-1] != vlt.shape[-1]:
+            g_vlt = F.pad(g_vlt, (0, vlt.shape[-1] - Tl))
+        if g_vvt.shape[-1] != vvt.shape[-1]:
+            g_vvt = F.pad(g_vvt, (0, vvt.shape[-1] - Tv))
         g_q = torch.matmul(d_s, heads(k, Tl)).transpose(1, 2).reshape(B, Tv, E)
         g_k = torch.matmul(d_s.transpose(-1, -2), heads(q, Tv)).transpose(1, 2).reshape(B, Tl, E)
-        return g_q, g_k, g_vlt.view_as(vlt), g_vvt.view_as(vvt), None, None, None
+        return g_q, g_k, g_vlt.reshape(vlt.shape), g_vvt.reshape(vvt.shape), None, None, None
 
 
 class RLIPv2_BiMultiHeadAttention(nn.Module):

@@ -40,6 +40,13 @@ constexpr int OFF_PV = TV_MAX * S_STRIDE * 4;
 constexpr int OFF_PL = OFF_PV + TV_MAX * PV_STRIDE * 2;
 constexpr int OFF_RED = OFF_PL + TL * PL_STRIDE * 2;          // float [2][4][TL]: partial max / sum of the column softmax
 constexpr int LDS_BYTES = OFF_RED + 2 * 4 * TL * 4;
+// operand staging (rows padded by 16 B so that the 32 rows a fragment read touches fall into different banks):
+//   K   [64 rows][256 + 8] bf16 in the P_l region during phase 1 (P_l is written in phase 2)
+//   V_l^T [256 rows][64 + 8] bf16 in the logits' region during phase 3 (the logits are dead after phase 2)
+constexpr int K_STRIDE = HD + 8;
+constexpr int VL_STRIDE = TL + 8;
+static_assert(TL * K_STRIDE * 2 <= TL * PL_STRIDE * 2, "K staging fits the P_l region");
+static_assert(HD * VL_STRIDE * 2 <= OFF_PV, "V_l^T staging fits the logits' region");
 
 __device__ __forceinline__ float bf(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ uint16_t rne(float f)
@@ -89,25 +96,39 @@ __global__ __launch_bounds__(THREADS) void alif_forward_kernel(
     const size_t bh = (size_t)b * H + h;
 
     // ---- phase 1: S = Q K^T, a wave per 32-row tile, both 32-column tiles -----------------------------------------
-    for (int rt = wave; rt < row_tiles; rt += 4) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-        const int i = rt * 32 + li;
-#pragma unroll 4
-        for (int ks = 0; ks < HD / 16; ++ks) {
-            const Frag a = load_frag(qb + (size_t)i * E + ks * 16 + kg, i < Tv);
-            const Frag b0 = load_frag(kb + (size_t)li * E + ks * 16 + kg, li < Tl);
-            const Frag b1 = load_frag(kb + (size_t)(32 + li) * E + ks * 16 + kg, 32 + li < Tl);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b0.v, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b1.v, acc[1], 0, 0, 0);
+    // K is staged in LDS once (coalesced 16-byte loads); a wave loads all 16 A fragments of its row tile in one go
+    // (one memory latency per tile instead of one per k-step) and reads the B fragments from LDS.
+    {
+        uint16_t *Ks = Pl;
+        for (int i = tid; i < TL * (HD / 8); i += THREADS) {
+            const int j = i / (HD / 8), c8 = i % (HD / 8);
+            const uint4 v = j < Tl ? *reinterpret_cast<const uint4 *>(kb + (size_t)j * E + c8 * 8) : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(Ks + j * K_STRIDE + c8 * 8) = v;
         }
+        __syncthreads();
+        for (int rt = wave; rt < row_tiles; rt += 4) {
+            f32x16 acc[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) S[(rt * 32 + acc_row(r, lane)) * S_STRIDE + c * 32 + li] = acc[c][r];
+                for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+            const int i = rt * 32 + li;
+            Frag a[HD / 16];
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ++ks) a[ks] = load_frag(qb + (size_t)i * E + ks * 16 + kg, i < Tv);
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ++ks) {
+                Frag b0, b1;
+                b0.u = *reinterpret_cast<const uint4 *>(Ks + li * K_STRIDE + ks * 16 + kg);
+                b1.u = *reinterpret_cast<const uint4 *>(Ks + (32 + li) * K_STRIDE + ks * 16 + kg);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks].v, b0.v, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks].v, b1.v, acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[(rt * 32 + acc_row(r, lane)) * S_STRIDE + c * 32 + li] = acc[c][r];
+        }
     }
     __syncthreads();
 
@@ -165,26 +186,36 @@ __global__ __launch_bounds__(THREADS) void alif_forward_kernel(
     __syncthreads();
 
     // ---- phase 3: out_v = P_v V_l  (K = 64 text tokens), a wave per 32-row tile, 8 column tiles of 32 channels ------
-    for (int rt = wave; rt < row_tiles; rt += 4) {
-        Frag a[TL / 16];
+    // V_l^T (256 channel rows x 64 tokens, 32 KB) is staged over the dead logits; phase 4's first B fragments are
+    // requested before, so that they travel underneath this phase.
+    {
+        uint16_t *Vs = reinterpret_cast<uint16_t *>(lds);
+        for (int i = tid; i < HD * (TL / 8); i += THREADS) {
+            const int c = i / (TL / 8), j8 = i % (TL / 8);
+            *reinterpret_cast<uint4 *>(Vs + c * VL_STRIDE + j8 * 8) = *reinterpret_cast<const uint4 *>(vlb + (size_t)c * TL + j8 * 8);
+        }
+        __syncthreads();
+        for (int rt = wave; rt < row_tiles; rt += 4) {
+            Frag a[TL / 16];
 #pragma unroll
-        for (int ks = 0; ks < TL / 16; ++ks)
-            a[ks].u = *reinterpret_cast<const uint4 *>(Pv + (rt * 32 + li) * PV_STRIDE + ks * 16 + kg);
+            for (int ks = 0; ks < TL / 16; ++ks)
+                a[ks].u = *reinterpret_cast<const uint4 *>(Pv + (rt * 32 + li) * PV_STRIDE + ks * 16 + kg);
 #pragma unroll 2
-        for (int nt = 0; nt < HD / 32; ++nt) {
-            f32x16 acc;
+            for (int nt = 0; nt < HD / 32; ++nt) {
+                f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const uint16_t *vrow = vlb + (size_t)(nt * 32 + li) * TL;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < TL / 16; ++ks) {
-                const Frag bf_ = load_frag(vrow + ks * 16 + kg, true);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks].v, bf_.v, acc, 0, 0, 0);
-            }
+                for (int ks = 0; ks < TL / 16; ++ks) {
+                    Frag bf_;
+                    bf_.u = *reinterpret_cast<const uint4 *>(Vs + (nt * 32 + li) * VL_STRIDE + ks * 16 + kg);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks].v, bf_.v, acc, 0, 0, 0);
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = rt * 32 + acc_row(r, lane);
-                if (i < Tv) out_v[((size_t)b * Tv + i) * E + h * HD + nt * 32 + li] = rne(acc[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int i = rt * 32 + acc_row(r, lane);
+                    if (i < Tv) out_v[((size_t)b * Tv + i) * E + h * HD + nt * 32 + li] = rne(acc[r]);
+                }
             }
         }
     }
@@ -198,7 +229,7 @@ __global__ __launch_bounds__(THREADS) void alif_forward_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[jt][c][r] = 0.f;
         const uint16_t *v0 = vvb + (size_t)(wave * 64 + li) * Tvp, *v1 = v0 + (size_t)32 * Tvp;
-#pragma unroll 2
+#pragma unroll 6
         for (int ks = 0; ks < Tvp / 16; ++ks) {
             Frag a0, a1;
             a0.u = *reinterpret_cast<const uint4 *>(Pl + li * PL_STRIDE + ks * 16 + kg);
@@ -218,6 +249,67 @@ __global__ __launch_bounds__(THREADS) void alif_forward_kernel(
                     const int j = jt * 32 + acc_row(r, lane);
                     if (j < Tl) out_l[((size_t)b * Tl + j) * E + h * HD + wave * 64 + c * 32 + li] = rne(acc[jt][c][r]);
                 }
+    }
+}
+
+// Backward of the two softmaxes (and of the dropout in front of the value products): from the saved probabilities and
+// the gradients of the (dropped) probabilities to the gradient of the shared logits,
+//   dS[i][j] = P_v[i][j] (g_v[i][j] - sum_j' P_v[i][j'] g_v[i][j']) + P_l[j][i] (g_l[j][i] - sum_i' P_l[j][i'] g_l[j][i'])
+// with g = dP * keep * keep_scale; also writes the dropped probabilities P * keep * keep_scale the value-projection
+// gradients need.  One workgroup per (image, head), float32 arithmetic, ~12 PyTorch launches otherwise.
+constexpr int BWD_THREADS = 1024;
+
+__device__ __forceinline__ float wave_sum64(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(BWD_THREADS) void alif_softmax_backward_kernel(
+    const uint16_t *__restrict__ p_v, const uint16_t *__restrict__ p_l, const uint16_t *__restrict__ d_pv,
+    const uint16_t *__restrict__ d_pl, const uint8_t *__restrict__ keep_v, const uint8_t *__restrict__ keep_l,
+    float keep_scale, int Tv, int Tl, uint16_t *__restrict__ d_s, uint16_t *__restrict__ pd_v, uint16_t *__restrict__ pd_l)
+{
+    // every global access is a wave reading / writing consecutive elements; the language-side term, which lives in
+    // [text][vision] order, reaches the [vision][text] output through an LDS tile
+    __shared__ float row_v[TV_MAX];              // sum_j P_v g_v per vision row
+    __shared__ float row_l[TL];                  // sum_i P_l g_l per text row
+    __shared__ float term_l[TL][TV_MAX + 1];     // P_l (g_l - row_l) in [text][vision] order
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int WAVES = BWD_THREADS / 64;
+    const size_t base = (size_t)blockIdx.x * Tv * Tl;
+    const uint16_t *pv = p_v + base, *pl = p_l + base, *gv = d_pv + base, *gl = d_pl + base;
+    const uint8_t *kv = DROP ? keep_v + base : nullptr, *kl = DROP ? keep_l + base : nullptr;
+    auto grad = [&](const uint16_t *g, const uint8_t *kp, int e) {
+        const float x = bf(g[e]);
+        return DROP ? (kp[e] ? x * keep_scale : 0.f) : x;
+    };
+    for (int i = wave; i < Tv; i += WAVES) {                     // vision rows: lane = text token
+        const int e = i * Tl + lane;
+        const float acc = wave_sum64(lane < Tl ? bf(pv[e]) * grad(gv, kv, e) : 0.f);
+        if (lane == 0) row_v[i] = acc;
+    }
+    for (int j = wave; j < Tl; j += WAVES) {                     // text rows: lanes stride over the vision tokens
+        float acc = 0.f;
+        for (int i = lane; i < Tv; i += 64) acc = fmaf(bf(pl[j * Tv + i]), grad(gl, kl, j * Tv + i), acc);
+        acc = wave_sum64(acc);
+        if (lane == 0) row_l[j] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < Tv * Tl; e += BWD_THREADS) {           // language-side term, [text][vision] order
+        const int j = e / Tv, i = e % Tv;
+        const float plv = bf(pl[e]);
+        term_l[j][i] = plv * (grad(gl, kl, e) - row_l[j]);
+        if (DROP) pd_l[base + e] = kl[e] ? rne(plv * keep_scale) : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int e = tid; e < Tv * Tl; e += BWD_THREADS) {           // [vision][text] order
+        const int i = e / Tl, j = e % Tl;
+        const float pvv = bf(pv[e]);
+        d_s[base + e] = rne(pvv * (grad(gv, kv, e) - row_v[i]) + term_l[j][i]);
+        if (DROP) pd_v[base + e] = kv[e] ? rne(pvv * keep_scale) : (uint16_t)0;
     }
 }
 
@@ -266,3 +358,27 @@ int alif_attention_forward_bf16(const void *q, const void *k, const void *values
 }
 
 }  // extern "C"
+
+extern "C" int alif_attention_softmax_backward_bf16(const void *probs_v, const void *probs_l, const void *d_probs_v,
+                                                    const void *d_probs_l, const void *keep_v, const void *keep_l,
+                                                    float keep_scale, int B, int H, int Tv, int Tl, void *d_logits,
+                                                    void *dropped_v, void *dropped_l, void *stream)
+{
+    if (!alif_attention_supported(B, H, Tv, Tl, HD)) return MSDA_ERR_BAD_SHAPE;
+    if (!probs_v || !probs_l || !d_probs_v || !d_probs_l || !d_logits) return MSDA_ERR_NULL_POINTER;
+    if ((keep_v == nullptr) != (keep_l == nullptr)) return MSDA_ERR_NULL_POINTER;
+    if (keep_v && (!dropped_v || !dropped_l)) return MSDA_ERR_NULL_POINTER;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
+    if (keep_v)
+        hipLaunchKernelGGL(alif_softmax_backward_kernel<true>, dim3(B * H), dim3(BWD_THREADS), 0, s, (const uint16_t *)probs_v,
+                           (const uint16_t *)probs_l, (const uint16_t *)d_probs_v, (const uint16_t *)d_probs_l,
+                           (const uint8_t *)keep_v, (const uint8_t *)keep_l, keep_scale, Tv, Tl, (uint16_t *)d_logits,
+                           (uint16_t *)dropped_v, (uint16_t *)dropped_l);
+    else
+        hipLaunchKernelGGL(alif_softmax_backward_kernel<false>, dim3(B * H), dim3(BWD_THREADS), 0, s, (const uint16_t *)probs_v,
+                           (const uint16_t *)probs_l, (const uint16_t *)d_probs_v, (const uint16_t *)d_probs_l,
+                           (const uint8_t *)nullptr, (const uint8_t *)nullptr, 1.f, Tv, Tl, (uint16_t *)d_logits,
+                           (uint16_t *)nullptr, (uint16_t *)nullptr);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}

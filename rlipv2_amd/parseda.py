@@ -315,6 +315,10 @@ class RLIP_ParSeDA(nn.Module):
             cur = torch.cuda.current_stream()
             side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=samples.tensors.device))
             fork = cur.record_event()
+        if 'fork' in locals() and os.environ.get("RLIPV2_TEXT_FIRST") == "1":      # (A/B switch: the round-1 issue order)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                encoded_text = tr._encode_text(text, samples.tensors.shape[0], samples.tensors.device)
         features, pos = self.backbone(samples)
         if encoded_text is None and 'fork' in locals():
             # Issued AFTER the backbone, forked from BEFORE it (the event): the two still run side by side, but the

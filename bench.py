@@ -412,13 +412,20 @@ def run_train_step_bench(args, world, rank, local_rank, device):
 
 
 def pmc_traffic(kernel_key, args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_msda.json; separate FETCH_SIZE / WRITE_SIZE runs of the same kernels, gfx950
-    correction applied there).  Only valid for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_msda.json")
+    """HBM bytes per launch (fetch + write) of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/r02_final_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of the same kernels with --kernel-trace only,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes; tools/gpu_final_r02.sh).  Only valid for the configuration it
+    was measured on (batch 4, bf16, 800x1333)."""
+    path = os.path.join(ROOT, "profiles", "r02_final_traffic.json")
     if args.dtype != "bf16" or args.batch != 4 or not os.path.exists(path):
         return None
-    return json.load(open(path))["traffic_bytes_per_launch"].get(kernel_key)
+    t = json.load(open(path))
+    parts = {"enc_bwd_fused": ["msda:quad_backward_shared_kernel+geometry", "msda:bin_kernel", "msda:dest_kernel", "msda:combine_kernel"],
+             "enc_bwd": ["b0:quad_backward_shared_kernel", "b0:bin_kernel", "b0:dest_kernel", "b0:combine_kernel"],
+             "enc_fwd_fused": ["fwd:quad_forward_fused_kernel"]}.get(kernel_key)
+    if not parts or any(k not in t for k in parts):
+        return None
+    return int(sum(t[k]["fetch_bytes"] + t[k]["write_bytes"] for k in parts))
 
 
 def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None,

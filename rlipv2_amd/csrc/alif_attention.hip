@@ -38,8 +38,8 @@ constexpr int PV_STRIDE = TL + 8;       // bf16 per row of P_v  [Tv][Tl]
 constexpr int PL_STRIDE = TV_MAX + 8;   // bf16 per row of P_l  [Tl][Tv]
 constexpr int OFF_PV = TV_MAX * S_STRIDE * 4;
 constexpr int OFF_PL = OFF_PV + TV_MAX * PV_STRIDE * 2;
-constexpr int OFF_RED = OFF_PL + TL * PL_STRIDE * 2;          // float [2][4][TL]: partial max / sum of the column softmax
-constexpr int LDS_BYTES = OFF_RED + 2 * 4 * TL * 4;
+constexpr int OFF_RED = OFF_PL + TL * PL_STRIDE * 2;          // softmax statistics: row max / 1/sum [2][TV_MAX], column max / 1/sum
+constexpr int LDS_BYTES = OFF_RED + (2 * TV_MAX + 2 * TL + 8 * TL) * 4;  // [2][TL], partials [8][TL]
 // operand staging (rows padded by 16 B so that the 32 rows a fragment read touches fall into different banks):
 //   K   [64 rows][256 + 8] bf16 in the P_l region during phase 1 (P_l is written in phase 2)
 //   V_l^T [256 rows][64 + 8] bf16 in the logits' region during phase 3 (the logits are dead after phase 2)
@@ -132,53 +132,84 @@ __global__ __launch_bounds__(THREADS) void alif_forward_kernel(
     }
     __syncthreads();
 
-    // ---- phase 2a: P_v = softmax over the text tokens, a thread per vision row --------------------------------------
-    for (int i = tid; i < Tvp; i += THREADS) {
-        uint16_t *prow = Pv + i * PV_STRIDE;
-        if (i < Tv) {
-            const float *srow = S + i * S_STRIDE;
-            float mx = -INFINITY;
-            for (int j = 0; j < Tl; ++j) mx = fmaxf(mx, srow[j]);
-            float sum = 0.f;
-            for (int j = 0; j < Tl; ++j) sum += __expf(srow[j] - mx);
-            const float inv = 1.f / sum;
-            uint16_t *g = p_v + (bh * Tv + i) * Tl;
-            const uint8_t *kp = DROP ? keep_v + (bh * Tv + i) * Tl : nullptr;
-            for (int j = 0; j < TL; ++j) {
-                uint16_t pb = 0;
-                if (j < Tl) {
-                    pb = rne(__expf(srow[j] - mx) * inv);          // the probability as bfloat16 (what the backward sees)
-                    g[j] = pb;
-                    if (DROP) pb = kp[j] ? rne(bf(pb) * keep_scale) : (uint16_t)0;
-                }
-                prow[j] = pb;
-            }
-        } else {
-            for (int j = 0; j < TL; ++j) prow[j] = 0;
-        }
+    // ---- phase 2: both softmaxes.  Statistics first (row maxima / sums by a thread per vision row, column maxima / sums
+    // by 4 threads per text token -- serial passes over LDS, no shuffles), then two element-wise sweeps in which every
+    // global access (saved probabilities, keep masks) is a wave reading / writing consecutive addresses ---------------
+    float *rmax = red, *rinv = red + TV_MAX, *cmax = red + 2 * TV_MAX, *cinv = cmax + TL, *part = cinv + TL;
+    for (int i = tid; i < Tv; i += THREADS) {
+        const float *srow = S + i * S_STRIDE;
+        float mx = -INFINITY;
+        for (int j = 0; j < Tl; ++j) mx = fmaxf(mx, srow[j]);
+        float sum = 0.f;
+        for (int j = 0; j < Tl; ++j) sum += __expf(srow[j] - mx);
+        rmax[i] = mx;
+        rinv[i] = 1.f / sum;
     }
-    // ---- phase 2b: P_l = softmax over the vision tokens of S^T (minus its row maximum: the softmax's own shift) -----
     {
-        const int j = tid & 63, part = tid >> 6;
+        const int j = tid & 63, pt = tid >> 6;
         float mx = -INFINITY;
         if (j < Tl)
-            for (int i = part; i < Tv; i += 4) mx = fmaxf(mx, S[i * S_STRIDE + j]);
-        red[part * TL + j] = mx;
+            for (int i = pt; i < Tv; i += 4) mx = fmaxf(mx, S[i * S_STRIDE + j]);
+        part[pt * TL + j] = mx;
         __syncthreads();
-        mx = fmaxf(fmaxf(red[j], red[TL + j]), fmaxf(red[2 * TL + j], red[3 * TL + j]));
+        mx = fmaxf(fmaxf(part[j], part[TL + j]), fmaxf(part[2 * TL + j], part[3 * TL + j]));
         float sum = 0.f;
         if (j < Tl)
-            for (int i = part; i < Tv; i += 4) sum += __expf(S[i * S_STRIDE + j] - mx);
-        red[(4 + part) * TL + j] = sum;
+            for (int i = pt; i < Tv; i += 4) sum += __expf(S[i * S_STRIDE + j] - mx);
+        part[(4 + pt) * TL + j] = sum;
         __syncthreads();
-        const float inv = 1.f / (red[4 * TL + j] + red[5 * TL + j] + red[6 * TL + j] + red[7 * TL + j]);
+        if (pt == 0) {
+            cmax[j] = mx;
+            cinv[j] = 1.f / (part[4 * TL + j] + part[5 * TL + j] + part[6 * TL + j] + part[7 * TL + j]);
+        }
+    }
+    __syncthreads();
+    // (the keep-mask bytes of a batch of elements are requested together, ahead of their use: inside a conditional a
+    //  load is not hoisted by the compiler, and a serial loop of dependent ~1 us global loads is what made the first
+    //  version of this phase take ~70 us)
+    {
+        constexpr int BATCH = 8;
+        const int j = tid & 63;
+        for (int i0 = tid >> 6; i0 < Tvp; i0 += 4 * BATCH) {        // P_v, [vision][text] order: a wave per row
+            uint8_t kb[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int i = i0 + 4 * u;
+                kb[u] = (DROP && i < Tv && j < Tl) ? keep_v[(bh * Tv + i) * Tl + j] : (uint8_t)1;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int i = i0 + 4 * u;
+                if (i >= Tvp) break;
+                uint16_t pb = 0;
+                if (i < Tv && j < Tl) {
+                    pb = rne(__expf(S[i * S_STRIDE + j] - rmax[i]) * rinv[i]);   // the probability as bfloat16 (what the backward sees)
+                    p_v[(bh * Tv + i) * Tl + j] = pb;
+                    if (DROP) pb = kb[u] ? rne(bf(pb) * keep_scale) : (uint16_t)0;
+                }
+                Pv[i * PV_STRIDE + j] = pb;
+            }
+        }
+    }
+    for (int j = wave; j < TL; j += THREADS / 64) {                 // P_l, [text][vision] order: a wave per text token
         uint16_t *prow = Pl + j * PL_STRIDE;
-        for (int i = part; i < Tvp; i += 4) {
+        const float mx = cmax[j], inv = cinv[j];
+        constexpr int STEPS = (TV_MAX + 63) / 64;
+        uint8_t kb[STEPS];
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            const int i = lane + 64 * u;
+            kb[u] = (DROP && i < Tv && j < Tl) ? keep_l[(bh * Tl + j) * Tv + i] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int u = 0; u < STEPS; ++u) {
+            const int i = lane + 64 * u;
+            if (i >= Tvp) break;
             uint16_t pb = 0;
-            if (j < Tl && i < Tv) {
-                pb = rne(__expf(S[i * S_STRIDE + j] - mx) * inv);
+            if (i < Tv && j < Tl) {
+                pb = rne(__expf(S[i * S_STRIDE + j] - mx) * inv);       // (bank (i + j) mod 64: conflict-free)
                 p_l[(bh * Tl + j) * Tv + i] = pb;
-                if (DROP) pb = keep_l[(bh * Tl + j) * Tv + i] ? rne(bf(pb) * keep_scale) : (uint16_t)0;
+                if (DROP) pb = kb[u] ? rne(bf(pb) * keep_scale) : (uint16_t)0;
             }
             prow[i] = pb;
         }

@@ -36,6 +36,8 @@ EXPORTS = (
     # include/rlipv2_alif.h
     "alif_attention_supported", "alif_attention_padded_tv", "alif_attention_forward_bf16",
     "alif_attention_softmax_backward_bf16",
+    # include/rlipv2_elementwise.h
+    "add_relu_bf16", "affine_relu_bf16", "affine_relu_backward_bf16",
 )
 
 _lib = None
@@ -122,6 +124,11 @@ def lib() -> ctypes.CDLL:
     L.alif_attention_softmax_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, f32, i, i, i, i, vp, vp, vp, vp]
     L.alif_attention_softmax_backward_bf16.restype = i
     L.alif_attention_supported.restype = L.alif_attention_padded_tv.restype = L.alif_attention_forward_bf16.restype = i
+    L.add_relu_bf16.argtypes = [vp, vp, vp, lg, vp]
+    L.add_relu_bf16.restype = i
+    L.affine_relu_bf16.argtypes = [vp, vp, vp, vp, lg, i, vp]
+    L.affine_relu_backward_bf16.argtypes = [vp, vp, vp, vp, lg, i, vp]
+    L.affine_relu_bf16.restype = L.affine_relu_backward_bf16.restype = i
     _lib = L
     return L
 

@@ -11,6 +11,8 @@ convolutions of the bf16 channels-last path run as token-major GEMMs with BatchN
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -20,6 +22,8 @@ from .linear import token_linear
 
 # 1x1 convolutions of channels-last bf16 feature maps as token-major GEMMs (tests switch it off to compare)
 pointwise_as_gemm = True
+# relu(a + b) of the bottleneck tails as one HIP pass (A/B switch: RLIPV2_ADD_RELU=0)
+fused_add_relu = os.environ.get("RLIPV2_ADD_RELU", "1") != "0"
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -60,6 +64,82 @@ class FrozenBatchNorm2d(nn.Module):
         return scale.view(-1), bias.view(-1)
 
 
+class AddReLUFunction(torch.autograd.Function):
+    """relu(a + b) as one HIP pass (csrc/elementwise.hip; bit-identical to `add` then `relu` in bfloat16); the gradient
+    of both addends is dy * (y > 0)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        from . import _lib, roofline
+        y = torch.empty_like(a)
+        st = _lib.lib().add_relu_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(),
+                                      torch.cuda.current_stream(a.device).cuda_stream)
+        if st:
+            raise RuntimeError("add_relu: " + _lib.strerror(st))
+        roofline.add(roofline.tensor_bytes(a, b, y))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(dy, y, 0)
+        return g, g
+
+
+class AffineReLUFunction(torch.autograd.Function):
+    """relu(x * scale[c] + bias[c]) of a channels-last bf16 tensor (frozen BatchNorm + ReLU) as one HIP pass each way
+    (csrc/elementwise.hip); scale / bias are constants (buffers of FrozenBatchNorm2d)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, bias):
+        from . import _lib, roofline
+        y = torch.empty_like(x)
+        C = x.shape[1]
+        st = _lib.lib().affine_relu_bf16(x.data_ptr(), scale.data_ptr(), bias.data_ptr(), y.data_ptr(), x.numel(), C,
+                                         torch.cuda.current_stream(x.device).cuda_stream)
+        if st:
+            raise RuntimeError("affine_relu: " + _lib.strerror(st))
+        roofline.add(roofline.tensor_bytes(x, y))
+        ctx.save_for_backward(y, scale)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        from . import _lib, roofline
+        y, scale = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(y)
+        st = _lib.lib().affine_relu_backward_bf16(dy.data_ptr(), y.data_ptr(), scale.data_ptr(), dx.data_ptr(), y.numel(),
+                                                  y.shape[1], torch.cuda.current_stream(y.device).cuda_stream)
+        if st:
+            raise RuntimeError("affine_relu_backward: " + _lib.strerror(st))
+        roofline.add(roofline.tensor_bytes(dy, y, dx))
+        return dx, None, None
+
+
+def bn_relu(x, bn):
+    """relu(bn(x)) for a FrozenBatchNorm2d; one fused pass for channels-last bf16 GPU tensors"""
+    if (fused_add_relu and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+            and not torch.is_autocast_enabled() and x.data_ptr() % 16 == 0):
+        scale, bias = bn.folded_vectors(x.dtype)
+        return AffineReLUFunction.apply(x, scale.contiguous(), bias.contiguous())
+    return F.relu(bn(x))
+
+
+def add_relu(a, b):
+    """relu(a + b); the fused kernel when both are bf16 GPU tensors of one shape and memory layout"""
+    if (fused_add_relu and a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape == b.shape
+            and a.stride() == b.stride() and a.numel() % 8 == 0 and not torch.is_autocast_enabled()
+            and (a.is_contiguous() or a.is_contiguous(memory_format=torch.channels_last))
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        return AddReLUFunction.apply(a, b)
+    return F.relu(a + b)
+
+
 def pointwise_conv_bn(x, conv, bn, relu):
     """1x1 stride-1 convolution + frozen BatchNorm (+ ReLU) of a channels-last bf16 tensor as ONE GEMM over
     the N*H*W pixels: the BN scale is folded into the weight rows (a [Cout, Cin] multiply, differentiable
@@ -87,13 +167,19 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        if (pointwise_as_gemm and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_autocast_enabled()
-                and x.is_contiguous(memory_format=torch.channels_last)):
+        fast = (pointwise_as_gemm and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_autocast_enabled()
+                and x.is_contiguous(memory_format=torch.channels_last))
+        if self.downsample is None:
+            idt = x
+        elif fast and self.downsample[0].stride == (1, 1):
+            idt = pointwise_conv_bn(x, self.downsample[0], self.downsample[1], relu=False)   # (layer1.0: BN folded into the GEMM)
+        else:
+            idt = self.downsample(x)
+        if fast:
             out = pointwise_conv_bn(x, self.conv1, self.bn1, relu=True)
-            out = F.relu(self.bn2(self.conv2(out)))
+            out = bn_relu(self.conv2(out), self.bn2)
             if out.is_contiguous(memory_format=torch.channels_last):
-                return F.relu(pointwise_conv_bn(out, self.conv3, self.bn3, relu=False) + idt)
+                return add_relu(pointwise_conv_bn(out, self.conv3, self.bn3, relu=False), idt)
             return F.relu(self.bn3(self.conv3(out)) + idt)
         out = F.relu(self.bn1(self.conv1(x)))
         out = F.relu(self.bn2(self.conv2(out)))
@@ -125,7 +211,7 @@ class ResNet50Body(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        x = F.max_pool2d(bn_relu(self.conv1(x), self.bn1), 3, stride=2, padding=1)
         c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

@@ -76,3 +76,54 @@ def test_add_layer_norm_module_route_and_fallback():
     assert not norm.supported(big_a.float(), None, ln32.weight, ln32.bias)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         norm.AddLayerNormFunction.apply(torch.zeros(8, 256), None, torch.ones(256), torch.zeros(256), 1e-5)
+
+
+def test_add_relu_kernel_is_bit_identical_to_add_then_relu():
+    """csrc/elementwise.hip: relu(a + b) in one pass (the ResNet bottleneck tail) -- same bits as the two PyTorch ops in
+    bfloat16 (the sum is rounded before the clamp), for contiguous and channels-last tensors, and the same gradients."""
+    import torch
+    from rlipv2_amd import backbone
+    g = torch.Generator(device="cuda:0").manual_seed(0)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        a = torch.randn(2, 64, 25, 42, device="cuda:0", generator=g).bfloat16().contiguous(memory_format=fmt).requires_grad_(True)
+        b = torch.randn(2, 64, 25, 42, device="cuda:0", generator=g).bfloat16().contiguous(memory_format=fmt).requires_grad_(True)
+        dy = torch.randn(2, 64, 25, 42, device="cuda:0", generator=g).bfloat16().contiguous(memory_format=fmt)
+        y = backbone.add_relu(a, b)
+        assert isinstance(y.grad_fn, backbone.AddReLUFunction._backward_cls)
+        y.backward(dy)
+        ga, gb = a.grad.clone(), b.grad.clone()
+        a.grad = b.grad = None
+        ref = torch.relu(a + b)
+        ref.backward(dy)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref) and y.stride() == ref.stride()
+        assert torch.equal(ga, a.grad) and torch.equal(gb, b.grad)
+    # shapes the kernel does not take fall back to the two ops
+    c = torch.randn(3, 5, device="cuda:0").bfloat16()
+    assert torch.equal(backbone.add_relu(c, c), torch.relu(c + c))
+
+
+def test_affine_relu_kernels_match_frozen_batchnorm_then_relu():
+    """csrc/elementwise.hip: relu(bn(x)) for a FrozenBatchNorm2d as one pass (and its backward as one pass): the same
+    bits as addcmul + relu forward, the same gradient as autograd's threshold_backward + mul to bf16 rounding."""
+    import torch
+    from rlipv2_amd import backbone
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    bn = backbone.FrozenBatchNorm2d(64).to("cuda:0")
+    bn.weight.copy_(torch.rand(64, device="cuda:0", generator=g) + 0.5)
+    bn.bias.copy_(torch.randn(64, device="cuda:0", generator=g))
+    bn.running_mean.copy_(torch.randn(64, device="cuda:0", generator=g))
+    bn.running_var.copy_(torch.rand(64, device="cuda:0", generator=g) + 0.3)
+    bn = bn.to(torch.bfloat16)
+    x = torch.randn(2, 64, 25, 42, device="cuda:0", generator=g).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    dy = torch.randn(2, 64, 25, 42, device="cuda:0", generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    y = backbone.bn_relu(x, bn)
+    assert isinstance(y.grad_fn, backbone.AffineReLUFunction._backward_cls)
+    y.backward(dy)
+    gx = x.grad.clone()
+    x.grad = None
+    ref = torch.relu(bn(x))
+    ref.backward(dy)
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    assert torch.equal(gx, x.grad)

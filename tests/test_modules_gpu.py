@@ -585,3 +585,72 @@ def test_alif_fused_attention_kernel_direct_vs_float64_and_dropout():
     assert float((out_l.double() - exp_l).abs().max()) <= 2e-2 * float(exp_l.abs().max())
     (out_v.float().sum() + out_l.float().sum()).backward()
     assert torch.isfinite(qg.grad).all()
+
+
+# ---- f4 on the device: inference tail and checkpoint interop ------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["plain", "temperature", "zeroshot"])
+def test_postprocess_hoi_on_gpu_matches_reference(variant):
+    """PostProcessHOI (hoi.py:4769-4873) with the model outputs resident on the GPU (whole batch on the device, one
+    D2H transfer) against the reference-generated golden: labels / ids exact, scores and boxes to float32 rounding."""
+    sys.path.insert(0, C.GOLD)
+    from make_model_golden import postprocess_case
+    from rlipv2_amd.postprocess import PostProcessHOI
+    g = C.load("postprocess")
+    out, sizes = postprocess_case()
+    out = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in out.items()}
+    pp = PostProcessHOI(0, temperature=(variant == "temperature"), zero_shot_hoi_eval=(variant == "zeroshot"))
+    res = pp(out, sizes.to(DEV))
+    assert len(res) == 3
+    for i, r in enumerate(res):
+        for k in ("labels", "sub_ids", "obj_ids"):
+            assert torch.equal(r[k].cpu(), torch.as_tensor(g[f"{variant}_{i}_{k}"])), (i, k)
+        C.close(r["boxes"].cpu(), g[f"{variant}_{i}_boxes"], 1e-5, 1e-3, "boxes")
+        C.close(r["verb_scores"].cpu(), g[f"{variant}_{i}_verb_scores"], 1e-5, 1e-7, "verb_scores")
+
+
+def test_checkpoint_round_trip_with_the_fused_optimiser_on_gpu(tmp_path):
+    """checkpoint.py on the device with the bf16 / float32-master policy of the train step: 'model' of the saved file
+    holds the float32 masters in the reference's layout and names (main.py:599-629), a `--resume` into a fresh model +
+    FusedMasterAdamW followed by one more step equals the uninterrupted run bit for bit; `--pretrained` semantics cut the
+    learned queries (util/misc.py:479-490)."""
+    from rlipv2_amd import checkpoint as CK, train
+
+    def make():
+        torch.manual_seed(2)
+        margs = parseda.default_args(num_queries=20, enc_layers=4, dec_layers=2, pseudo_verb=False)
+        model, criterion = train.build_training(margs, device=DEV, with_text_encoder=False)
+        train.to_bf16(model)
+        model.eval()
+        return model, criterion
+
+    mem = torch.tanh(torch.randn(10, 1, 768, generator=torch.Generator().manual_seed(9))).repeat(1, 2, 1).to(DEV).bfloat16()
+    text = (~(mem.sum(-1) > 0), mem, torch.tensor([[6, 4]]))
+    samples, _, targets = train.synthetic_batch(2, 128, 160, n_obj=6, n_verb=4, triplets=2, device=DEV, seed=4)
+    samples.tensors = samples.tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    batch = (samples, text, targets)
+
+    m1, crit = make()
+    step1 = train.ParSeDATrainStep(m1)
+    train.freeze_parameters_without_gradient(step1, crit, batch)
+    o1 = train.FusedMasterAdamW(m1)
+    for _ in range(2):
+        train.train_step(step1, crit, o1, batch, autocast_dtype=None)
+    path = str(tmp_path / "ck.pth")
+    CK.save_checkpoint(path, m1, o1, epoch=7)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 7 and all(v.dtype == torch.float32 for k, v in ck["model"].items() if v.is_floating_point())
+    assert set(ck["model"]) == set(m1.state_dict())
+    train.train_step(step1, crit, o1, batch, autocast_dtype=None)
+    torch.cuda.synchronize()
+
+    m2, _ = make()
+    step2 = train.ParSeDATrainStep(m2)
+    train.freeze_parameters_without_gradient(step2, crit, batch)
+    o2 = train.FusedMasterAdamW(m2)
+    ck = torch.load(path, map_location=DEV, weights_only=False)
+    CK.load_resume(m2, {"model": {k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in ck["model"].items()}})
+    o2.load_state_dict(ck["optimizer"])                     # float32 masters + moments: the state the update continues from
+    train.train_step(step2, crit, o2, batch, autocast_dtype=None)
+    torch.cuda.synchronize()
+    worst = max(float((a.float() - b.float()).abs().max()) for a, b in zip(m1.parameters(), m2.parameters()))
+    assert worst <= 1e-3, worst          # (the device backward is not bit-repeatable: attention atomics)

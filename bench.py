@@ -248,7 +248,9 @@ class KernelTimer:
                 moved = [value, rest[0], rest[1], rest[2], rest[3], *out]
             nbytes = sum(t.numel() * t.element_size() for t in moved)
             dims = (N, S, M, D, shapes.shape[0], Lq, 4)
-            self.records.append((direction, dims, code, a, b, nbytes, self.msda.last_variant.get(direction), True))
+            # grad_value written as bfloat16: 2 bytes per element less than the float32 grad_value of msda_algorithmic_bytes
+            saved = N * S * M * D * 2 if (direction == "bwd" and out[0].dtype == torch.bfloat16) else 0
+            self.records.append((direction, dims, code, a, b, (nbytes, saved), self.msda.last_variant.get(direction), True))
             return out
         return timed
 
@@ -274,12 +276,16 @@ class KernelTimer:
         kern = {}
         for direction, dims, code, a, b, saved, variant, fused in self.records:
             kind = "enc" if dims[5] == dims[1] else f"dec{dims[5]}"
-            # B0-signature calls: algorithmic bytes of SURVEY.md 8d; fused calls: the operands they actually take
-            # (raw projection rows instead of float32 locations / weights), each tensor once
-            nbytes = saved if fused else _lib.algorithmic_bytes(code, direction == "bwd", *dims) - saved
+            # `bytes` = the ALGORITHMIC bytes of SURVEY.md 8d for this call (value, sampling_loc, attn_weight, output and,
+            # backward, their gradients, each once in the dtypes of the call) -- also for the fused kernels, which do
+            # the same job (plus the module's sampling geometry) on fewer operand bytes: those are `operand_bytes`
+            operand = None
+            if fused:
+                operand, saved = saved
+            nbytes = _lib.algorithmic_bytes(code, direction == "bwd", *dims) - saved
             k = kern.setdefault(f"{kind}_{direction}" + ("_fused" if fused else ""),
                                 {"ms": 0.0, "n": 0, "dims": dims, "code": code, "bwd": direction == "bwd",
-                                 "variant": variant, "bytes": nbytes})
+                                 "variant": variant, "bytes": nbytes, "operand_bytes": operand})
             k["ms"] += a.elapsed_time(b)
             k["n"] += 1
         return kern
@@ -329,8 +335,10 @@ def run_train_step_bench(args, world, rank, local_rank, device):
             else:
                 synchronizer = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
                 if os.environ.get("RLIPV2_DP_OVERLAP", "1") != "0" and not train.captured_collective_selftest(device):
+                    # (RCCL only; every other backend is answered "no" without a capture attempt)
                     # (all ranks agree on the verdict) captured collectives do not replay here: flat schedule
-                    print("[bench] captured all-reduce self-test failed: one flat all-reduce after the backward graph",
+                    print("[bench] collectives cannot be captured into the backward graph here (not RCCL, or the self-test "
+                          "failed): one flat all-reduce after the backward graph",
                           file=sys.stderr)
                     os.environ["RLIPV2_DP_OVERLAP"] = "0"
             if args.var_targets:
@@ -401,7 +409,7 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     # step-level roofline: algorithmic bytes / matrix FLOPs of one eager step of the same model + batch
     step_roofline = None
-    if rank == 0:
+    if rank == 0 and world == 1:       # (the probe runs a whole train step, collectives included: single-process runs only)
         from rlipv2_amd import roofline
         try:
             step_roofline = roofline.probe(
@@ -468,6 +476,11 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": pmc_traffic(dominant, args),
             "algorithmic_bytes_per_launch": kd["bytes"],
+            "bytes_definition": "SURVEY.md 8d: value + sampling_loc + attn_weight + grad_out read, grad_value + "
+                                "grad_sampling_loc + grad_attn_weight written, each once (bf16 value / grad_out / grad_value, "
+                                "float32 locations / weights)" + ("; the kernel that ran is the fused form (geometry backward "
+                                "as its epilogue), whose own operands are `operand_bytes_per_launch`" if kd.get("operand_bytes") else ""),
+            "operand_bytes_per_launch": kd.get("operand_bytes"),
             "mean_launch_us": round(mean_s * 1e6, 2),
             "timing": probe_note or "HIP events on the launch stream around every call inside the timed region",
             "msda_ms_per_step": round(sum(k["ms"] for k in kern.values()) / max(1, probe_steps), 3),

@@ -131,6 +131,9 @@ class GraphedStep:
         self.criterion = criterion
         if overlap is None:
             overlap = os.environ.get("RLIPV2_DP_OVERLAP", "1") != "0"
+            if overlap and synchronizer is not None:
+                import torch.distributed as dist                  # only RCCL collectives can be captured into the graph
+                overlap = dist.is_initialized() and dist.get_backend(synchronizer.group) == "nccl"
         self.overlap = bool(overlap) and synchronizer is not None
         self.wrapper = GraphedTrainForward(step_module, text["obj_pred_names_sums"],
                                            model.transformer.ho_decoder.num_layers, model.pseudo_verb)
@@ -367,6 +370,10 @@ def captured_collective_selftest(device, group=None):
     (fork to a communication stream, SUM all-reduce, join) is captured, replayed twice and checked; every rank gets the
     same answer (the verdicts are combined with a MIN all-reduce), so all ranks pick the same schedule."""
     import torch.distributed as dist
+    if dist.get_backend(group) != "nccl":
+        # only RCCL's collectives can be stream-captured; a host-staged backend (gloo) raises INSIDE the capture and
+        # leaves the stream in capture mode for good -- do not even try
+        return False
     ok = 1
     try:
         world, rank = dist.get_world_size(group), dist.get_rank(group)

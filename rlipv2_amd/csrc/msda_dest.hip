@@ -646,6 +646,10 @@ size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host)
 // grad_value only (K1 = launch_quad_backward_reduce is issued by the caller).  out_bf16: grad_value is bfloat16.
 void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *workspace, bool out_bf16)
 {
+    if (sparse_dest_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_SPARSE", 1)) {
+        launch_sparse_dest(p, shapes_host, out_bf16);      // few queries: per-(image, head, level) pass, see msda_sparse.hip
+        return;
+    }
     DestPlan pl;
     make_plan(p, shapes_host, pl);
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);

@@ -76,5 +76,8 @@ bool dest_supports(const Problem &p, const int64_t *shapes_host);
 int dest_shapes_consistent(const Problem &p, const int64_t *shapes_host);
 size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host);
 void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *workspace, bool out_bf16);
+// few queries (decoders): one workgroup per (image, head, level), records sorted by pixel in LDS (msda_sparse.hip)
+bool sparse_dest_supports(const Problem &p, const int64_t *shapes_host);
+void launch_sparse_dest(const Problem &p, const int64_t *shapes_host, bool out_bf16);
 
 }  // namespace msda

@@ -427,6 +427,34 @@ def test_dest_backward_is_bitwise_repeatable(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Lq", [150, 300, 37])
+def test_sparse_backward_for_few_queries_is_repeatable_and_matches_the_generic_kernel(dtype, Lq):
+    """Decoder shapes (msda_sparse.hip: one workgroup per (image, head, level), records counting-sorted by pixel in
+    LDS, runs summed in record order): bit-for-bit repeatable, grad_value equal to the generic kernel's to float32 /
+    bfloat16 rounding, also when hundreds of samples fall on ONE pixel."""
+    from tools.msda_inputs import make_inputs
+    inp = make_inputs(4, Lq=Lq, mode="decoder", dtype=dtype, device=DEV, seed=5)
+    loc = inp["loc"].clone()
+    loc[0, : Lq // 2, 0, 3] = 0.5                       # half of image 0's queries: head 0, level 3, all points on one spot
+    a = (inp["value"], inp["shapes"], inp["starts"], loc, inp["aw"], inp["grad_out"])
+    msda.set_variant("quad", "dest")
+    try:
+        first = msda.ms_deform_attn_backward(*a, 64)
+        again = msda.ms_deform_attn_backward(*a, 64)
+        msda.set_variant("generic", "generic")
+        ref = msda.ms_deform_attn_backward(*a, 64)
+    finally:
+        msda.set_variant("auto")
+    torch.cuda.synchronize()
+    for x, y in zip(first, again):
+        assert torch.equal(x, y)
+    gv, rv = first[0].float(), ref[0].float()
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    assert float((gv - rv).abs().max()) <= tol * float(rv.abs().max())
+    assert int((gv != 0).any(-1).sum()) == int((rv != 0).any(-1).sum()) or dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_full_size_single_image_vs_oracle(dtype):
     """One 800x1333 image (S = Lq = 22223) through the product kernels (auto: quad forward, K1 + destination-
     stationary backward) against the CPU oracle -- ties the full-size fast path to the oracle directly."""

@@ -11,6 +11,7 @@ the weight gradients of the projections run on the MFMA kernel of csrc/token_gem
 from __future__ import annotations
 
 import math
+import os
 import warnings
 
 import torch
@@ -28,6 +29,44 @@ fused_geometry = True
 # fold that geometry into the sampling kernels themselves (msda.FusedMSDeformAttnFunction) when the reference points
 # need no gradient
 fused_sampling = True
+
+
+class _AdjacentCat(torch.autograd.Function):
+    """torch.cat([a, b], 0) of two parameters that live back to back in ONE buffer (`flat`): the forward hands out the
+    buffer itself, the backward hands each parameter its slice of the incoming gradient -- no copy either way."""
+
+    @staticmethod
+    def forward(ctx, flat, a, b):
+        ctx.rows = a.shape[0]
+        return flat.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g[:ctx.rows], g[ctx.rows:]
+
+
+shared_parameter_storage = os.environ.get("RLIPV2_ADJACENT_CAT", "1") != "0"      # (A/B switch)
+
+
+def adjacent_cat(owner, key, a, b):
+    """cat([a, b], 0) for two parameters of `owner` without a kernel: their storage is (re-)laid out back to back in
+    one buffer the first time (and whenever a `.to()` / `load` has separated them again), after which optimiser updates
+    of the parameters are updates of the buffer.  Parameter objects, names and state_dict are untouched."""
+    if not shared_parameter_storage:
+        return torch.cat([a, b], 0)
+    flat = owner.__dict__.get(key)
+    n1 = a.numel() * a.element_size()
+    if not (flat is not None and flat.dtype == a.dtype == b.dtype and flat.device == a.device == b.device
+            and a.data_ptr() == flat.data_ptr() and b.data_ptr() == flat.data_ptr() + n1
+            and a.is_contiguous() and b.is_contiguous() and flat.shape[0] == a.shape[0] + b.shape[0]):
+        if torch.cuda.is_available() and a.is_cuda and torch.cuda.is_current_stream_capturing():
+            return torch.cat([a, b], 0)                      # never re-lay parameters out inside a capture
+        with torch.no_grad():
+            flat = torch.cat([a.detach(), b.detach()], 0)
+            a.data = flat[:a.shape[0]]
+            b.data = flat[a.shape[0]:]
+        owner.__dict__[key] = flat
+    return _AdjacentCat.apply(flat, a, b)
 
 
 def _is_power_of_2(n):
@@ -98,9 +137,10 @@ class MSDeformAttn(nn.Module):
         value = value.view(N, Len_in, M, self.d_model // M)
 
         n_off = M * L * P * 2
+        # (the two projections' parameters share one buffer: "concatenating" them is free, see adjacent_cat)
         qproj = token_linear(query,
-                             torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
-                             torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+                             adjacent_cat(self, "_qproj_w", self.sampling_offsets.weight, self.attention_weights.weight),
+                             adjacent_cat(self, "_qproj_b", self.sampling_offsets.bias, self.attention_weights.bias))
         if (qproj.is_cuda and fused_geometry and L == 4 and P == 4 and reference_points.shape[-1] in (2, 4)
                 and qproj.dtype in (torch.float32, torch.bfloat16)):
             if (fused_sampling and msda_function is msda.MSDeformAttnFunction and qproj.dtype == value.dtype

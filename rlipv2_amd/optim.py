@@ -82,7 +82,8 @@ class FusedMasterAdamW:
         return idx, grads
 
     def _table(self, idx, grads, eff_group):
-        key = (tuple(idx), tuple(g.data_ptr() for g in grads), tuple(eff_group))
+        # (parameter addresses are part of the key: modules may re-lay their parameters out, deform_attn.adjacent_cat)
+        key = (tuple(idx), tuple(g.data_ptr() for g in grads), tuple(eff_group), tuple(self.params[i].data_ptr() for i in idx))
         hit = self._tables.get(key)
         if hit is not None:
             return hit

@@ -78,6 +78,7 @@ def test_add_layer_norm_module_route_and_fallback():
         norm.AddLayerNormFunction.apply(torch.zeros(8, 256), None, torch.ones(256), torch.zeros(256), 1e-5)
 
 
+@gpu
 def test_add_relu_kernel_is_bit_identical_to_add_then_relu():
     """csrc/elementwise.hip: relu(a + b) in one pass (the ResNet bottleneck tail) -- same bits as the two PyTorch ops in
     bfloat16 (the sum is rounded before the clamp), for contiguous and channels-last tensors, and the same gradients."""
@@ -103,6 +104,7 @@ def test_add_relu_kernel_is_bit_identical_to_add_then_relu():
     assert torch.equal(backbone.add_relu(c, c), torch.relu(c + c))
 
 
+@gpu
 def test_affine_relu_kernels_match_frozen_batchnorm_then_relu():
     """csrc/elementwise.hip: relu(bn(x)) for a FrozenBatchNorm2d as one pass (and its backward as one pass): the same
     bits as addcmul + relu forward, the same gradient as autograd's threshold_backward + mul to bf16 rounding."""

@@ -465,6 +465,13 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
             "batch_per_gpu": args.batch,
             "pyramid": PYRAMID_800x1333,
             "parallelism": parallelism,
+            "library_tuning": {
+                "miopen": ("find at first use (RLIPV2_MIOPEN_FIND=1)" if os.environ.get("RLIPV2_MIOPEN_FIND", "0") == "1"
+                           else "recorded find-db, lookup only (rlipv2_amd/tuned/miopen)"
+                           if "rlipv2_miopen_db" in os.environ.get("MIOPEN_USER_DB_PATH", "") else "library default"),
+                "hipblaslt": "recorded solution table, lookup only (rlipv2_amd/tuned/gemm_gfx950.csv)"
+                             if os.environ.get("RLIPV2_TUNED_GEMMS", "1") != "0" else "library default",
+            },
         },
         "roofline": {
             "bound": "hbm",

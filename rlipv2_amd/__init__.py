@@ -5,7 +5,49 @@ C ABI of ``include/rlipv2_msda.h``) and the host-side mirror of the reference's 
 module interface.  There is no CPU fallback: every op raises if the HIP library is missing or
 a tensor is not on the GPU.
 """
-from .msda import (  # noqa: F401
+import os as _os
+
+
+def use_tuned_miopen_db() -> str | None:
+    """Points MIOpen (the library behind the 3x3 / 7x7 / strided convolutions of the R50 trunk) at the Find results
+    recorded on an MI355X by `tools/tune_miopen.sh` (`rlipv2_amd/tuned/miopen/`, two small text files keyed by MIOpen
+    version and device).  Without them PyTorch's immediate mode picks split-K solvers with float32 workspace
+    zero / cast passes for most of these shapes: 41.8 against 39.8 ms per train step on the same box.  Lookup only
+    -- nothing is searched at run time unless the caller turns on `torch.backends.cudnn.benchmark`.  The files are
+    copied to a scratch directory (MIOpen writes into its user-db directory; the tree stays as committed).
+    A MIOPEN_USER_DB_PATH set by the caller wins; RLIPV2_TUNED_MIOPEN=0 disables.  Must run before the first
+    convolution of the process (import time)."""
+    if _os.environ.get("RLIPV2_TUNED_MIOPEN", "1") == "0" or _os.environ.get("MIOPEN_USER_DB_PATH"):
+        return None
+    import shutil
+    import tempfile
+    src = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuned", "miopen")
+    if not _os.path.isdir(src):
+        return None
+    import hashlib
+    names = sorted(n for n in _os.listdir(src) if n.endswith(".txt"))
+    digest = hashlib.md5()
+    for name in names:
+        with open(_os.path.join(src, name), "rb") as f:
+            digest.update(f.read())
+    dst = _os.path.join(tempfile.gettempdir(), "rlipv2_miopen_db_%d_%s" % (_os.getuid(), digest.hexdigest()[:10]))
+    try:
+        _os.makedirs(dst, exist_ok=True)
+        for name in names:
+            target = _os.path.join(dst, name)
+            if not _os.path.exists(target):
+                tmp = "%s.%d.tmp" % (target, _os.getpid())
+                shutil.copyfile(_os.path.join(src, name), tmp)
+                _os.replace(tmp, target)                    # atomic: the other ranks of the node race for this
+    except OSError:
+        return None
+    _os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return dst
+
+
+use_tuned_miopen_db()
+
+from .msda import (  # noqa: E402,F401
     MSDeformAttnFunction,
     ms_deform_attn_backward,
     ms_deform_attn_forward,

@@ -13,6 +13,7 @@ from .blocks import MLP, inverse_sigmoid, sine_embed_for_position
 from .deform_attn import MSDeformAttn
 from .encoder import _activation, _clones
 from .linear import token_linear
+from .norm import add_layer_norm
 
 
 class DeformableTransformerDecoderLayer(nn.Module):
@@ -42,16 +43,16 @@ class DeformableTransformerDecoderLayer(nn.Module):
         if self.do_self_attn:
             qk = (tgt if query_pos is None else tgt + query_pos).transpose(0, 1)
             sa = self.self_attn(qk, qk, tgt.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
-            tgt = self.norm2(tgt + self.dropout2(sa))
+            tgt = add_layer_norm(tgt, self.dropout2(sa), self.norm2)
         ca = self.cross_attn(tgt if query_pos is None else tgt + query_pos, reference_points, src,
                              src_spatial_shapes, level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(ca))
+        tgt = add_layer_norm(tgt, self.dropout1(ca), self.norm1)
         if self.activation is F.relu:
             hidden = token_linear(tgt, self.linear1.weight, self.linear1.bias, relu=True)
         else:
             hidden = self.activation(self.linear1(tgt))
         ffn = self.linear2(self.dropout3(hidden))
-        return self.norm3(tgt + self.dropout4(ffn))
+        return add_layer_norm(tgt, self.dropout4(ffn), self.norm3)
 
 
 class DABDeformableTransformerDecoderHOI(nn.Module):

@@ -115,7 +115,7 @@ __device__ __forceinline__ void mfma_step(const StepFragments &s, f32x16 (&acc)[
 template <int dbg, int DIRECT = 0>
 __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
     const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x, int M, int K, int steps_total,
-    int steps_per_chunk, int chunks, float *__restrict__ partial, float *__restrict__ bias_partial)
+    int steps_per_chunk, int chunks, int bias_parts, float *__restrict__ partial, float *__restrict__ bias_partial)
 {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tiles_k = K / BN, tiles = (M / BM) * tiles_k;
@@ -163,7 +163,14 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
     float bsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-    const bool want_bias = (tk == 0) && bias_partial != nullptr;
+    // Bias gradient: the `bias_parts` (1, 2, 4 or 8; 1 when DIRECT) workgroups tk < bias_parts of a (chunk, tm) row share
+    // the column sums of the dY tile they all hold: part tk takes row groups [tk, tk + 1) * 8 / bias_parts of every step.
+    // (With one workgroup doing all of it -- 2 x b128 + ~40 VALU per thread per step next to 8 MFMAs -- the tk == 0
+    //  workgroups ran 1.5x longer than the others and the kernel waited for them: tools/wgrad_big.py, ablation arms.)
+    const bool want_bias = (tk < bias_parts) && bias_partial != nullptr;
+    const int rg_lo = tk * (8 / bias_parts), rg_hi = rg_lo + 8 / bias_parts;
+    const bool bias_h0 = want_bias && wave >= rg_lo && wave < rg_hi;              // wave-uniform
+    const bool bias_h1 = want_bias && wave + 4 >= rg_lo && wave + 4 < rg_hi;
 
     // Always four DMAs per wave per call, so the vmcnt arithmetic below is exact; steps past the end of
     // the chunk re-load its last step into a stage nobody reads again.
@@ -180,7 +187,8 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
     auto compute = [&](auto stage_c) {
         constexpr int SB = decltype(stage_c)::value * STAGE_BYTES;
         StepFragments f0, f1;
-        if (dbg & 2) {
+        if (dbg & 8) {                                          // DMA only
+        } else if (dbg & 2) {
             for (int q = 0; q < 8; ++q) { f0.r[q] = s16x4{1, 2, 3, 4}; f1.r[q] = s16x4{1, 2, 3, 4}; }
             mfma_step(f0, acc);
             mfma_step(f1, acc);
@@ -198,20 +206,25 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
         wait_step(f1);
         mfma_step(f1, acc);
         }
-        if (want_bias) {
-            // thread t re-reads slot t & 63 of row groups (t >> 6) and (t >> 6) + 4 of the dY tile: always
-            // the same 8 columns (piece (t & 15) ^ 4 ((t >> 4) & 3)), one row of each group
-            u32x4 v[2] = {lds_read_b128<SB>(bias_addr), lds_read_b128<SB + 4 * GROUP_BYTES>(bias_addr)};
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]));
+        // thread t re-reads slot t & 63 of row groups (t >> 6) and (t >> 6) + 4 of the dY tile: always
+        // the same 8 columns (piece (t & 15) ^ 4 ((t >> 4) & 3)), one row of each group
+        auto bias_add = [&](const u32x4 &v) {
+            const uint32_t w[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t w[4] = {v[h][0], v[h][1], v[h][2], v[h][3]};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bsum[2 * j] += bf16_to_float(w[j] & 0xffffu);
-                    bsum[2 * j + 1] += bf16_to_float(w[j] >> 16);
-                }
+            for (int j = 0; j < 4; ++j) {
+                bsum[2 * j] += __uint_as_float(w[j] << 16);
+                bsum[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
             }
+        };
+        if (bias_h0) {
+            u32x4 v = lds_read_b128<SB>(bias_addr);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+            bias_add(v);
+        }
+        if (bias_h1) {
+            u32x4 v = lds_read_b128<SB + 4 * GROUP_BYTES>(bias_addr);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+            bias_add(v);
         }
     };
     // iteration i: this wave's DMAs of step i have landed once at most the 4 of step i+1 are outstanding;
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
             float s = 0.f;
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) s += red[rg * BM + tid];
-            const size_t e = (size_t)(DIRECT ? 0 : chunk) * M + tm * BM + tid;
+            const size_t e = (size_t)(DIRECT ? 0 : chunk * bias_parts + tk) * M + tm * BM + tid;
             if (DIRECT == 1) reinterpret_cast<uint16_t *>(bias_partial)[e] = rne(s);              // `bias_partial` IS db
             else bias_partial[e] = s;
         }
@@ -341,7 +354,8 @@ __device__ __forceinline__ void reduce_body(const float *__restrict__ partial, i
 // bias-gradient partials (db may be absent: then the grid is dw_blocks)
 template <bool F32, int CG>
 __global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__ partial,
-                                                       const float *__restrict__ bias_partial, int chunks, int dw_blocks,
+                                                       const float *__restrict__ bias_partial, int chunks, int bias_slots,
+                                                       int dw_blocks,
                                                        const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x,
                                                        int tail0, int T, int M, int K, void *__restrict__ dw,
                                                        void *__restrict__ db)
@@ -350,16 +364,16 @@ __global__ __launch_bounds__(256) void reduce_partials(const float *__restrict__
     if ((int)blockIdx.x < dw_blocks)
         reduce_body<F32, false, CG>(partial, chunks, (size_t)M * K, blockIdx.x, dy, x, tail0, T, M, K, dw, red);
     else
-        reduce_body<F32, true, CG>(bias_partial, chunks, (size_t)M, blockIdx.x - dw_blocks, dy, x, tail0, T, M, K, db, red);
+        reduce_body<F32, true, CG>(bias_partial, bias_slots, (size_t)M, blockIdx.x - dw_blocks, dy, x, tail0, T, M, K, db, red);
 }
 
-struct Plan { int chunks, steps_per_chunk, steps_total, tiles; size_t partial_floats, bias_floats; };
+struct Plan { int chunks, steps_per_chunk, steps_total, tiles, bias_parts; size_t partial_floats, bias_floats; };
 
 bool make_plan(int T, int M, int K, Plan &pl)
 {
     if (T < 1 || M < BM || K < BN || M % BM || K % BN) return false;
-    pl.tiles = (M / BM) * (K / BN);
     pl.steps_total = T / BK;                                   // whole 32-token steps; the rest is the tail
+    pl.tiles = (M / BM) * (K / BN);
     // two workgroups per CU in flight (a third fits, but its extra partial sums cost more than it hides)
     static int target = msda::ablation_env("RLIPV2_WGRAD_BLOCKS", 512);   // measured: 512 beats 768 (fewer partials) and 256
     int chunks = (target + pl.tiles - 1) / pl.tiles;
@@ -371,7 +385,11 @@ bool make_plan(int T, int M, int K, Plan &pl)
     pl.chunks = pl.steps_total ? (pl.steps_total + pl.steps_per_chunk - 1) / pl.steps_per_chunk : 0;
     // at least one slot so that the workspace is never empty
     pl.partial_floats = (size_t)(pl.chunks ? pl.chunks : 1) * M * K;
-    pl.bias_floats = (size_t)(pl.chunks ? pl.chunks : 1) * M;
+    // workgroups of one (chunk, tm) row that share the bias gradient's column sums (power of two, <= 8 row groups)
+    const int tiles_k = K / BN;
+    pl.bias_parts = tiles_k >= 8 ? 8 : tiles_k >= 4 ? 4 : tiles_k >= 2 ? 2 : 1;
+    if (pl.chunks <= 1) pl.bias_parts = 1;                     // (the one-chunk kernel writes db itself)
+    pl.bias_floats = (size_t)(pl.chunks ? pl.chunks : 1) * pl.bias_parts * M;
     return true;
 }
 
@@ -408,11 +426,11 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
         const int grid = ((pl.tiles + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
         if (out_f32)
             hipLaunchKernelGGL((wgrad_kernel<0, 2>), dim3(grid), dim3(THREADS), LDS_BYTES, stream, dy16, x16, M, K,
-                               pl.steps_total, pl.steps_per_chunk, pl.chunks, static_cast<float *>(dw),
+                               pl.steps_total, pl.steps_per_chunk, pl.chunks, 1, static_cast<float *>(dw),
                                static_cast<float *>(db));
         else
             hipLaunchKernelGGL((wgrad_kernel<0, 1>), dim3(grid), dim3(THREADS), LDS_BYTES, stream, dy16, x16, M, K,
-                               pl.steps_total, pl.steps_per_chunk, pl.chunks, static_cast<float *>(dw),
+                               pl.steps_total, pl.steps_per_chunk, pl.chunks, 1, static_cast<float *>(dw),
                                static_cast<float *>(db));
         return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
     }
@@ -421,7 +439,7 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
         const int grid = ((total + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
         static int dbg = msda::ablation_env("RLIPV2_WGRAD_DBG", 0);      // ablation builds only (skips work)
 #define LAUNCH(D) hipLaunchKernelGGL(wgrad_kernel<D>, dim3(grid), dim3(THREADS), LDS_BYTES, stream, dy16, x16, M, K, \
-                                     pl.steps_total, pl.steps_per_chunk, pl.chunks, partial, db ? bias_partial : nullptr)
+                                     pl.steps_total, pl.steps_per_chunk, pl.chunks, pl.bias_parts, partial, db ? bias_partial : nullptr)
         switch (dbg) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;
@@ -429,6 +447,7 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
         case 4: LAUNCH(4); break;
         case 5: LAUNCH(5); break;
         case 7: LAUNCH(7); break;
+        case 8: LAUNCH(8); break;
         default: LAUNCH(0); break;
         }
 #undef LAUNCH
@@ -440,7 +459,7 @@ extern "C" int linear_wgrad_bf16(const void *dy, const void *x, int T, int M, in
     const int cg = terms >= 16 ? 16 : terms >= 4 ? 4 : 1, q = 256 / cg;
     const int gw = (int)((n / 4 + q - 1) / q), gb = db ? (int)(((size_t)M / 4 + q - 1) / q) : 0;
 #define REDUCE(F, C) hipLaunchKernelGGL((reduce_partials<F, C>), dim3(gw + gb), dim3(256), 0, stream, partial, bias_partial, \
-                                        pl.chunks, gw, dy16, x16, tail0, T, M, K, dw, db)
+                                        pl.chunks, pl.chunks * pl.bias_parts, gw, dy16, x16, tail0, T, M, K, dw, db)
     if (out_f32) { if (cg == 16) REDUCE(true, 16); else if (cg == 4) REDUCE(true, 4); else REDUCE(true, 1); }
     else         { if (cg == 16) REDUCE(false, 16); else if (cg == 4) REDUCE(false, 4); else REDUCE(false, 1); }
 #undef REDUCE

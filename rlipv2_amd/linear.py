@@ -24,7 +24,8 @@ enabled = True
 _workspaces = {}
 
 
-TUNED_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
+TUNED_TABLE = os.environ.get("RLIPV2_TUNED_GEMM_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned",
+                                                                         "gemm_gfx950.csv")
 
 
 def use_tuned_library_gemms(path: str = TUNED_TABLE) -> bool:

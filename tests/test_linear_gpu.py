@@ -25,7 +25,9 @@ def _case(T, M, K, seed=0):
                                    (480, 384, 128), (33, 256, 128), (1000, 128, 256),
                                    (600, 256, 256), (2048, 384, 256), (2049, 256, 384), (2079, 128, 128),
                                    (4099, 384, 256), (22223, 256, 256), (88892, 256, 256), (88892, 1024, 256),
-                                   (88892, 256, 1024), (88892, 384, 256)])
+                                   (88892, 256, 1024), (88892, 384, 256),
+                                   # bias gradient shared by 8 / 4 / 4 workgroups of a row of tiles (K / 128 >= 2)
+                                   (88892, 2048, 256), (88892, 256, 2048), (32769, 1024, 512), (40000, 768, 768)])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 def test_wgrad_matches_float32_reference(T, M, K, out_dtype):
     from rlipv2_amd import linear
@@ -60,6 +62,13 @@ def test_wgrad_exact_on_integer_data():
     dw2, no_bias = linear.linear_wgrad(dy.to(torch.bfloat16).cuda(), x.to(torch.bfloat16).cuda(), with_bias=False,
                                        out_dtype=torch.float32)
     assert no_bias is None and torch.equal(dw2, dw)
+    # many chunks, 6 tiles per row: the bias gradient's column sums are split over 4 workgroups per row
+    T, M, K = 33001, 768, 768
+    dy = torch.randint(-2, 3, (T, M), generator=g)
+    x = torch.randint(-2, 3, (T, K), generator=g)
+    dw, db = linear.linear_wgrad(dy.to(torch.bfloat16).cuda(), x.to(torch.bfloat16).cuda(), out_dtype=torch.float32)
+    assert torch.equal(dw.cpu().long(), dy.t() @ x)
+    assert torch.equal(db.cpu().long(), dy.sum(0))
 
 
 @gpu

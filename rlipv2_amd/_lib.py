@@ -38,6 +38,9 @@ EXPORTS = (
     "alif_attention_softmax_backward_bf16",
     # include/rlipv2_elementwise.h
     "add_relu_bf16", "affine_relu_bf16", "affine_relu_backward_bf16",
+    # include/rlipv2_groupnorm.h
+    "groupnorm_tokens_supported", "groupnorm_tokens_workspace_bytes", "groupnorm_tokens_forward_bf16",
+    "groupnorm_tokens_backward_bf16",
 )
 
 _lib = None
@@ -129,6 +132,14 @@ def lib() -> ctypes.CDLL:
     L.affine_relu_bf16.argtypes = [vp, vp, vp, vp, lg, i, vp]
     L.affine_relu_backward_bf16.argtypes = [vp, vp, vp, vp, lg, i, vp]
     L.affine_relu_bf16.restype = L.affine_relu_backward_bf16.restype = i
+    L.groupnorm_tokens_supported.argtypes = [i, i, i]
+    L.groupnorm_tokens_workspace_bytes.argtypes = [i, ip, i]
+    L.groupnorm_tokens_workspace_bytes.restype = ctypes.c_size_t
+    pp = ctypes.POINTER(vp)
+    L.groupnorm_tokens_forward_bf16.argtypes = [pp, ip, i, i, pp, pp, f32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.groupnorm_tokens_backward_bf16.argtypes = [vp, pp, ip, i, i, pp, vp, vp, pp, pp, pp, vp, ctypes.c_size_t, vp]
+    L.groupnorm_tokens_supported.restype = L.groupnorm_tokens_forward_bf16.restype = i
+    L.groupnorm_tokens_backward_bf16.restype = i
     _lib = L
     return L
 

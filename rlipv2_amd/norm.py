@@ -95,3 +95,90 @@ def add_layer_norm(a, b, norm: torch.nn.LayerNorm):
     if supported(a, b, norm.weight, norm.bias) and len(norm.normalized_shape) == 1:
         return AddLayerNormFunction.apply(a, b, norm.weight, norm.bias, norm.eps)
     return norm(a if b is None else a + b)
+
+
+# ---- GroupNorm(32, 256) of the token-major feature pyramid (csrc/groupnorm_tokens.hip, include/rlipv2_groupnorm.h) ----
+level_group_norm_enabled = os.environ.get("RLIPV2_LEVEL_GN", "1") != "0"
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(values):
+    import ctypes
+    return (ctypes.c_int * len(values))(*values)
+
+
+def level_group_norm_supported(xs, norms) -> bool:
+    if not (level_group_norm_enabled and 1 <= len(xs) <= 4 and len(xs) == len(norms)):
+        return False
+    for x, gn in zip(xs, norms):
+        if not (isinstance(gn, torch.nn.GroupNorm) and gn.affine and x.is_cuda and x.dim() == 3
+                and x.dtype == torch.bfloat16 and gn.weight.dtype == torch.bfloat16 and gn.bias.dtype == torch.bfloat16
+                and x.shape[0] == xs[0].shape[0] and gn.eps == norms[0].eps
+                and _lib.lib().groupnorm_tokens_supported(x.shape[-1], gn.num_groups, len(xs))):
+            return False
+    return not torch.is_autocast_enabled()
+
+
+class LevelGroupNormFunction(torch.autograd.Function):
+    """(x_0 .. x_{L-1}, gamma_0, beta_0, .. ) -> [N, sum(hw_l), 256]: every level normalised into its slice of the
+    flattened pyramid (reference: input_proj's GroupNorm, models/hoi.py:1936-1957, + the flatten / cat of
+    models/dab_deformable/deformable_transformer.py:520-547)."""
+
+    @staticmethod
+    def forward(ctx, eps, n_levels, *args):
+        xs = [a.contiguous() for a in args[:n_levels]]
+        gammas = list(args[n_levels:2 * n_levels])
+        betas = list(args[2 * n_levels:3 * n_levels])
+        if not xs[0].is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        N = xs[0].shape[0]
+        hw = [x.shape[1] for x in xs]
+        L = _lib.lib()
+        out = torch.empty(N, sum(hw), xs[0].shape[2], dtype=xs[0].dtype, device=xs[0].device)
+        mean = torch.empty(n_levels, N, 32, dtype=torch.float32, device=out.device)
+        rstd = torch.empty_like(mean)
+        hw_c = _int_array(hw)
+        ws = _workspace(out.device, L.groupnorm_tokens_workspace_bytes(N, hw_c, n_levels))
+        _check(L.groupnorm_tokens_forward_bf16(_ptr_array(xs), hw_c, n_levels, N, _ptr_array(gammas), _ptr_array(betas),
+                                               float(eps), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(),
+                                               ws.numel(), torch.cuda.current_stream(out.device).cuda_stream),
+               "groupnorm_tokens_forward")
+        roofline.add(2 * roofline.tensor_bytes(*xs) + roofline.tensor_bytes(out))
+        ctx.save_for_backward(mean, rstd, *xs, *gammas)
+        ctx.n_levels = n_levels
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        n = ctx.n_levels
+        mean, rstd = ctx.saved_tensors[:2]
+        xs = list(ctx.saved_tensors[2:2 + n])
+        gammas = list(ctx.saved_tensors[2 + n:2 + 2 * n])
+        dy = dy.contiguous()
+        N = xs[0].shape[0]
+        hw = [x.shape[1] for x in xs]
+        L = _lib.lib()
+        dxs = [torch.empty_like(x) for x in xs]
+        dgs = [torch.empty_like(g) for g in gammas]
+        dbs = [torch.empty_like(g) for g in gammas]
+        hw_c = _int_array(hw)
+        ws = _workspace(dy.device, L.groupnorm_tokens_workspace_bytes(N, hw_c, n))
+        _check(L.groupnorm_tokens_backward_bf16(dy.data_ptr(), _ptr_array(xs), hw_c, n, N, _ptr_array(gammas),
+                                                mean.data_ptr(), rstd.data_ptr(), _ptr_array(dxs), _ptr_array(dgs),
+                                                _ptr_array(dbs), ws.data_ptr(), ws.numel(),
+                                                torch.cuda.current_stream(dy.device).cuda_stream),
+               "groupnorm_tokens_backward")
+        roofline.add(2 * roofline.tensor_bytes(dy, *xs) + roofline.tensor_bytes(*dxs))
+        return (None, None, *dxs, *dgs, *dbs)
+
+
+def level_group_norm(xs, norms):
+    """[N, hw_l, 256] token-major projections of the pyramid levels + their GroupNorm modules -> the flattened,
+    normalised [N, sum(hw_l), 256] tensor the encoder consumes."""
+    return LevelGroupNormFunction.apply(norms[0].eps, len(xs), *xs, *[gn.weight for gn in norms],
+                                        *[gn.bias for gn in norms])

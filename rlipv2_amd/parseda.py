@@ -56,6 +56,12 @@ def default_args(**overrides):
     return a
 
 
+
+class LevelViews(list):
+    """Per-level [N, 256, H, W] views of one flattened [N, S, 256] tensor (`.flat`)."""
+    flat = None
+
+
 class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
     def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
                  dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4,
@@ -139,7 +145,9 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
         if encode_and_save:
             shapes_list = [tuple(s.shape[-2:]) for s in srcs]
             bs = srcs[0].shape[0]
-            src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+            src_flatten = getattr(srcs, "flat", None)        # (levels already flattened by the model's projection)
+            if src_flatten is None:
+                src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
             mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
             lvl_pos = torch.cat([add_row_vector(p.flatten(2).transpose(1, 2), self.level_embed[l])
                                  for l, p in enumerate(pos_embeds)], 1)
@@ -329,17 +337,28 @@ class RLIP_ParSeDA(nn.Module):
             with torch.cuda.stream(side):
                 encoded_text = tr._encode_text(text, samples.tensors.shape[0], samples.tensors.device)
         srcs, masks = [], []
-        for l, feat in enumerate(features):
-            src, mask = feat.decompose()
-            assert mask is not None
-            srcs.append(self.input_proj[l](src))
-            masks.append(mask)
-        for l in range(len(srcs), self.num_feature_levels):
-            src = self.input_proj[l](features[-1].tensors if l == len(features) else srcs[-1])
-            mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]   # Q13
-            pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
-            srcs.append(src)
-            masks.append(mask)
+        fast = self._project_levels_token_major(features)
+        if fast is not None:
+            # (every level projected + normalised token-major, straight into the flattened [N, S, 256] tensor; the
+            #  per-level NCHW tensors handed on are views of it, `srcs.flat` lets the transformer skip its cat)
+            srcs = fast
+            masks = [feat.decompose()[1] for feat in features]
+            for l in range(len(features), self.num_feature_levels):
+                mask = F.interpolate(samples.mask[None].float(), size=srcs[l].shape[-2:]).to(torch.bool)[0]   # Q13
+                pos.append(self.backbone[1](NestedTensor(srcs[l], mask)).to(srcs[l].dtype))
+                masks.append(mask)
+        else:
+            for l, feat in enumerate(features):
+                src, mask = feat.decompose()
+                assert mask is not None
+                srcs.append(self.input_proj[l](src))
+                masks.append(mask)
+            for l in range(len(srcs), self.num_feature_levels):
+                src = self.input_proj[l](features[-1].tensors if l == len(features) else srcs[-1])
+                mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]   # Q13
+                pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
+                srcs.append(src)
+                masks.append(mask)
         query_embeds = self._query_embeds()
         if encoded_text is not None:
             torch.cuda.current_stream().wait_stream(side)
@@ -348,6 +367,47 @@ class RLIP_ParSeDA(nn.Module):
         return self.transformer(srcs=srcs, masks=masks, pos_embeds=pos, query_embed=query_embeds, text=text,
                                 encode_and_save=True, encoded_text=encoded_text,
                                 no_padding=bool(getattr(samples, "no_padding", False)))
+
+    def _project_levels_token_major(self, features):
+        """input_proj (reference models/hoi.py:1936-1957) on channels-last bf16 features without leaving the token-major
+        layout: the 1x1 convolutions are GEMMs over [N*H*W, C_in] views, the extra level's 3x3 stride-2 convolution stays
+        on MIOpen, and one GroupNorm launch pair writes all levels into the flattened tensor (`norm.level_group_norm`).
+        Returns None when the fast path does not apply (float32 / autocast runs, more than one extra level, other
+        widths): the caller falls back to the module-by-module form."""
+        from .linear import token_linear
+        from .norm import level_group_norm, level_group_norm_supported
+        n_out = len(features)
+        if self.num_feature_levels - n_out > 1 or self.num_feature_levels > 4 or torch.is_autocast_enabled():
+            return None
+        xs, shapes = [], []
+        for l in range(self.num_feature_levels):
+            conv = self.input_proj[l][0]
+            x = features[min(l, n_out - 1)].tensors
+            if not (x.is_cuda and x.dtype == torch.bfloat16 and conv.weight.dtype == torch.bfloat16
+                    and x.is_contiguous(memory_format=torch.channels_last)):
+                return None
+            if l < n_out:
+                if conv.kernel_size != (1, 1) or conv.stride != (1, 1):
+                    return None
+                N, Cin, H, W = x.shape
+                y = token_linear(x.permute(0, 2, 3, 1).reshape(N, H * W, Cin), conv.weight.view(conv.out_channels, Cin),
+                                 conv.bias)
+            else:
+                y4 = conv(x)                                            # channels-last in, channels-last out
+                N, _, H, W = y4.shape
+                y = y4.permute(0, 2, 3, 1).reshape(N, H * W, y4.shape[1])
+            xs.append(y)
+            shapes.append((H, W))
+        norms = [proj[1] for proj in self.input_proj]
+        if not level_group_norm_supported(xs, norms):
+            return None
+        flat = level_group_norm(xs, norms)                              # [N, S, 256]
+        srcs, start = LevelViews(), 0
+        for (H, W), y in zip(shapes, xs):
+            srcs.append(flat[:, start:start + H * W].view(flat.shape[0], H, W, flat.shape[2]).permute(0, 3, 1, 2))
+            start += H * W
+        srcs.flat = flat
+        return srcs
 
     def forward(self, samples, encode_and_save=True, memory_cache=None, **kwargs):
         if not isinstance(samples, NestedTensor):

@@ -129,3 +129,50 @@ def test_affine_relu_kernels_match_frozen_batchnorm_then_relu():
     torch.cuda.synchronize()
     assert torch.equal(y, ref)
     assert torch.equal(gx, x.grad)
+
+
+# ---- GroupNorm(32, 256) of the token-major pyramid (csrc/groupnorm_tokens.hip) against torch.nn.functional.group_norm in
+# float64 on the same bf16 inputs.  Tolerances: outputs / dx are bf16 (one rounding, 2^-8 relative, of a float32 result);
+# dgamma / dbeta are sums over N * H * W terms in float32, rounded once to bf16.
+def _gn_case(N, hw, seed):
+    g = torch.Generator().manual_seed(seed)
+    xs = [(torch.randn(N, t, 256, generator=g) * (1 + 0.5 * l) + 0.2 * l).to(torch.bfloat16) for l, t in enumerate(hw)]
+    gam = [(1 + 0.2 * torch.randn(256, generator=g)).to(torch.bfloat16) for _ in hw]
+    bet = [(0.1 * torch.randn(256, generator=g)).to(torch.bfloat16) for _ in hw]
+    dy = torch.randn(N, sum(hw), 256, generator=g).to(torch.bfloat16)
+    return xs, gam, bet, dy
+
+
+@gpu
+@pytest.mark.parametrize("N,hw", [(1, [1]), (2, [300, 77, 20, 6]), (3, [256, 257]), (4, [16700, 4200, 1050, 273])])
+def test_level_group_norm_matches_float64_group_norm(N, hw):
+    from rlipv2_amd import norm
+    xs, gam, bet, dy = _gn_case(N, hw, sum(hw) + N)
+    eps = 1e-5
+    mods = []
+    for g_, b_ in zip(gam, bet):
+        m = torch.nn.GroupNorm(32, 256, eps=eps).cuda().to(torch.bfloat16)
+        m.weight.data.copy_(g_); m.bias.data.copy_(b_)
+        mods.append(m)
+    xc = [x.cuda().requires_grad_(True) for x in xs]
+    assert norm.level_group_norm_supported(xc, mods)
+    out = norm.level_group_norm(xc, mods)
+    out.backward(dy.cuda())
+    out2 = norm.level_group_norm([x.detach() for x in xc], mods)
+    assert torch.equal(out, out2)                                               # repeatable bit for bit
+    start = 0
+    for l, t in enumerate(hw):
+        xd = xs[l].double().requires_grad_(True)
+        gd, bd = gam[l].double().requires_grad_(True), bet[l].double().requires_grad_(True)
+        # [N, t, 256] token-major -> [N, 256, t]: group statistics over t x 8 channels
+        ref = F.group_norm(xd.transpose(1, 2), 32, gd, bd, eps).transpose(1, 2)
+        ref.backward(dy[:, start:start + t].double())
+        got = out[:, start:start + t].float().cpu()
+        assert ((got - ref.detach()).abs() <= 2.0 ** -7 * ref.detach().abs() + 1e-3).all(), l
+        dx = xc[l].grad.float().cpu()
+        scale = float(xd.grad.abs().max())
+        assert ((dx - xd.grad).abs() <= 2.0 ** -7 * xd.grad.abs() + 2e-3 * scale).all(), l
+        for got_p, ref_p in ((mods[l].weight.grad, gd.grad), (mods[l].bias.grad, bd.grad)):
+            tol = 2.0 ** -7 * ref_p.abs() + 1e-5 * (N * t) ** 0.5 * float(dy.abs().max()) * 4 + 1e-3
+            assert ((got_p.float().cpu() - ref_p).abs() <= tol).all(), l
+        start += t

@@ -5,6 +5,8 @@ and DABDeformableTransformerDecoderHOI (:1404-1552).  Parameter names match the 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -14,6 +16,27 @@ from .deform_attn import MSDeformAttn
 from .encoder import _activation, _clones
 from .linear import token_linear
 from .norm import add_layer_norm
+
+
+class _SplitRows(torch.autograd.Function):
+    """(w[:n], w[n:]) as views; the backward is ONE cat of the two gradients (plain slicing costs a zero-fill, a copy
+    and an accumulation per slice)."""
+
+    @staticmethod
+    def forward(ctx, w, n):
+        ctx.n, ctx.shape = n, w.shape
+        return w[:n], w[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            g = (ga if ga is not None else gb).new_zeros(ctx.shape)
+            (g[:ctx.n] if ga is not None else g[ctx.n:]).copy_(ga if ga is not None else gb)
+            return g, None
+        return torch.cat((ga, gb), 0), None
+
+
+direct_self_attention = os.environ.get("RLIPV2_DEC_SELF_ATTN", "1") != "0"      # (A/B switch)
 
 
 class DeformableTransformerDecoderLayer(nn.Module):
@@ -41,9 +64,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask=None):
         if self.do_self_attn:
-            qk = (tgt if query_pos is None else tgt + query_pos).transpose(0, 1)
-            sa = self.self_attn(qk, qk, tgt.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
-            tgt = add_layer_norm(tgt, self.dropout2(sa), self.norm2)
+            tgt = add_layer_norm(tgt, self.dropout2(self._self_attention(tgt, query_pos)), self.norm2)
         ca = self.cross_attn(tgt if query_pos is None else tgt + query_pos, reference_points, src,
                              src_spatial_shapes, level_start_index, src_padding_mask)
         tgt = add_layer_norm(tgt, self.dropout1(ca), self.norm1)
@@ -53,6 +74,30 @@ class DeformableTransformerDecoderLayer(nn.Module):
             hidden = self.activation(self.linear1(tgt))
         ffn = self.linear2(self.dropout3(hidden))
         return add_layer_norm(tgt, self.dropout4(ffn), self.norm3)
+
+
+def _decoder_self_attention(self, tgt, query_pos):
+    """nn.MultiheadAttention(q = k = tgt + pos, v = tgt) of the decoder layer (reference deformable_transformer.py:
+    1377-1381) on the module's own parameters, batch-first throughout: one GEMM for Q and K, one for V, fused attention,
+    output projection -- no seq-first round trip (the module transposes [N, nq, C] -> [nq, N, C] and back, 8 copies per
+    layer and direction) and one `cat` instead of slice gradients for the packed projection."""
+    mha = self.self_attn
+    if not (direct_self_attention and tgt.is_cuda and mha._qkv_same_embed_dim and mha.in_proj_bias is not None
+            and mha.bias_k is None and not mha.add_zero_attn and not torch.is_autocast_enabled()):
+        qk = (tgt if query_pos is None else tgt + query_pos).transpose(0, 1)
+        return mha(qk, qk, tgt.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
+    B, L, E = tgt.shape
+    H = mha.num_heads
+    w_qk, w_v = _SplitRows.apply(mha.in_proj_weight, 2 * E)
+    b_qk, b_v = _SplitRows.apply(mha.in_proj_bias, 2 * E)
+    qk = token_linear(tgt if query_pos is None else tgt + query_pos, w_qk, b_qk).view(B, L, 2, H, E // H)
+    v = token_linear(tgt, w_v, b_v).view(B, L, H, E // H)
+    out = F.scaled_dot_product_attention(qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2), v.transpose(1, 2),
+                                         dropout_p=mha.dropout if self.training else 0.0)
+    return token_linear(out.transpose(1, 2).reshape(B, L, E), mha.out_proj.weight, mha.out_proj.bias)
+
+
+DeformableTransformerDecoderLayer._self_attention = _decoder_self_attention
 
 
 class DABDeformableTransformerDecoderHOI(nn.Module):

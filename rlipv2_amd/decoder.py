@@ -170,5 +170,9 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
 
         if self.return_intermediate:
             refs = torch.stack((torch.stack(inter_sub), torch.stack(inter_obj)), dim=0).transpose(0, 1)
-            return torch.stack(inter), refs
+            hs = torch.stack(inter)
+            # consumers that walk the layers take the per-layer tensors themselves: hs[l] would put a select (and its
+            # zero-fill + copy + accumulate backward) between every head and the layer that feeds it
+            hs.layers = tuple(inter)
+            return hs, refs
         return output, reference_points

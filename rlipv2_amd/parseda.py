@@ -202,7 +202,7 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
 
         hs_ho, inter_refs = self.ho_decoder(tgt, init_reference, img_memory, spatial_shapes, level_start_index,
                                             valid_ratios, query_pos=None, src_padding_mask=masks)
-        last_sub, last_obj = hs_ho[-1][:, :nq // 2], hs_ho[-1][:, nq // 2:]
+        last_sub, last_obj = getattr(hs_ho, "layers", hs_ho)[-1].split(nq // 2, dim=1)
         kind = self.verb_query_tgt_type
         if kind == "vanilla":
             verb_in = verb_tgt[:, :nq // 2] + verb_tgt[:, nq // 2:]
@@ -418,12 +418,16 @@ class RLIP_ParSeDA(nn.Module):
         mc = memory_cache
         hs_ho, hs_verb, text_dec, init_reference, inter_references, _, _, _, _ = self._transformer_phase_b(mc)
         half = self.num_queries // 2
-        hs_h, hs_o = hs_ho[:, :, :half], hs_ho[:, :, half:]
+        # per-layer decoder outputs (the tensors the layers produced, not selects of their stack), split once into the
+        # subject / object halves: one cat in the backward pass instead of slice gradients
+        ho_layers, verb_layers = getattr(hs_ho, "layers", hs_ho), getattr(hs_verb, "layers", hs_verb)
         sums = mc["obj_pred_names_sums"]
         n_obj, n_verb = int(sums[:, 0].max()), int(sums[:, 1].max())
 
         sub_cls, obj_cls, verb_cls, sub_box, obj_box = [], [], [], [], []
-        for lvl in range(hs_h.shape[0]):
+        hs_h, hs_o = [None] * len(ho_layers), [None] * len(ho_layers)
+        for lvl in range(len(ho_layers)):
+            hs_h[lvl], hs_o[lvl] = ho_layers[lvl].split(half, dim=1)
             ref_s, ref_o = init_reference if lvl == 0 else inter_references[lvl - 1]
             sub_box.append(_add_reference(self.sub_bbox_embed[lvl](hs_h[lvl]), ref_s).sigmoid())
             obj_box.append(_add_reference(self.obj_bbox_embed[lvl](hs_o[lvl]), ref_o).sigmoid())
@@ -432,7 +436,7 @@ class RLIP_ParSeDA(nn.Module):
             assert n_obj + n_verb == proj.shape[1]
             obj_text, verb_text = proj[:, :n_obj], proj[:, n_obj:n_obj + n_verb]
             obj_cls.append(torch.matmul(hs_o[lvl] + self.bias_obj_a, obj_text.transpose(1, 2)) + self.bias_c)
-            verb_cls.append(torch.matmul(hs_verb[lvl] + self.bias_pred_a, verb_text.transpose(1, 2)) + self.bias_c)
+            verb_cls.append(torch.matmul(verb_layers[lvl] + self.bias_pred_a, verb_text.transpose(1, 2)) + self.bias_c)
             if self.subject_class:
                 sub_cls.append(torch.matmul(hs_h[lvl] + self.bias_obj_a, obj_text.transpose(1, 2)) + self.bias_c)
 

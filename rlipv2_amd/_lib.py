@@ -41,6 +41,8 @@ EXPORTS = (
     # include/rlipv2_groupnorm.h
     "groupnorm_tokens_supported", "groupnorm_tokens_workspace_bytes", "groupnorm_tokens_forward_bf16",
     "groupnorm_tokens_backward_bf16",
+    # include/rlipv2_decoder.h
+    "dab_refine_boxes", "dab_reference_embed",
 )
 
 _lib = None
@@ -140,6 +142,9 @@ def lib() -> ctypes.CDLL:
     L.groupnorm_tokens_backward_bf16.argtypes = [vp, pp, ip, i, i, pp, vp, vp, pp, pp, pp, vp, ctypes.c_size_t, vp]
     L.groupnorm_tokens_supported.restype = L.groupnorm_tokens_forward_bf16.restype = i
     L.groupnorm_tokens_backward_bf16.restype = i
+    L.dab_refine_boxes.argtypes = [vp, i, vp, vp, lg, f32, vp]
+    L.dab_reference_embed.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, vp, i, vp]
+    L.dab_refine_boxes.restype = L.dab_reference_embed.restype = i
     _lib = L
     return L
 

@@ -340,6 +340,9 @@ class RLIPv2_VLFuse(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # sparse language layer (RoBERTa-base encoder layer, post-LN)
 # ------------------------------------------------------------------------------------------------
+fused_text_attention = os.environ.get("RLIPV2_TEXT_SDPA", "1") != "0"      # (A/B switch)
+
+
 class _RobertaSelfAttention(nn.Module):
     def __init__(self, hidden, heads, attn_dropout):
         super().__init__()
@@ -352,6 +355,19 @@ class _RobertaSelfAttention(nn.Module):
 
     def forward(self, x, additive_mask):
         B, T, C = x.shape
+        if fused_text_attention and x.is_cuda and not torch.is_autocast_enabled():
+            # one GEMM for the three projections (their parameters share one buffer: deform_attn.adjacent_cat_n) and the
+            # library's fused attention on strided views of its output: the matmul / scale / mask / softmax / dropout /
+            # matmul chain and the head permutes' copies were ~25 launch-bound launches per layer and direction
+            from .deform_attn import adjacent_cat_n
+            from .linear import token_linear
+            w = adjacent_cat_n(self, "_qkv_w", (self.query.weight, self.key.weight, self.value.weight))
+            b = adjacent_cat_n(self, "_qkv_b", (self.query.bias, self.key.bias, self.value.bias))
+            qkv = token_linear(x, w, b).view(B, T, 3, self.num_attention_heads, self.attention_head_size)
+            q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+            out = F.scaled_dot_product_attention(q, k, v, attn_mask=additive_mask,
+                                                 dropout_p=self.dropout.p if self.training else 0.0)
+            return out.transpose(1, 2).reshape(B, T, C)
         split = lambda t: t.view(B, T, self.num_attention_heads, self.attention_head_size).permute(0, 2, 1, 3)
         q, k, v = split(self.query(x)), split(self.key(x)), split(self.value(x))
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(self.attention_head_size)

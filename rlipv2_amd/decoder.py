@@ -11,7 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .blocks import MLP, inverse_sigmoid, sine_embed_for_position
+from . import _lib
+from .blocks import MLP, _sine_dim_t, inverse_sigmoid, sine_embed_for_position
 from .deform_attn import MSDeformAttn
 from .encoder import _activation, _clones
 from .linear import token_linear
@@ -37,6 +38,46 @@ class _SplitRows(torch.autograd.Function):
 
 
 direct_self_attention = os.environ.get("RLIPV2_DEC_SELF_ATTN", "1") != "0"      # (A/B switch)
+fused_glue = os.environ.get("RLIPV2_DEC_GLUE", "1") != "0"                     # (A/B switch)
+
+
+def _glue_ok(*tensors):
+    return fused_glue and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def refine_boxes(delta, ref, eps=1e-5):
+    """sigmoid(delta + inverse_sigmoid(ref)) without autograd, float32 (reference deformable_transformer.py:1519-1541):
+    one launch of csrc/decoder_glue.hip on the GPU."""
+    with torch.no_grad():
+        if not (_glue_ok(ref) and delta.is_cuda and delta.dtype in (torch.bfloat16, torch.float32)
+                and delta.shape == ref.shape and ref.shape[-1] == 4):
+            return (delta.float() + inverse_sigmoid(ref, eps)).sigmoid()
+        delta, ref = delta.contiguous(), ref.contiguous()
+        out = torch.empty_like(ref)
+        st = _lib.lib().dab_refine_boxes(delta.data_ptr(), int(delta.dtype == torch.bfloat16), ref.data_ptr(),
+                                         out.data_ptr(), ref.numel() // 4, float(eps),
+                                         torch.cuda.current_stream(ref.device).cuda_stream)
+        if st:
+            raise RuntimeError("dab_refine_boxes: " + _lib.strerror(st))
+        return out
+
+
+def reference_embed(sub_ref, obj_ref, valid_ratios, parse, out_dtype):
+    """(ref_in [N, nq, L, 4] float32, sine features of its level 0 [N, nq, 512] in `out_dtype`) from the anchor boxes:
+    one launch of csrc/decoder_glue.hip (the boxes are detached, nothing here carries a gradient)."""
+    N, n, _ = sub_ref.shape
+    L = valid_ratios.shape[1]
+    nq = 2 * n if parse else n
+    sub_ref, obj_ref, valid_ratios = sub_ref.contiguous(), obj_ref.contiguous(), valid_ratios.contiguous()
+    ref_in = torch.empty(N, nq, L, 4, dtype=torch.float32, device=sub_ref.device)
+    embed = torch.empty(N, nq, 512, dtype=out_dtype, device=sub_ref.device)
+    st = _lib.lib().dab_reference_embed(sub_ref.data_ptr(), obj_ref.data_ptr(), valid_ratios.data_ptr(),
+                                        _sine_dim_t(sub_ref.device).data_ptr(), N, n, L, int(bool(parse)),
+                                        ref_in.data_ptr(), embed.data_ptr(), int(out_dtype == torch.bfloat16),
+                                        torch.cuda.current_stream(sub_ref.device).cuda_stream)
+    if st:
+        raise RuntimeError("dab_reference_embed: " + _lib.strerror(st))
+    return ref_in, embed
 
 
 class DeformableTransformerDecoderLayer(nn.Module):
@@ -142,13 +183,21 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
         # (explicit .float() before mixing with the float32 box chain: PyTorch-ROCm's mixed-dtype elementwise
         #  kernel costs ~40 us even on a [4, 150, 4] tensor, against ~2 us for a cast + a same-dtype op)
         inter, inter_sub, inter_obj = [], [], []
+        glue = (self.use_dab and not self.no_sine_embed and _glue_ok(sub_ref, obj_ref, src_valid_ratios)
+                and output.dtype in (torch.bfloat16, torch.float32) and src_valid_ratios.shape[1] <= 8)
         for lid, layer in enumerate(self.layers):
-            if self.ParSe:
+            feat = None
+            # (layer 0's anchors are learnable parameters and keep the differentiable form; the refined boxes of the
+            #  later layers are detached)
+            if glue and not (sub_ref.requires_grad or obj_ref.requires_grad):
+                ref_in, feat = reference_embed(sub_ref, obj_ref, src_valid_ratios, self.ParSe, output.dtype)
+            elif self.ParSe:
                 ref_in = torch.cat((sub_ref[:, :, None] * ratios4, obj_ref[:, :, None] * ratios4), dim=1)
             else:
                 ref_in = 0.5 * (sub_ref + obj_ref)[:, :, None] * ratios4
             if self.use_dab:
-                feat = ref_in if self.no_sine_embed else sine_embed_for_position(ref_in[:, :, 0, :])
+                if feat is None:
+                    feat = ref_in if self.no_sine_embed else sine_embed_for_position(ref_in[:, :, 0, :])
                 raw = self.ref_point_head(feat.to(output.dtype))
                 query_pos = raw if lid == 0 else self.query_scale(output) * raw
             if self.high_dim_query_update and lid != 0:
@@ -157,12 +206,15 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
             output = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
                            src_padding_mask)
 
+            # (the refined boxes are detached, reference :1525 / :1541: heads and chain run without autograd)
             if self.sub_bbox_embed is not None:
-                h = output[:, :n_pair] if self.ParSe else output
-                sub_ref = (self.sub_bbox_embed[lid](h).float() + inverse_sigmoid(sub_ref)).sigmoid().detach()
+                with torch.no_grad():
+                    delta = self.sub_bbox_embed[lid](output[:, :n_pair] if self.ParSe else output)
+                sub_ref = refine_boxes(delta, sub_ref)
             if self.obj_bbox_embed is not None:
-                h = output[:, n_pair:] if self.ParSe else output
-                obj_ref = (self.obj_bbox_embed[lid](h).float() + inverse_sigmoid(obj_ref)).sigmoid().detach()
+                with torch.no_grad():
+                    delta = self.obj_bbox_embed[lid](output[:, n_pair:] if self.ParSe else output)
+                obj_ref = refine_boxes(delta, obj_ref)
             if self.return_intermediate:
                 inter.append(output)
                 inter_sub.append(sub_ref)

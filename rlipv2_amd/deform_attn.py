@@ -45,7 +45,48 @@ class _AdjacentCat(torch.autograd.Function):
         return None, g[:ctx.rows], g[ctx.rows:]
 
 
+class _AdjacentCatN(torch.autograd.Function):
+    """torch.cat(params, 0) of parameters that live back to back in ONE buffer (see _AdjacentCat)."""
+
+    @staticmethod
+    def forward(ctx, flat, *params):
+        ctx.rows = [p.shape[0] for p in params]
+        return flat.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, r0 = [None], 0
+        for r in ctx.rows:
+            out.append(g[r0:r0 + r])
+            r0 += r
+        return tuple(out)
+
+
 shared_parameter_storage = os.environ.get("RLIPV2_ADJACENT_CAT", "1") != "0"      # (A/B switch)
+
+
+def adjacent_cat_n(owner, key, params):
+    """`adjacent_cat` for any number of parameters (the query / key / value projections of a RoBERTa layer)."""
+    if not shared_parameter_storage:
+        return torch.cat(list(params), 0)
+    flat = owner.__dict__.get(key)
+    ok = flat is not None and flat.shape[0] == sum(p.shape[0] for p in params)
+    if ok:
+        off = flat.data_ptr()
+        for p in params:
+            ok = ok and p.data_ptr() == off and p.is_contiguous() and p.dtype == flat.dtype and p.device == flat.device
+            off += p.numel() * p.element_size()
+    if not ok:
+        if torch.cuda.is_available() and params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            return torch.cat(list(params), 0)                # never re-lay parameters out inside a capture
+        with torch.no_grad():
+            flat = torch.cat([p.detach() for p in params], 0)
+            r0 = 0
+            for p in params:
+                p.data = flat[r0:r0 + p.shape[0]]
+                r0 += p.shape[0]
+        owner.__dict__[key] = flat
+    return _AdjacentCatN.apply(flat, *params)
 
 
 def adjacent_cat(owner, key, a, b):

@@ -654,3 +654,33 @@ def test_checkpoint_round_trip_with_the_fused_optimiser_on_gpu(tmp_path):
     torch.cuda.synchronize()
     worst = max(float((a.float() - b.float()).abs().max()) for a, b in zip(m1.parameters(), m2.parameters()))
     assert worst <= 1e-3, worst          # (the device backward is not bit-repeatable: attention atomics)
+
+
+@pytest.mark.parametrize("parse", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_decoder_glue_kernels_match_the_op_sequence(parse, dtype):
+    """csrc/decoder_glue.hip against the PyTorch statement of the same float32 arithmetic (decoder.py's fallback path,
+    reference deformable_transformer.py:1490-1541): the reference points and the refined boxes exactly (same operations,
+    same order, same device math library), the sine features to one bf16 / float32 rounding of sin / cos."""
+    from rlipv2_amd.blocks import inverse_sigmoid, sine_embed_for_position
+    g = torch.Generator().manual_seed(5)
+    N, n, L = 3, 37, 4
+    sub = torch.rand(N, n, 4, generator=g).cuda()
+    obj = torch.rand(N, n, 4, generator=g).cuda()
+    obj[0, 0] = torch.tensor([0.0, 1.0, 1e-7, 1 - 1e-7])                       # clamp / eps branches of inverse_sigmoid
+    ratios = (0.5 + 0.5 * torch.rand(N, L, 2, generator=g)).cuda()
+    ratios4 = torch.cat([ratios, ratios], -1)[:, None]
+    ref_in, feat = decoder.reference_embed(sub, obj, ratios, parse, dtype)
+    if parse:
+        want = torch.cat((sub[:, :, None] * ratios4, obj[:, :, None] * ratios4), dim=1)
+    else:
+        want = 0.5 * (sub + obj)[:, :, None] * ratios4
+    assert torch.equal(ref_in, want)
+    want_feat = sine_embed_for_position(want[:, :, 0, :])
+    tol = 2.0 ** -8 if dtype == torch.bfloat16 else 2e-6
+    assert (feat.float() - want_feat).abs().max() <= tol
+    delta = (torch.randn(N, n, 4, generator=g) * 2).to(dtype).cuda()
+    got = decoder.refine_boxes(delta, obj)
+    want_box = (delta.float() + inverse_sigmoid(obj)).sigmoid()
+    assert (got - want_box).abs().max() <= 1e-6
+    assert got.dtype == torch.float32 and not got.requires_grad

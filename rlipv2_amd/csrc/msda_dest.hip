@@ -86,6 +86,7 @@ struct DestPlan {                            // by-value kernel argument, built 
     int cbase[kL];                           // first combine block of a split level (one per tile), -1 if unsplit
     int Td, Ts;                              // destination tiles, source tiles
     int items, pslots, ctiles;
+    int queues;                              // item queues: 8 (one per XCD) when N * M divides, else 1
     int tiled;                               // source tiles are 16x16 patches of the pyramid (Lq == S)
 };
 
@@ -292,20 +293,32 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
 
     unsigned long long ts_last = clock64();
     (void)ts_last;
+    // Item queues.  pl.queues == 8: one queue per XCD (workgroup b runs on XCD b % 8) holding the items of NM / 8
+    // consecutive (image, head) pairs -- neighbouring destination tiles of one (image, head) share most of their source
+    // rows (a query's 4 points of a level straddle ~2.5 tiles), and with ONE queue those re-reads were spread over all
+    // eight L2s (every XCD saw all N * M slices: 80 MB of live rows against 4 MB of L2).  A workgroup that finds its
+    // queue empty helps with the next XCD's (the tail only).
+    const int nq = pl.queues, NMq = NM / nq;
+    int queue = (int)(blockIdx.x % (unsigned)nq), tried = 0;
     for (;;) {
-        if (tid == 0) misc[16] = atomicAdd(counter, 1);
+        if (tid == 0) misc[16] = atomicAdd(counter + queue * 4, 1);
         __syncthreads();
         DTS(0);
         const int item = misc[16];
-        if (item >= pl.items) break;
+        if (item >= pl.items / nq) {
+            if (++tried >= nq) break;
+            queue = (queue + 1) % nq;
+            __syncthreads();                 // (everybody has read misc[16])
+            continue;
+        }
 
         // ---- decode the item: destination level (coarsest first), tile, part, (image, head) -----------------------
         int l = 0;
 #pragma unroll
-        for (int k = 1; k < kL; ++k) l = (item >= pl.ibase[k] && item < pl.ibase[k] + pl.nitems[k]) ? k : l;
-        const int local = item - pl.ibase[l];
-        const int nm = local % NM;
-        const int rest = local / NM;
+        for (int k = 1; k < kL; ++k) l = (item >= pl.ibase[k] / nq && item < (pl.ibase[k] + pl.nitems[k]) / nq) ? k : l;
+        const int local = item - pl.ibase[l] / nq;
+        const int nm = queue * NMq + local % NMq;
+        const int rest = local / NMq;
         const int nparts = pl.parts[l];
         const int part = rest % nparts, d = rest / nparts;
         const int n = nm / M, m = nm % M;
@@ -603,6 +616,8 @@ bool make_plan(const Problem &p, const int64_t *hs, DestPlan &pl)
         }
     }
     pl.items = items; pl.pslots = pslots; pl.ctiles = ctiles;
+    static const int xcd_queues = ablation_env("RLIPV2_DEST_XCD", 1);
+    pl.queues = (xcd_queues && NM % 8 == 0) ? 8 : 1;
     return true;
 }
 

@@ -43,6 +43,8 @@ EXPORTS = (
     "groupnorm_tokens_backward_bf16",
     # include/rlipv2_decoder.h
     "dab_refine_boxes", "dab_reference_embed",
+    # include/rlipv2_matcher.h
+    "hoi_assign_batch",
 )
 
 _lib = None
@@ -145,6 +147,8 @@ def lib() -> ctypes.CDLL:
     L.dab_refine_boxes.argtypes = [vp, i, vp, vp, lg, f32, vp]
     L.dab_reference_embed.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, vp, i, vp]
     L.dab_refine_boxes.restype = L.dab_reference_embed.restype = i
+    L.hoi_assign_batch.argtypes = [vp, i, i, i, ip, vp, vp, lg]
+    L.hoi_assign_batch.restype = lg
     _lib = L
     return L
 

@@ -16,6 +16,8 @@ the GIoU costs are reused; results are identical.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -148,6 +150,9 @@ def build_weight_dict(dec_layers, obj_loss_coef=1.0, verb_loss_coef=1.0, bbox_lo
         for i in range(dec_layers - 1):
             w.update({f'{k}_{i}': v for k, v in list(w.items()) if not k[-1].isdigit()})
     return w
+
+
+native_assignment = os.environ.get("RLIPV2_NATIVE_LSA", "1") != "0"      # (A/B switch)
 
 
 class SetCriterionHOI(nn.Module):
@@ -314,11 +319,30 @@ class SetCriterionHOI(nn.Module):
         """number of (query, target) pairs the assignment yields: min(nq, targets) per image and layer"""
         return K * sum(min(nq, n) for n in sizes)
 
-    def assign(self, state):
-        """Host side: the cost matrix comes over in ONE copy, scipy solves the K*bs assignment problems;
-        returns int64 [2, K*n]: rows of the stacked predictions / columns of the concatenated targets."""
+    def assign(self, state, C_host=None):
+        """Host side: the cost matrix comes over in ONE copy (`C_host`: the caller's host copy, e.g. a pinned staging
+        buffer; else copied here), the K*bs assignment problems are solved in one native call (`hoi_assign_batch`,
+        include/rlipv2_matcher.h: scipy's algorithm and tie-breaking without Python in the loop; RLIPV2_NATIVE_LSA=0 or a
+        non-finite cost goes through scipy itself); returns int64 [2, K*n]: rows of the stacked predictions / columns of
+        the concatenated targets."""
         K, bs, nq, sizes = state['K'], state['bs'], state['nq'], state['sizes']
-        C_host = state['C'].float().cpu().view(K, bs, nq, sum(sizes))
+        if C_host is None:
+            C_host = state['C'].float().cpu()
+        C_host = C_host.view(K, bs, nq, sum(sizes))
+        if native_assignment and C_host.dtype == torch.float32 and C_host.is_contiguous():
+            from . import _lib
+            import ctypes
+            n = self.matched_pairs(sizes, nq, K)
+            out = torch.empty(2, n, dtype=torch.int64)
+            if n == 0:
+                return out
+            got = _lib.lib().hoi_assign_batch(C_host.data_ptr(), K, bs, nq, (ctypes.c_int * bs)(*sizes),
+                                              out[0].data_ptr(), out[1].data_ptr(), n)
+            if got == n:
+                return out
+            if got != -1:
+                raise RuntimeError(f"hoi_assign_batch returned {got} for {n} expected pairs")
+            # (NaN / -inf / infeasible: let scipy raise the reference's error)
         starts = [0]
         for n in sizes:
             starts.append(starts[-1] + n)

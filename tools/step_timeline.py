@@ -40,9 +40,10 @@ for it in range(steps + 3):
     graphed._load_inputs(samples, text, targets)
     graphed.fwd_graph.replay()
     ev[1].record(); hs.append(time.perf_counter())
-    graphed.pinned_index.copy_(criterion.assign(graphed.state))
+    graphed.pinned_index.copy_(criterion.assign(graphed.state, graphed._cost_on_host()))
     graphed.static_index.copy_(graphed.pinned_index, non_blocking=True)
-    graphed.static_num.copy_(criterion._num_interactions(graphed.sizes, graphed.static_num.device).reshape(1))
+    if sync is not None:
+        graphed.static_num.copy_(criterion._num_interactions(graphed.sizes, graphed.static_num.device).reshape(1))
     ev[2].record(); hs.append(time.perf_counter())
     graphed.bwd_graph.replay()
     graphed._deliver()

@@ -195,14 +195,23 @@ __device__ __forceinline__ int select_bit(uint32_t w, int k)      // position of
     return pos;
 }
 
+// inclusive prefix sum over the 64 lanes on DPP row shifts / broadcasts (gfx9 encodings; the ds_bpermute form of
+// __shfl_up costs an LDS round trip per step, six steps per scan, two scans per pass)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_add(int v)
+{
+    // lanes whose source is outside the row / masked off keep `v + 0` (old = 0, bound_ctrl = false keeps `old`)
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
 __device__ __forceinline__ int wave_inclusive_scan(int v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(v, off, 64);
-        if (lane >= off) v += u;
-    }
+    v = dpp_add<0x111, 0xf, 0xf>(v);           // row_shr:1
+    v = dpp_add<0x112, 0xf, 0xf>(v);           // row_shr:2
+    v = dpp_add<0x114, 0xf, 0xf>(v);           // row_shr:4
+    v = dpp_add<0x118, 0xf, 0xf>(v);           // row_shr:8   -> inclusive within each row of 16
+    v = dpp_add<0x142, 0xa, 0xf>(v);           // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc, 0xf>(v);           // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -250,10 +259,12 @@ template <> struct GRow<float> {
 // LDS carve-up (bytes; every offset a multiple of 16)
 template <typename VT, int TH> struct DestLds {
     typedef Geo<TH> G;
-    static constexpr int kOffG = 0;
-    static constexpr int kOffRec = kOffG + G::kGroups * GRow<VT>::kStride;
-    static constexpr int kOffHist = kOffRec + G::kRec * 8;                    // int [waves][pixels]
-    static constexpr int kOffPix = kOffHist + G::kWaves * G::kPix * 4;        // int pixoff[pixels], tot[pixels]
+    static constexpr int kOffG = 0;                                           // [2 pass parities][groups] staged rows
+    static constexpr int kGBytes = G::kGroups * GRow<VT>::kStride;
+    static constexpr int kOffRec = kOffG + 2 * kGBytes;
+    static constexpr int kOffHist = kOffRec + G::kRec * 8;                    // int [2 pass parities][waves][pixels]
+    static constexpr int kHistInts = G::kWaves * G::kPix;
+    static constexpr int kOffPix = kOffHist + 2 * kHistInts * 4;              // int pixoff[pixels], tot[pixels]
     static constexpr int kOffMisc = kOffPix + 2 * G::kPix * 4;                // int [32]: wave sums, item, ...
     static constexpr int kOffSrc = kOffMisc + 128;                      // per source tile: mask[8], off, q0, pitch
     static int bytes(int Ts) { return kOffSrc + Ts * 32 + (Ts + 4) * 4 * 3; }
@@ -273,10 +284,13 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
     typedef DestLds<VT, TH> LD;
     typedef Geo<TH> G;
     constexpr int kPix = G::kPix, kThreads = G::kThreads, kGroups = G::kGroups, kWaves = G::kWaves;
-    static_assert(kThreads * 16 >= kWaves * kPix * 4, "hist is cleared with one 16-byte store per thread");
-    unsigned char *gl = lds + LD::kOffG;
+    static_assert(kThreads * 16 >= 2 * kWaves * kPix * 4, "hist is cleared with one 16-byte store per thread");
+    // Staged rows and per-wave histograms are double-buffered by pass parity: a wave that has finished walking pass c
+    // starts phase 1 of pass c + 1 (stage rows, histogram atomics) while slower quads still walk -- the walk needs no
+    // closing barrier.  (rec / pixoff / tot are rewritten only behind the next pass's first barrier.)
+    unsigned char *gl0 = lds + LD::kOffG;
     uint2 *rec = reinterpret_cast<uint2 *>(lds + LD::kOffRec);
-    int *hist = reinterpret_cast<int *>(lds + LD::kOffHist);
+    int *hist0 = reinterpret_cast<int *>(lds + LD::kOffHist);
     int *pixoff = reinterpret_cast<int *>(lds + LD::kOffPix);
     int *tot = pixoff + kPix;
     int *misc = reinterpret_cast<int *>(lds + LD::kOffMisc);          // [0..15] wave sums, [16] item
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
         {
             const uint32_t *mg = masks + ((size_t)((long)nm * pl.Td + pl.tbase[l] + d) * Ts) * 8;
             for (int i = tid; i < Ts * 8; i += kThreads) mrow[i] = mg[i];
-            if (tid * 4 < kWaves * kPix) reinterpret_cast<int4 *>(hist)[tid] = make_int4(0, 0, 0, 0);
+            if (tid * 4 < 2 * kWaves * kPix) reinterpret_cast<int4 *>(hist0)[tid] = make_int4(0, 0, 0, 0);
         }
         __syncthreads();
         {
@@ -418,6 +432,8 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
 
         for (int c0 = 0; c0 < npass; ++c0) {
             // ---- pass, phase 1: one thread per (group, point) ------------------------------------------------------
+            unsigned char *gl = gl0 + (c0 & 1) * LD::kGBytes;
+            int *hist = hist0 + (c0 & 1) * LD::kHistInts;
             const Fetch me = nxt;
 #ifdef MSDA_DEST_TIMELINE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -466,13 +482,21 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
             __syncthreads();
             DTS(3);
             // ---- phase 2: per pixel, prefix over the waves; prefix over the pixels -----------------------------------
+            // (the other parity's histograms were last read before the previous pass's third barrier: clear them for the
+            //  next pass here, ordered before anybody's next phase 1 by this pass's remaining barriers)
+            {
+                int *nh = hist0 + ((c0 + 1) & 1) * LD::kHistInts;
+                if (tid * 4 < kWaves * kPix) reinterpret_cast<int4 *>(nh)[tid] = make_int4(0, 0, 0, 0);
+            }
             if (tid < kPix) {
+                int cnt[kWaves];                                   // all the loads first: one LDS round trip, not kWaves
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) cnt[w] = hist[w * kPix + tid];
                 int run = 0;
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) {
-                    const int c = hist[w * kPix + tid];
                     hist[w * kPix + tid] = run;
-                    run += c;
+                    run += cnt[w];
                 }
                 tot[tid] = run;
                 const int inc = wave_inclusive_scan(run);
@@ -497,7 +521,6 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
             __syncthreads();
             DTS(7);
             // ---- phase 4: every quad walks the list of its pixel; the next pass's operands travel meanwhile ----------
-            if (tid * 4 < kWaves * kPix) reinterpret_cast<int4 *>(hist)[tid] = make_int4(0, 0, 0, 0);   // for the next pass
             {
                 const int kw = grp >> 6;
                 const int wpre = kw == 0 ? 0 : kw == 1 ? ws0 : kw == 2 ? ws1 : ws2;
@@ -517,8 +540,7 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
                 }
             }
             DTS(8);
-            __syncthreads();
-            DTS(9);
+            DTS(9);                          // (no barrier: see the double-buffering note at the top of the kernel)
 #ifdef MSDA_DEST_TIMELINE
             if (tid == 0 && blockIdx.x == 0) dest_ts[15] += 1;
 #endif

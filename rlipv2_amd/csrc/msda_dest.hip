@@ -222,13 +222,16 @@ template <> struct GRow<bf16_t> {
     typedef uint4 piece;
     static __device__ __forceinline__ piece load_global(const bf16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
     static __device__ __forceinline__ void store_lds(unsigned char *p, const piece &v) { *reinterpret_cast<uint4 *>(p) = v; }
-    static __device__ __forceinline__ void fma(float w, const unsigned char *p, float (&acc)[8])
+    static __device__ __forceinline__ void fma_piece(float w, const uint4 &r, float (&acc)[8])
     {
-        const uint4 r = *reinterpret_cast<const uint4 *>(p);
         acc[0] = fmaf(w, bf16_lo(r.x), acc[0]); acc[1] = fmaf(w, bf16_hi(r.x), acc[1]);
         acc[2] = fmaf(w, bf16_lo(r.y), acc[2]); acc[3] = fmaf(w, bf16_hi(r.y), acc[3]);
         acc[4] = fmaf(w, bf16_lo(r.z), acc[4]); acc[5] = fmaf(w, bf16_hi(r.z), acc[5]);
         acc[6] = fmaf(w, bf16_lo(r.w), acc[6]); acc[7] = fmaf(w, bf16_hi(r.w), acc[7]);
+    }
+    static __device__ __forceinline__ void fma(float w, const unsigned char *p, float (&acc)[8])
+    {
+        fma_piece(w, *reinterpret_cast<const uint4 *>(p), acc);
     }
 };
 template <> struct GRow<float> {
@@ -247,12 +250,16 @@ template <> struct GRow<float> {
         *reinterpret_cast<float4 *>(p) = v.a;
         *reinterpret_cast<float4 *>(p + 16) = v.b;
     }
-    static __device__ __forceinline__ void fma(float w, const unsigned char *p, float (&acc)[8])
+    static __device__ __forceinline__ void fma_piece(float w, const piece &r, float (&acc)[8])
     {
-        const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 16);
+        const float4 a = r.a, b = r.b;
         acc[0] = fmaf(w, a.x, acc[0]); acc[1] = fmaf(w, a.y, acc[1]); acc[2] = fmaf(w, a.z, acc[2]);
         acc[3] = fmaf(w, a.w, acc[3]); acc[4] = fmaf(w, b.x, acc[4]); acc[5] = fmaf(w, b.y, acc[5]);
         acc[6] = fmaf(w, b.z, acc[6]); acc[7] = fmaf(w, b.w, acc[7]);
+    }
+    static __device__ __forceinline__ void fma(float w, const unsigned char *p, float (&acc)[8])
+    {
+        fma_piece(w, *reinterpret_cast<const piece *>(p), acc);
     }
 };
 
@@ -534,9 +541,17 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
                     GRow<VT>::fma(__uint_as_float(rc.x), gsub + rc.y, acc);
                     GRow<VT>::fma(__uint_as_float(rd.x), gsub + rd.y, acc);
                 }
-                for (; i < e; ++i) {
-                    const uint2 ra = rec[i];
-                    GRow<VT>::fma(__uint_as_float(ra.x), gsub + ra.y, acc);
+                if (i < e) {
+                    // the last 1-3 records in ONE round of reads (a record-at-a-time tail is two dependent LDS round trips
+                    // per record); same order of additions, absent records skipped
+                    const int n_left = e - i;
+                    const uint2 ra = rec[i], rb = rec[min(i + 1, e - 1)], rc = rec[min(i + 2, e - 1)];
+                    typename GRow<VT>::piece pa = *reinterpret_cast<const typename GRow<VT>::piece *>(gsub + ra.y);
+                    typename GRow<VT>::piece pb = *reinterpret_cast<const typename GRow<VT>::piece *>(gsub + rb.y);
+                    typename GRow<VT>::piece pc = *reinterpret_cast<const typename GRow<VT>::piece *>(gsub + rc.y);
+                    GRow<VT>::fma_piece(__uint_as_float(ra.x), pa, acc);
+                    if (n_left > 1) GRow<VT>::fma_piece(__uint_as_float(rb.x), pb, acc);
+                    if (n_left > 2) GRow<VT>::fma_piece(__uint_as_float(rc.x), pc, acc);
                 }
             }
             DTS(8);

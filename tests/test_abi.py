@@ -162,3 +162,31 @@ def test_compat_shim_registers_reference_import_paths():
         for k in [k for k in sys.modules if k == "MultiScaleDeformableAttention" or k.startswith("models")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_round2_entry_points_validate_their_arguments_on_the_host():
+    """groupnorm / decoder-glue / matcher entry points: shape and pointer checks run before anything touches a device."""
+    import ctypes
+    from rlipv2_amd import _lib
+    L = _lib.lib()
+    assert L.groupnorm_tokens_supported(256, 32, 4) == 1 and L.groupnorm_tokens_supported(256, 32, 1) == 1
+    assert L.groupnorm_tokens_supported(128, 32, 4) == 0 and L.groupnorm_tokens_supported(256, 16, 4) == 0
+    assert L.groupnorm_tokens_supported(256, 32, 5) == 0 and L.groupnorm_tokens_supported(256, 32, 0) == 0
+    hw = (ctypes.c_int * 4)(16700, 4200, 1050, 273)
+    chunks = sum((n + 255) // 256 for n in hw)                       # 256 tokens per workgroup
+    want = (4 * chunks * 256 * 2 + 4 * 4 * 32 * 2 + 4 * 4 * 256 * 2) * 4
+    assert L.groupnorm_tokens_workspace_bytes(4, hw, 4) == want
+    assert L.groupnorm_tokens_workspace_bytes(0, hw, 4) == 0 and L.groupnorm_tokens_workspace_bytes(4, hw, 5) == 0
+    bad = (ctypes.c_int * 2)(10, 0)
+    assert L.groupnorm_tokens_workspace_bytes(2, bad, 2) == 0
+    assert L.groupnorm_tokens_forward_bf16(None, hw, 4, 4, None, None, 1e-5, None, None, None, None, 0, None) != 0
+    # decoder glue: empty problems are a no-op, negative sizes and missing pointers are refused
+    assert L.dab_refine_boxes(None, 1, None, None, 0, 1e-5, None) == 0
+    assert L.dab_refine_boxes(None, 1, None, None, -1, 1e-5, None) != 0
+    assert L.dab_refine_boxes(None, 1, None, None, 8, 1e-5, None) != 0
+    assert L.dab_reference_embed(None, None, None, None, 0, 5, 4, 1, None, None, 1, None) == 0
+    assert L.dab_reference_embed(None, None, None, None, 2, 5, 9, 1, None, None, 1, None) != 0
+    assert L.dab_reference_embed(None, None, None, None, 2, 5, 4, 1, None, None, 1, None) != 0
+    # matcher: argument errors are -2
+    sizes = (ctypes.c_int * 1)(3)
+    assert L.hoi_assign_batch(None, 1, 1, 4, sizes, None, None, 3) == -2

@@ -416,6 +416,7 @@ def run_train_step_bench(args, world, rank, local_rank, device):
                 lambda: train.train_step(eager_step, criterion, optimizer, batch, autocast_dtype=dtype))
         except Exception as e:                                  # noqa: BLE001 -- accounting only, never fatal
             print(f"[bench] step roofline probe failed: {type(e).__name__}: {e}", file=sys.stderr)
+            step_roofline = {"error": f"{type(e).__name__}: {e}"}   # the line says so instead of dropping the key
     return elapsed, timer.summary(), float(loss), n_params, graphed, step_roofline
 
 
@@ -498,7 +499,9 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
     }
     if b0 is not None:
         line["roofline"]["b0_signature_kernels"] = b0
-    if step_roofline is not None:
+    if step_roofline is not None and "error" in step_roofline:
+        line["step_roofline"] = step_roofline
+    elif step_roofline is not None:
         t_mem, t_mfma = step_roofline["T_mem_s"], step_roofline["T_mfma_s"]
         step_s = elapsed / args.steps
         line["step_roofline"] = {
@@ -516,6 +519,27 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
     print(json.dumps(line), flush=True)
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child process and return its exit code.  Counting devices does not initialise the GPU on this
+    image (torch.cuda.device_count() reads the driver's device list)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus and os.environ.get("RLIPV2_SINGLE_DEVICE") != "1":
+        print(f"[bench] --gpus {n_gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:                        # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs between the ranks on this host
+    print("[bench] launching", " ".join(cmd), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -542,11 +566,19 @@ def main():
                     help="non-best-case variant: 6 / 8 / 11 triplets per image in rotation (one graph capture per bucket)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Plain `python bench.py --gpus N`: launch the N ranks ourselves (the reference launches with
+        # torch.distributed.launch --nproc_per_node, scripts/RLIP_ParSeDA/train_RLIP_ParSeDA_v2_mixed_vgcoco_resnet.sh:1-2).
+        # The launcher is a CHILD process started before this process touches the GPU (no HIP call, no
+        # torch.cuda.is_available() above this line): a process that has initialised the GPU must never exec or be
+        # replaced.  Rank 0's JSON line passes through on stdout; the exit code is the launcher's.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}, or without RANK in the environment to let bench.py launch its ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # Development aid for boxes with ONE GPU: RLIPV2_SINGLE_DEVICE=1 puts every rank on cuda:0 and

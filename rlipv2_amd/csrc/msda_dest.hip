@@ -132,9 +132,10 @@ __device__ __forceinline__ void source_tile(const DestPlan &pl, const int64_t *_
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bin_kernel(DestPlan pl, const int64_t *__restrict__ starts,
                                                   const float *__restrict__ loc, int M, int Lq,
-                                                  uint32_t *__restrict__ masks)
+                                                  uint32_t *__restrict__ masks, const int *__restrict__ gate)
 {
     extern __shared__ uint32_t bmask[];               // [Td][8]
+    if (gate && *gate == 0) return;                   // the patch pass of msda_patch.hip has taken the call
     const int tid = threadIdx.x;
     const int m = blockIdx.x % M;
     const int s = (blockIdx.x / M) % pl.Ts;
@@ -285,9 +286,10 @@ template <typename VT, typename OT, int TH, int WAVES>
 __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
     DestPlan pl, const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ aw,
     const VT *__restrict__ grad_out, const uint32_t *__restrict__ masks, int *__restrict__ counter,
-    OT *__restrict__ g_value, float *__restrict__ partials, int N, int S, int M, int Lq)
+    OT *__restrict__ g_value, float *__restrict__ partials, int N, int S, int M, int Lq, const int *__restrict__ gate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (gate && *gate == 0) return;                   // the patch pass of msda_patch.hip has taken the call
     typedef DestLds<VT, TH> LD;
     typedef Geo<TH> G;
     constexpr int kPix = G::kPix, kThreads = G::kThreads, kGroups = G::kGroups, kWaves = G::kWaves;
@@ -585,8 +587,10 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
 template <typename OT, int TH>
 __global__ __launch_bounds__(Geo<TH>::kThreads) void combine_kernel(DestPlan pl, const int64_t *__restrict__ starts,
                                                            const float *__restrict__ partials,
-                                                           OT *__restrict__ g_value, int N, int S, int M)
+                                                           OT *__restrict__ g_value, int N, int S, int M,
+                                                           const int *__restrict__ gate)
 {
+    if (gate && *gate == 0) return;
     const int NM = N * M;
     const int nm = blockIdx.x % NM, t = blockIdx.x / NM;
     int l = 0;
@@ -688,11 +692,14 @@ int dest_shapes_consistent(const Problem &p, const int64_t *shapes_host)
     return sum == p.S;
 }
 
+static size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
+
 size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host)
 {
     DestPlan pl;
     if (!dest_supports(p, shapes_host) || !make_plan(p, shapes_host, pl)) return 0;
-    return kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl);
+    // [control block | tile masks | partial tiles | patch masks of msda_patch.hip (encoder calls, bfloat16)]
+    return round16(kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl)) + patch_workspace_bytes(p, shapes_host);
 }
 
 // grad_value only (K1 = launch_quad_backward_reduce is issued by the caller).  out_bf16: grad_value is bfloat16.
@@ -709,8 +716,17 @@ void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *wor
     uint32_t *masks = reinterpret_cast<uint32_t *>(ws + kCtlBytes);
     float *partials = reinterpret_cast<float *>(ws + kCtlBytes + mask_bytes(p, pl));
     (void)hipMemsetAsync(counter, 0, kCtlBytes, p.stream);
+    // Encoder calls with bfloat16 gradients: the matrix-core patch pass (msda_patch.hip) produces grad_value; the
+    // kernels below then find the gate word zero and return at once.  Only when bin2_kernel met a sample outside its
+    // cell's reach (gate != 0: the patch pass has returned without writing) does the sorting pass run.
+    const int *gate = nullptr;
+    if (patch_workspace_bytes(p, shapes_host) > 0 && ablation_env("RLIPV2_MSDA_PATCH", 1)) {
+        int *ctl = counter;
+        launch_patch_dest(p, shapes_host, ctl, ws + round16(kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl)), out_bf16);
+        gate = ctl + 60;
+    }
     hipLaunchKernelGGL(bin_kernel, dim3(p.N * pl.Ts * p.M), dim3(256), pl.Td * 32, p.stream, pl, p.starts,
-                       (const float *)p.loc, p.M, p.Lq, masks);
+                       (const float *)p.loc, p.M, p.Lq, masks, gate);
     constexpr int TH = kDestTH, kThreads = Geo<TH>::kThreads;
     static const int per_cu = ablation_env("RLIPV2_DEST_WGS", 2);
     static const int waves = ablation_env("RLIPV2_DEST_WAVES", 4);
@@ -721,7 +737,7 @@ void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *wor
         auto kern = waves == 8 ? dest_kernel<VT, OT, TH, 8> : waves == 6 ? dest_kernel<VT, OT, TH, 6> : dest_kernel<VT, OT, TH, 4>; \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, p.stream, pl, p.starts, (const float *)p.loc, \
                            (const float *)p.aw, (const VT *)p.grad_out, masks, counter, (OT *)p.g_value, partials,  \
-                           p.N, p.S, p.M, p.Lq);                                                                     \
+                           p.N, p.S, p.M, p.Lq, gate);                                                               \
     } while (0)
     if (p.dtype == MSDA_F32) MSDA_LAUNCH_DEST(float, float);
     else if (out_bf16) MSDA_LAUNCH_DEST(bf16_t, bf16_t);
@@ -731,10 +747,10 @@ void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *wor
         const int cgrid = pl.ctiles * p.N * p.M;
         if (p.dtype == MSDA_BF16 && out_bf16)
             hipLaunchKernelGGL((combine_kernel<bf16_t, TH>), dim3(cgrid), dim3(kThreads), 0, p.stream, pl, p.starts, partials,
-                               (bf16_t *)p.g_value, p.N, p.S, p.M);
+                               (bf16_t *)p.g_value, p.N, p.S, p.M, gate);
         else
             hipLaunchKernelGGL((combine_kernel<float, TH>), dim3(cgrid), dim3(kThreads), 0, p.stream, pl, p.starts, partials,
-                               (float *)p.g_value, p.N, p.S, p.M);
+                               (float *)p.g_value, p.N, p.S, p.M, gate);
     }
 }
 

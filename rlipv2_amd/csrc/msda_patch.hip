@@ -1,0 +1,597 @@
+// msda_patch.hip -- grad_value of the encoder's MSDA backward pass (Lq == S, bfloat16 grad_out, D = 32, L = P = 4)
+// as a wave-autonomous, destination-stationary pass on the matrix cores of gfx950.
+// (Semantics: reference ms_deform_im2col_cuda.cuh:87-159, the `atomicAdd(grad_value + ptr, w * top_grad_value)`
+//  lines of ms_deform_attn_col2im_bilinear; the reference's result depends on atomic order, this one does not.)
+//
+// Why (round 3): the workgroup-cooperative pass of msda_dest.hip routes every bilinear corner record to the DPP quad
+// that owns its pixel through an LDS counting sort -- four barriers and ~10 dependent LDS round trips per pass of
+// 2 048 records, 35 % VALU utilisation, 385 us per batch-4 encoder call.  Here the routing IS the arithmetic:
+//
+//   grad_value[pix, ch] = sum over (query, level) groups g of  A[pix, g] * G[g, ch]
+//   A[pix, g] = sum over the group's 4 points of  attn * tent(x - pix_x) * tent(y - pix_y),   tent(d) = max(0, 1 - |d|)
+//
+// (the bilinear corner weights of .cuh:33-84 are exactly the tent products at the two neighbouring pixel centres).
+// A wave owns a PATCH of 4 x 4 pixels of one (image, head, level).  It walks the exact list of groups that touch
+// the patch (bit masks written by bin2_kernel), 32 groups per step: lane (g, half) loads the group's two points of
+// that half, evaluates the separable tents for the patch's 4 columns and 4 rows (48 multiplies for 16 pixels), splits
+// the 16 weights into bfloat16 hi + lo (relative error 2^-16 per weight, below the bfloat16 rounding of grad_out and of
+// the bfloat16 result by 2^7) and writes them as a row of the K x 16 matrix `A^T` in LDS next to the group's
+// grad_out row; ds_read_b64_tr_b16 turns both row-major images into MFMA operands and
+// v_mfma_f32_16x16x32_bf16 accumulates D^T[ch, pix] += G^T[ch, g] A^T[g, pix] -- eight MFMAs per 32 groups.
+// No sort, no atomics, no lists per pixel, no workgroup barrier inside the loop: waves are independent, five per
+// SIMD hide each other's latencies.  Every row of grad_value has exactly one writer and a fixed summation order:
+// bit-for-bit repeatable, no zero-fill.
+//
+// Candidate lists.  Queries are grouped into CELLS: the pyramid column over a 16 x 16 block of level-0 pixels, i.e.
+// the queries (iy, ix) of level lq with (iy >> (4 - lq), ix >> (4 - lq)) == (cy, cx) -- at most 256 + 64 + 16 + 4 = 340
+// queries, one bit each.  A patch looks at a fixed NEIGHBOURHOOD of cells around its own position (radius 1 / 2 / 3 /
+// 6 cells at level 0 / 1 / 2 / 3: every sample within >= 12 pixels of its query's own pyramid position); for every
+// (patch, neighbourhood slot) bin2_kernel stores the 340-bit mask of that cell's queries with a corner in the patch.
+// A sample that lands outside its cell's reach ("far": uniform random locations, degenerate pyramids) raises a flag
+// and the whole call falls back to the sorting pass of msda_dest.hip, which has no such assumption.
+#include <algorithm>
+
+#include "msda_device.h"
+#include "msda_internal.h"
+
+namespace msda {
+
+namespace {
+
+constexpr int kL = 4, kP = 4, kD = 32;
+constexpr int kCellQ = 340;                   // queries (bits) per cell: 256 + 64 + 16 + 4
+constexpr int kSlotWords = 12;                // 11 mask words + 1 of padding: 48 bytes per (patch, slot)
+constexpr int kStep = 32;                     // groups per MFMA step (K of v_mfma_f32_16x16x32_bf16)
+constexpr int kListCap = 384;                 // entries: < 32 carried over + one cell's <= 340
+constexpr int kWaves = 4;                     // waves per workgroup (each owns a patch, or a part of one)
+constexpr int kThreads = kWaves * 64;
+// per-wave LDS: candidate list | staged grad_out rows [32][32 ch] bf16 | A^T [half][hi/lo][32][16 px] bf16
+constexpr int kOffList = 0, kOffG = kListCap * 2, kOffA = kOffG + kStep * 64, kWaveLds = kOffA + 4 * kStep * 32;
+static_assert(kOffG % 16 == 0 && kOffA % 16 == 0 && kWaveLds % 16 == 0, "16-byte carve-up");
+constexpr int kFarWord = 60;                  // int index of the "far sample seen" flag in the control block
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct PatchPlan {                            // by-value kernel argument, built from the host copy of spatial_shapes
+    int H[kL], W[kL];
+    int CY, CX;                               // cells
+    int PY[kL], PX[kL];                       // patches per level
+    int rad[kL];                              // neighbourhood radius (cells)
+    int nby[kL], nbx[kL];                     // neighbourhood extent (cells), always inside the cell grid
+    int invx[kL];                             // ceil(65536 / nbx): slot / nbx == (slot * invx) >> 16 for slot < 128
+    int sbase[kL];                            // first mask slot of the level, per (image, head)
+    int slots;                                // mask slots per (image, head)
+    int parts[kL];                            // waves per patch (1, 2 or 4)
+    int ibase[kL], nitems[kL];                // workgroups of the level per (image, head); coarsest level first
+    int items;
+    int bin_lds;                              // bytes of bin2_kernel's LDS table (maximum over the cells)
+};
+
+// first cell row / column of the neighbourhood of patch row / column `pp` of level l
+__host__ __device__ inline int nb_origin(int l, int pp, int rad, int nb, int cells)
+{
+    const int home = (pp * 4) >> (4 - l);
+    const int o = home - rad;
+    return o < 0 ? 0 : (o > cells - nb ? cells - nb : o);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bin2_kernel: one workgroup per (image, cell, head) -- which of the cell's queries touch which patch
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kBinThreads = 1024;              // 128 (query, head) rows of 8 lanes per pass over a cell's 340 queries
+__global__ __launch_bounds__(kBinThreads) void bin2_kernel(PatchPlan pl, const int64_t *__restrict__ starts,
+                                                   const float *__restrict__ loc, const float *__restrict__ aw, int M,
+                                                   int Lq, uint32_t *__restrict__ masks, float *__restrict__ recs,
+                                                   int *__restrict__ ctl)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    __shared__ int rng[kL][4];                // per level: first / last patch row, first / last patch column in reach
+    const int tid = threadIdx.x;
+    const int cells = pl.CY * pl.CX;
+    const int m = blockIdx.x % M;
+    const int c = (blockIdx.x / M) % cells;
+    const int n = blockIdx.x / (M * cells);
+    const int cy = c / pl.CX, cx = c % pl.CX;
+    if (tid < 16) rng[tid >> 2][tid & 3] = (tid & 1) ? -1 : (1 << 30);
+    __syncthreads();
+    // the patches whose neighbourhood contains this cell: a contiguous range of rows and of columns per level
+#pragma unroll
+    for (int l = 0; l < kL; ++l) {
+        for (int t = tid; t < pl.PY[l]; t += kBinThreads) {
+            const int o = nb_origin(l, t, pl.rad[l], pl.nby[l], pl.CY);
+            if (o <= cy && cy < o + pl.nby[l]) { atomicMin(&rng[l][0], t); atomicMax(&rng[l][1], t); }
+        }
+        for (int t = tid; t < pl.PX[l]; t += kBinThreads) {
+            const int o = nb_origin(l, t, pl.rad[l], pl.nbx[l], pl.CX);
+            if (o <= cx && cx < o + pl.nbx[l]) { atomicMin(&rng[l][2], t); atomicMax(&rng[l][3], t); }
+        }
+    }
+    __syncthreads();
+    int base[kL], ylo[kL], xlo[kL], ph[kL], pw[kL], total = 0;
+#pragma unroll
+    for (int l = 0; l < kL; ++l) {
+        ylo[l] = rng[l][0]; xlo[l] = rng[l][2];
+        ph[l] = max(rng[l][1] - rng[l][0] + 1, 0); pw[l] = max(rng[l][3] - rng[l][2] + 1, 0);
+        if (ph[l] == 0 || pw[l] == 0) { ph[l] = 0; pw[l] = 0; }
+        base[l] = total;
+        total += ph[l] * pw[l] * kSlotWords;
+    }
+    for (int i = tid; i < total; i += kBinThreads) tab[i] = 0u;
+    __syncthreads();
+
+    // 8 lanes read the 128 bytes of one (query, head): lane chunk holds points (2 chunk & 3, +1) of level chunk / 2
+    const int chunk = tid & 7, l = chunk >> 1;
+    const int H = pl.H[l], W = pl.W[l];
+    const int tb = base[l], y_lo = ylo[l], x_lo = xlo[l], hh = ph[l], ww = pw[l];
+    bool far = false;
+    for (int j = tid >> 3; j < kCellQ; j += kBinThreads / 8) {
+        const int lq = j < 256 ? 0 : j < 320 ? 1 : j < 336 ? 2 : 3;
+        const int r = j - (lq == 0 ? 0 : lq == 1 ? 256 : lq == 2 ? 320 : 336);
+        const int sh = 4 - lq;
+        const int iy = (cy << sh) + (r >> sh), ix = (cx << sh) + (r & ((1 << sh) - 1));
+        if (iy >= pl.H[lq] || ix >= pl.W[lq]) continue;
+        const int q = (int)starts[lq] + iy * pl.W[lq] + ix;
+        const long qm = ((long)n * Lq + q) * M + m;
+        const float4 v = reinterpret_cast<const float4 *>(loc)[qm * 8 + chunk];
+        {   // the group's record for the patch pass: [x0 y0 x1 y1 | x2 y2 x3 y3 | a0 a1 a2 a3], cell-major
+            const float2 a = reinterpret_cast<const float2 *>(aw)[qm * 8 + chunk];
+            float *rec = recs + ((((size_t)(n * M + m) * kL + l) * cells + c) * kCellQ + j) * 12;
+            reinterpret_cast<float4 *>(rec)[chunk & 1] = v;
+            reinterpret_cast<float2 *>(rec + 8)[chunk & 1] = a;
+        }
+        const uint32_t bit = 1u << (j & 31);
+        const int word = j >> 5;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float x = k ? v.z : v.x, y = k ? v.w : v.y;
+            const float h_im = fmaf(y, (float)H, -0.5f), w_im = fmaf(x, (float)W, -0.5f);
+            const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);   // .cuh:285
+            if (!inside) continue;
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const int ya = max(h_low, 0) >> 2, yb = min(h_low + 1, H - 1) >> 2;
+            const int xa = max(w_low, 0) >> 2, xb = min(w_low + 1, W - 1) >> 2;
+            auto mark = [&](int py, int px) {
+                const int ry = py - y_lo, rx = px - x_lo;
+                if ((unsigned)ry < (unsigned)hh && (unsigned)rx < (unsigned)ww)
+                    atomicOr(&tab[tb + (ry * ww + rx) * kSlotWords + word], bit);
+                else
+                    far = true;
+            };
+            mark(ya, xa);
+            if (xb != xa) mark(ya, xb);
+            if (yb != ya) {
+                mark(yb, xa);
+                if (xb != xa) mark(yb, xb);
+            }
+        }
+    }
+    if (far) atomicOr(ctl + kFarWord, 1);
+    __syncthreads();
+    // masks[(n, m)][slot of (patch, this cell)][12 words]: every slot of the buffer has exactly one writer
+    const long nm = (long)n * M + m;
+#pragma unroll
+    for (int lv = 0; lv < kL; ++lv) {
+        const int rows = ph[lv] * pw[lv], nb2 = pl.nby[lv] * pl.nbx[lv];
+        for (int i = tid; i < rows * 3; i += kBinThreads) {
+            const int row = i / 3, piece = i - row * 3;
+            const int py = ylo[lv] + row / pw[lv], px = xlo[lv] + row % pw[lv];
+            const int oy = nb_origin(lv, py, pl.rad[lv], pl.nby[lv], pl.CY);
+            const int ox = nb_origin(lv, px, pl.rad[lv], pl.nbx[lv], pl.CX);
+            const int k = (cy - oy) * pl.nbx[lv] + (cx - ox);
+            const size_t slot = (size_t)nm * pl.slots + pl.sbase[lv] + (size_t)(py * pl.PX[lv] + px) * nb2 + k;
+            reinterpret_cast<uint4 *>(masks + slot * kSlotWords)[piece] =
+                reinterpret_cast<const uint4 *>(tab + base[lv] + row * kSlotWords)[piece];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// patch_dest_kernel
+// ------------------------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ int dpp_add(int v)
+{
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v)       // DPP row shifts / broadcasts, no LDS
+{
+    v = dpp_add<0x111, 0xf, 0xf>(v);
+    v = dpp_add<0x112, 0xf, 0xf>(v);
+    v = dpp_add<0x114, 0xf, 0xf>(v);
+    v = dpp_add<0x118, 0xf, 0xf>(v);
+    v = dpp_add<0x142, 0xa, 0xf>(v);
+    v = dpp_add<0x143, 0xc, 0xf>(v);
+    return v;
+}
+
+__device__ __forceinline__ s16x4 lds_tr_read(unsigned addr)
+{
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// two floats -> packed bfloat16 pair (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b)
+{
+    const f32x2 f = {a, b};
+    const bf16x2 h = __builtin_convertvector(f, bf16x2);
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// hi / lo bfloat16 split of two weights: hi = rne(e), lo = rne(e - hi)
+__device__ __forceinline__ void split_pair(float e0, float e1, uint32_t &hi, uint32_t &lo)
+{
+    hi = cvt_pk_bf16(e0, e1);
+    lo = cvt_pk_bf16(e0 - bf16_lo(hi), e1 - bf16_hi(hi));
+}
+
+template <typename OT> __device__ __forceinline__ void store4(OT *p, const f32x4 &v);
+template <> __device__ __forceinline__ void store4<float>(float *p, const f32x4 &v)
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, const f32x4 &v)
+{
+    *reinterpret_cast<uint2 *>(p) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+}
+
+template <typename OT, int WPS>
+__global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
+    PatchPlan pl, const int64_t *__restrict__ starts, const float *__restrict__ recs,
+    const bf16_t *__restrict__ grad_out, const uint32_t *__restrict__ masks, const int *__restrict__ ctl,
+    OT *__restrict__ g_value, int N, int S, int M, int Lq, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (ctl[kFarWord] != 0) return;                       // a far sample: the sorting pass of msda_dest.hip takes the call
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned char *wl = lds + wave * kWaveLds;
+    uint16_t *list = reinterpret_cast<uint16_t *>(wl + kOffList);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)wl;
+
+    // ---- item: (image, head) group by XCD (hardware block b runs on XCD b % 8), coarsest level first -----------------
+    const int NM = N * M;
+    int nm, it;
+    if ((NM & 7) == 0) {
+        const int per = NM >> 3, idx = blockIdx.x >> 3;
+        nm = (blockIdx.x & 7) * per + idx % per;
+        it = idx / per;
+    } else {
+        nm = blockIdx.x % NM;
+        it = blockIdx.x / NM;
+    }
+    int l = 0;
+#pragma unroll
+    for (int k = 0; k < kL; ++k) l = (it >= pl.ibase[k] && it < pl.ibase[k] + pl.nitems[k]) ? k : l;
+    const int parts = pl.parts[l];
+    const int pi = (it - pl.ibase[l]) * (kWaves / parts) + wave / parts, part = wave % parts;
+    const int PX = pl.PX[l], npatch = pl.PY[l] * PX;
+    const bool active = pi < npatch;
+    const int n = nm / M, m = nm % M;
+    const int H = pl.H[l], W = pl.W[l];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // channels 0-15 | 16-31 of pixel lane & 15
+    const int py = active ? pi / PX : 0, px = active ? pi % PX : 0;
+
+    if (active) {
+        const int nbx = pl.nbx[l], nb2 = pl.nby[l] * nbx, invx = pl.invx[l];
+        const int oy = nb_origin(l, py, pl.rad[l], pl.nby[l], pl.CY), ox = nb_origin(l, px, pl.rad[l], nbx, pl.CX);
+        const uint32_t *mrow = masks + ((size_t)nm * pl.slots + pl.sbase[l] + (size_t)pi * nb2) * kSlotWords;
+        const float *rbase = recs + ((size_t)nm * kL + l) * (size_t)(pl.CY * pl.CX) * kCellQ * 12;
+        const float Hf = (float)H, Wf = (float)W;
+        const float y0f = (float)(py * 4), x0f = (float)(px * 4);
+        const bool border = py * 4 + 3 >= H || px * 4 + 3 >= W;
+        // per-level (start, width) of the query levels, selected per lane below
+        const int st0 = (int)starts[0], st1 = (int)starts[1], st2 = (int)starts[2], st3 = (int)starts[3];
+        const int W0 = pl.W[0], W1 = pl.W[1], W2 = pl.W[2], W3 = pl.W[3];
+        const int kk = lane & 31, half = lane >> 5;
+        const int nq = n * Lq;
+        // transpose-read addresses: lane (p = lane & 15, kg = lane >> 4) supplies row 8 kg + 4 j + (p >> 2), piece p & 3
+        const int p16 = lane & 15, kg = lane >> 4;
+        const unsigned a_rd = lds0 + kOffA + (8 * kg + (p16 >> 2)) * 32 + (p16 & 3) * 8;     // + matrix * 1024 + j * 128
+        const unsigned g_rd = lds0 + kOffG + (8 * kg + (p16 >> 2)) * 64 + (p16 & 3) * 8;     // + tile * 32 + j * 256
+
+        // This wave's mask words: slots part, part + parts, ... of the patch's neighbourhood, 12 words each, taken 64 at
+        // a time (lane i holds word wbase + i; the next 64 are already travelling).  Word order = (slot, word) order, so
+        // a wave-wide prefix sum of the popcounts puts the candidates in a fixed order.
+        const int nslots = (nb2 - part + parts - 1) / parts, nwords = nslots * kSlotWords;
+        auto word_of = [&](int w) -> uint32_t {              // (captures scalars only; inlined)
+            if (w >= nwords) return 0u;
+            const int s = (w * 683) >> 13, wi = w - s * kSlotWords;      // w / 12 for w < 2048
+            return mrow[(part + s * parts) * kSlotWords + wi];
+        };
+        int wbase = 0;
+        uint32_t cur = word_of(lane), nxt = word_of(64 + lane);
+        int head = 0, tail = 0;
+        bool exhausted = nwords <= 0;
+        int avail_c = 0;                                   // the step whose operands are in flight / in registers
+        float4 xy_c = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 a2_c = make_float2(0.f, 0.f);
+        uint4 g0_c = make_uint4(0u, 0u, 0u, 0u), g1_c = g0_c;
+        for (;;) {
+            // ---- refill: expand mask bits into the candidate list until a full step is there ---------------------------
+            while (tail - head < kStep && !exhausted) {
+                if (__builtin_amdgcn_ballot_w64(cur != 0u) == 0ull) {
+                    wbase += 64;
+                    if (wbase >= nwords) { exhausted = true; break; }
+                    cur = nxt;
+                    nxt = word_of(wbase + 64 + lane);
+                    continue;
+                }
+                if (head > 0) {                           // carry the < 32 left-over entries to the front
+                    const int left = tail - head;
+                    int v = 0;
+                    if (lane < left) v = list[head + lane];
+                    if (lane < left) list[lane] = (uint16_t)v;
+                    head = 0; tail = left;
+                }
+                const int cnt = __popc(cur);
+                const int incl = wave_inclusive_scan(cnt);
+                const bool fits = incl <= kListCap - tail;             // a prefix of the lanes
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(fits);
+                const int nfit = __popcll(fm);                          // >= 1: 32 bits of one lane always fit
+                const int total = __builtin_amdgcn_readlane(incl, nfit - 1);
+                if (fits) {
+                    const int w = wbase + lane;
+                    const int s = (w * 683) >> 13, wi = w - s * kSlotWords;
+                    const int code0 = ((part + s * parts) << 9) | (wi * 32);
+                    int pos = tail + incl - cnt;
+                    uint32_t f = cur;
+                    while (f) {
+                        const int b = __ffs(f) - 1;
+                        list[pos++] = (uint16_t)(code0 | b);
+                        f &= f - 1u;
+                    }
+                    cur = 0u;
+                }
+                tail += total;
+            }
+            // ---- operands of the NEXT step start travelling (software pipeline: one step of loads in flight) ------------
+            const int avail_n = min(tail - head, kStep);
+            float4 xy_n = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 a2_n = make_float2(0.f, 0.f);
+            uint4 g0_n = make_uint4(0u, 0u, 0u, 0u), g1_n = g0_n;
+            if (avail_n > 0) {
+                const int h0 = head;
+                head += avail_n;
+                const int code = list[h0 + (kk < avail_n ? kk : 0)];
+                const int slot = code >> 9, bit = code & 511;
+                const int sy = (slot * invx) >> 16, sx = slot - sy * nbx;
+                const int lq = bit < 256 ? 0 : bit < 320 ? 1 : bit < 336 ? 2 : 3;
+                const int r = bit - (lq == 0 ? 0 : lq == 1 ? 256 : lq == 2 ? 320 : 336);
+                const int sh = 4 - lq;
+                const int iy = ((oy + sy) << sh) + (r >> sh), ix = ((ox + sx) << sh) + (r & ((1 << sh) - 1));
+                const int stq = lq == 0 ? st0 : lq == 1 ? st1 : lq == 2 ? st2 : st3;
+                const int Wq = lq == 0 ? W0 : lq == 1 ? W1 : lq == 2 ? W2 : W3;
+                int qm = (nq + stq + iy * Wq + ix) * M + m;                            // < 2^25 (checked by the ABI)
+                int ri = ((oy + sy) * pl.CX + ox + sx) * kCellQ + bit;                 // record of (cell, query)
+                if (MSDA_DBG(dbg) & 2) { qm = (nq + (lane & 7)) * M + m; ri = lane & 7; }   // ablation: cache-resident operands
+                const float *rec = rbase + (size_t)ri * 12;
+                xy_n = reinterpret_cast<const float4 *>(rec)[half];
+                a2_n = reinterpret_cast<const float2 *>(rec + 8)[half];
+                const uint4 *gp = reinterpret_cast<const uint4 *>(grad_out + (size_t)qm * kD + half * 16);
+                g0_n = gp[0]; g1_n = gp[1];
+            }
+            // ---- one MFMA step over the `avail` <= 32 candidates whose operands were requested one iteration ago -------
+            const int avail = avail_c;
+            const float4 xy = xy_c;
+            const float2 a2 = a2_c;
+            const uint4 g0 = g0_c, g1 = g1_c;
+            avail_c = avail_n; xy_c = xy_n; a2_c = a2_n; g0_c = g0_n; g1_c = g1_n;
+            if (avail <= 0) {
+                if (avail_n <= 0) break;
+                continue;
+            }
+            if (MSDA_DBG(dbg) & 1) { acc0[0] += (float)avail; continue; }            // ablation: enumeration only
+            if (MSDA_DBG(dbg) & 4) { acc0[0] += xy.x + a2.x + __uint_as_float(g0.x ^ g1.y); continue; }   // ablation: loads only
+            const bool valid = kk < avail;
+            float e[16];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const float x = pt ? xy.z : xy.x, y = pt ? xy.w : xy.y, a_in = pt ? a2.y : a2.x;
+                const float h_im = fmaf(y, Hf, -0.5f), w_im = fmaf(x, Wf, -0.5f);
+                const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);            // .cuh:285
+                const bool use = inside && valid;
+                const float a = use ? a_in : 0.f;
+                const float dx = use ? w_im - x0f : -8.f, dy = use ? h_im - y0f : -8.f;
+                float tx[4], ty[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    tx[c] = fmaxf(0.f, 1.f - fabsf(dx - (float)c));
+                    ty[c] = a * fmaxf(0.f, 1.f - fabsf(dy - (float)c));
+                }
+                if (border) {                              // pixels of the patch beyond the level's edge receive nothing
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        tx[c] = px * 4 + c < W ? tx[c] : 0.f;
+                        ty[c] = py * 4 + c < H ? ty[c] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int ry = 0; ry < 4; ++ry)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        e[ry * 4 + c] = pt ? fmaf(ty[ry], tx[c], e[ry * 4 + c]) : ty[ry] * tx[c];
+            }
+            uint32_t hi[8], lo[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_pair(e[2 * i], e[2 * i + 1], hi[i], lo[i]);
+            // A^T matrices: [half][hi | lo][32 groups][16 pixels] bfloat16, row kk of the lane's half
+            uint4 *arow = reinterpret_cast<uint4 *>(wl + kOffA + half * 2048 + kk * 32);
+            arow[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            arow[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+            arow[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);            // + 1024 bytes
+            arow[65] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+            uint4 *grow = reinterpret_cast<uint4 *>(wl + kOffG + kk * 64 + half * 32);
+            grow[0] = g0;
+            grow[1] = g1;
+            // operands: G^T tiles (channels 0-15 | 16-31) and the four A^T matrices, 8 consecutive groups per lane
+            union Frag { bf16x8 v; s16x4 h[2]; };
+            Frag gt0, gt1, at0, at1, at2, at3;
+            gt0.h[0] = lds_tr_read(g_rd); gt0.h[1] = lds_tr_read(g_rd + 256);
+            gt1.h[0] = lds_tr_read(g_rd + 32); gt1.h[1] = lds_tr_read(g_rd + 32 + 256);
+            at0.h[0] = lds_tr_read(a_rd); at0.h[1] = lds_tr_read(a_rd + 128);
+            at1.h[0] = lds_tr_read(a_rd + 1024); at1.h[1] = lds_tr_read(a_rd + 1024 + 128);
+            at2.h[0] = lds_tr_read(a_rd + 2048); at2.h[1] = lds_tr_read(a_rd + 2048 + 128);
+            at3.h[0] = lds_tr_read(a_rd + 3072); at3.h[1] = lds_tr_read(a_rd + 3072 + 128);
+            // (the wait names the fragments so that the scheduler cannot lift an MFMA above it: the compiler does not
+            //  know that the transpose-reads' results are still in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(gt0.h[0]), "+v"(gt0.h[1]), "+v"(gt1.h[0]), "+v"(gt1.h[1]), "+v"(at0.h[0]), "+v"(at0.h[1]),
+                           "+v"(at1.h[0]), "+v"(at1.h[1]), "+v"(at2.h[0]), "+v"(at2.h[1]), "+v"(at3.h[0]), "+v"(at3.h[1])
+                         :
+                         : "memory");
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at0.v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at0.v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at1.v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at1.v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at2.v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at2.v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at3.v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at3.v, acc1, 0, 0, 0);
+        }
+    }
+
+    // ---- parts of one patch: summed in part order by the first wave of the patch, then the rows leave once ----------
+    if (parts > 1) {
+        float *red = reinterpret_cast<float *>(wl);           // this wave's own (now idle) LDS
+        if (part > 0) {
+            reinterpret_cast<f32x4 *>(red)[lane * 2] = acc0;
+            reinterpret_cast<f32x4 *>(red)[lane * 2 + 1] = acc1;
+        }
+        __syncthreads();
+        if (part == 0) {
+            for (int j = 1; j < parts; ++j) {
+                const f32x4 *o = reinterpret_cast<const f32x4 *>(lds + (wave + j) * kWaveLds);
+                acc0 += o[lane * 2];
+                acc1 += o[lane * 2 + 1];
+            }
+        }
+    }
+    if (active && part == 0) {
+        const int pix = lane & 15, y = py * 4 + (pix >> 2), x = px * 4 + (pix & 3);
+        if (y < H && x < W) {
+            const long row = (long)n * S + (long)starts[l] + (long)y * W + x;
+            OT *dst = g_value + (row * M + m) * kD + 4 * (lane >> 4);
+            store4<OT>(dst, acc0);
+            store4<OT>(dst + 16, acc1);
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+bool make_patch_plan(const Problem &p, const int64_t *hs, PatchPlan &pl)
+{
+    if (!hs || p.L != kL || p.P != kP || p.D != kD || p.dtype != MSDA_BF16 || p.Lq != p.S) return false;
+    long sum = 0;
+    pl.CY = 1; pl.CX = 1;
+    for (int l = 0; l < kL; ++l) {
+        const int64_t H = hs[2 * l], W = hs[2 * l + 1];
+        if (H < 1 || W < 1 || H > 4096 || W > 4096) return false;
+        pl.H[l] = (int)H; pl.W[l] = (int)W;
+        const int cs = 16 >> l;
+        pl.CY = std::max(pl.CY, (int)((H + cs - 1) / cs));
+        pl.CX = std::max(pl.CX, (int)((W + cs - 1) / cs));
+        pl.PY[l] = (int)((H + 3) / 4); pl.PX[l] = (int)((W + 3) / 4);
+        sum += H * W;
+    }
+    if (sum != p.S) return false;
+    static const int kRad[kL] = {1, 2, 3, 6};
+    long slots = 0;
+    int items = 0;
+    for (int l = 0; l < kL; ++l) {
+        pl.rad[l] = kRad[l];
+        const int nb = 2 * kRad[l] + 1 + (l == 3 ? 1 : 0);
+        pl.nby[l] = std::min(nb, pl.CY); pl.nbx[l] = std::min(nb, pl.CX);
+        if (pl.nby[l] * pl.nbx[l] > 128) return false;            // 7-bit slot in the 16-bit candidate code
+        pl.invx[l] = (65536 + pl.nbx[l] - 1) / pl.nbx[l];
+        pl.sbase[l] = (int)slots;
+        slots += (long)pl.PY[l] * pl.PX[l] * pl.nby[l] * pl.nbx[l];
+        if (slots >= (1L << 30)) return false;
+    }
+    pl.slots = (int)slots;
+    for (int l = kL - 1; l >= 0; --l) {
+        // expected MFMA steps per patch: a (query, level) group touches ~3.5 patches
+        const double steps = (double)p.Lq * 3.5 / ((double)pl.PY[l] * pl.PX[l]) / kStep;
+        pl.parts[l] = steps > 16.0 ? 4 : steps > 6.0 ? 2 : 1;
+        pl.ibase[l] = items;
+        const int per = kWaves / pl.parts[l];
+        pl.nitems[l] = (pl.PY[l] * pl.PX[l] + per - 1) / per;
+        items += pl.nitems[l];
+    }
+    pl.items = items;
+    if ((long)items * p.N * p.M >= (1L << 30)) return false;
+    // LDS of bin2_kernel: the largest table over all cells
+    int worst = 0;
+    for (int cy = 0; cy < pl.CY; ++cy)
+        for (int cx = 0; cx < pl.CX; ++cx) {
+            int words = 0;
+            for (int l = 0; l < kL; ++l) {
+                int ny = 0, nx = 0;
+                for (int t = 0; t < pl.PY[l]; ++t) {
+                    const int o = nb_origin(l, t, pl.rad[l], pl.nby[l], pl.CY);
+                    ny += (o <= cy && cy < o + pl.nby[l]);
+                }
+                for (int t = 0; t < pl.PX[l]; ++t) {
+                    const int o = nb_origin(l, t, pl.rad[l], pl.nbx[l], pl.CX);
+                    nx += (o <= cx && cx < o + pl.nbx[l]);
+                }
+                words += ny * nx * kSlotWords;
+            }
+            worst = std::max(worst, words);
+        }
+    pl.bin_lds = worst * 4;
+    if (pl.bin_lds > 60 * 1024) return false;
+    return true;
+}
+
+}  // namespace
+
+static size_t mask_bytes(const Problem &p, const PatchPlan &pl) { return (size_t)p.N * p.M * pl.slots * kSlotWords * 4; }
+static size_t rec_bytes(const Problem &p, const PatchPlan &pl)
+{
+    return (size_t)p.N * p.M * kL * pl.CY * pl.CX * kCellQ * 48;
+}
+
+bool patch_supports(const Problem &p, const int64_t *shapes_host)
+{
+    PatchPlan pl;
+    if (!make_patch_plan(p, shapes_host, pl)) return false;
+    return mask_bytes(p, pl) + rec_bytes(p, pl) <= ((size_t)1 << 31);
+}
+
+size_t patch_workspace_bytes(const Problem &p, const int64_t *shapes_host)
+{
+    PatchPlan pl;
+    if (!patch_supports(p, shapes_host) || !make_patch_plan(p, shapes_host, pl)) return 0;
+    return mask_bytes(p, pl) + rec_bytes(p, pl);
+}
+
+// ctl: the control block of launch_dest_scatter (zeroed by the caller on the stream), masks: patch_workspace_bytes
+void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16)
+{
+    PatchPlan pl;
+    make_patch_plan(p, shapes_host, pl);
+    uint32_t *masks = reinterpret_cast<uint32_t *>(mask_ws);
+    float *recs = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(mask_ws) + mask_bytes(p, pl));
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)bin2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(bin2_kernel, dim3(p.N * pl.CY * pl.CX * p.M), dim3(kBinThreads), pl.bin_lds, p.stream, pl, p.starts,
+                       (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);
+    const int grid = pl.items * p.N * p.M;
+    static const int wps = ablation_env("RLIPV2_PATCH_WPS", 4);
+#define MSDA_PATCH(OT, WPS)                                                                                          \
+    hipLaunchKernelGGL((patch_dest_kernel<OT, WPS>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, pl,   \
+                       p.starts, (const float *)recs, (const bf16_t *)p.grad_out, masks,                            \
+                       (const int *)ctl, (OT *)p.g_value, p.N, p.S, p.M, p.Lq, ablation_env("RLIPV2_PATCH_DBG", 0))
+    if (out_bf16) { if (wps == 5) MSDA_PATCH(bf16_t, 5); else MSDA_PATCH(bf16_t, 4); }
+    else { if (wps == 5) MSDA_PATCH(float, 5); else MSDA_PATCH(float, 4); }
+#undef MSDA_PATCH
+}
+
+}  // namespace msda

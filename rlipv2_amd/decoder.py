@@ -207,13 +207,17 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
                            src_padding_mask)
 
             # (the refined boxes are detached, reference :1525 / :1541: heads and chain run without autograd)
+            # (the heads see a DETACHED tensor: a module called under no_grad on an input that requires grad trips
+            #  torch's ModuleTracker -- FlopCounterMode, i.e. bench.py's step-roofline probe -- with "Expected gradient
+            #  function to be set"; that is what removed `step_roofline` from round 2's bench line)
+            out_d = output.detach()
             if self.sub_bbox_embed is not None:
                 with torch.no_grad():
-                    delta = self.sub_bbox_embed[lid](output[:, :n_pair] if self.ParSe else output)
+                    delta = self.sub_bbox_embed[lid](out_d[:, :n_pair] if self.ParSe else out_d)
                 sub_ref = refine_boxes(delta, sub_ref)
             if self.obj_bbox_embed is not None:
                 with torch.no_grad():
-                    delta = self.obj_bbox_embed[lid](output[:, n_pair:] if self.ParSe else output)
+                    delta = self.obj_bbox_embed[lid](out_d[:, n_pair:] if self.ParSe else out_d)
                 obj_ref = refine_boxes(delta, obj_ref)
             if self.return_intermediate:
                 inter.append(output)

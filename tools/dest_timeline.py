@@ -1,5 +1,5 @@
 """Cycle totals per phase of workgroup 0 of dest_kernel (instrumented library: make -C rlipv2_amd/csrc timeline).
-usage: RLIPV2_LIB_PATH=rlipv2_amd/librlipv2_msda_tl.so python tools/dest_timeline.py [bf16|f32] [model|uniform]"""
+usage: RLIPV2_LIB_PATH=tools/_build/librlipv2_msda_tl.so python tools/dest_timeline.py [bf16|f32] [model|uniform]"""
 import ctypes
 import os
 import sys

@@ -2,7 +2,7 @@
 # A/B of dest_kernel's item queues (one global queue vs one per XCD), ablation build: kernel durations + HBM fetch
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/destxcd; mkdir -p $O
-export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/rlipv2_amd/librlipv2_msda_ablation.so
+export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so
 for x in 0 1 0 1; do
     export RLIPV2_DEST_XCD=$x
     ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/t_$x -o p -- python3 $GRAFT_REPO_ROOT/tools/bwd_once.py dest bf16 model 20 > $O/log.txt 2>&1 )

@@ -2,7 +2,7 @@
 # per-kernel durations of the weight-gradient ablation arms (rocprofv3 --kernel-trace --stats, ablation build)
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/wgprof; mkdir -p $O
-export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/rlipv2_amd/librlipv2_msda_ablation.so
+export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so
 for arm in "0 512 0" "0 512 1" "0 512 3" "0 512 5" "0 512 8"; do
     set -- $arm
     export RLIPV2_WGRAD_WIDE=$1 RLIPV2_WGRAD_BLOCKS=$2 RLIPV2_WGRAD_DBG=$3 WGRAD_SHAPES=2048x256

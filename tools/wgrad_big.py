@@ -6,7 +6,7 @@ import os, subprocess, sys
 if len(sys.argv) == 1:
     env = dict(os.environ)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env["RLIPV2_LIB_PATH"] = os.path.join(root, "rlipv2_amd", "librlipv2_msda_ablation.so")
+    env["RLIPV2_LIB_PATH"] = os.path.join(root, "tools", "_build", "librlipv2_msda_ablation.so")
     combos = [(0, 512, d) for d in (0, 1, 3, 5, 8)] if "split" in os.environ.get("WGRAD_BIG", "") \
         else [(0, b, d) for b in (256, 512, 768) for d in (0, 1, 8)]
     for wide, blocks, dbg in combos:

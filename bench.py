@@ -421,16 +421,17 @@ def run_train_step_bench(args, world, rank, local_rank, device):
 
 
 def pmc_traffic(kernel_key, args):
-    """HBM bytes per launch (fetch + write) of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r02_final_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of the same kernels with --kernel-trace only,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes; tools/gpu_final_r02.sh).  Only valid for the configuration it
-    was measured on (batch 4, bf16, 800x1333)."""
-    path = os.path.join(ROOT, "profiles", "r02_final_traffic.json")
+    """HBM bytes per launch (fetch + write) of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's
+    kernels (profiles/r03_final_traffic.json, written by tools/gpu_final_r03.sh: separate FETCH_SIZE / WRITE_SIZE runs with
+    --kernel-trace only, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  A recorded value, not measured by this
+    run: it is only reported when the file names the same kernels the call ran (a kernel revision that renames or
+    replaces them makes the key `null` instead of quoting stale bytes) and the configuration matches."""
+    path = os.path.join(ROOT, "profiles", "r03_final_traffic.json")
     if args.dtype != "bf16" or args.batch != 4 or not os.path.exists(path):
         return None
     t = json.load(open(path))
-    parts = {"enc_bwd_fused": ["msda:quad_backward_shared_kernel+geometry", "msda:bin_kernel", "msda:dest_kernel", "msda:combine_kernel"],
-             "enc_bwd": ["b0:quad_backward_shared_kernel", "b0:bin_kernel", "b0:dest_kernel", "b0:combine_kernel"],
+    parts = {"enc_bwd_fused": ["msda:cell_backward_kernel+geometry", "msda:patch_dest_kernel"],
+             "enc_bwd": ["b0:cell_backward_kernel", "b0:patch_dest_kernel"],
              "enc_fwd_fused": ["fwd:quad_forward_fused_kernel"]}.get(kernel_key)
     if not parts or any(k not in t for k in parts):
         return None
@@ -483,6 +484,8 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": pmc_traffic(dominant, args),
+            "traffic_source": "recorded: profiles/r03_final_traffic.json (rocprofv3 --pmc passes of the same kernels, "
+                              "tools/gpu_final_r03.sh); null when no profile of the kernels that ran is committed",
             "algorithmic_bytes_per_launch": kd["bytes"],
             "bytes_definition": "SURVEY.md 8d: value + sampling_loc + attn_weight + grad_out read, grad_value + "
                                 "grad_sampling_loc + grad_attn_weight written, each once (bf16 value / grad_out / grad_value, "

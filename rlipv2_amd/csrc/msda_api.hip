@@ -265,8 +265,8 @@ int msda_backward_ws(int variant, int dtype, const void *value, const int64_t *s
         (void)hipGetLastError();
         // (K1 forked onto a second stream beside the grad_value pass was measured: 678 vs 633 us -- K1's 44 k
         //  workgroups fill the chip first, nothing overlaps)
-        launch_quad_backward_reduce(p);                                     // grad_sampling_loc / grad_attn_weight
-        launch_dest_scatter(p, spatial_shapes_host, workspace, out_bf16);   // grad_value, every row written once
+        // grad_sampling_loc / grad_attn_weight (K1) + grad_value (every row written once)
+        launch_backward_dest(p, nullptr, spatial_shapes_host, workspace, out_bf16);
         return finish_launch();
     }
     if (v == MSDA_VARIANT_DEST || out_bf16) return MSDA_ERR_BAD_VARIANT;
@@ -332,8 +332,7 @@ int msda_fused_backward_ws(int flags, int dtype, const void *value, const int64_
     Fused f{};
     f.ref = ref; f.refdim = refdim; f.g_qproj = grad_qproj;
     (void)hipGetLastError();
-    launch_quad_backward_reduce_fused(p, f);                            // grad of the projection row
-    launch_dest_scatter(p, spatial_shapes_host, workspace, out_bf16);   // grad_value, every row written once
+    launch_backward_dest(p, &f, spatial_shapes_host, workspace, out_bf16);   // grad of the projection row + grad_value
     return finish_launch();
 }
 

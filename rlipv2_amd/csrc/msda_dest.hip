@@ -702,10 +702,12 @@ size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host)
     return round16(kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl)) + patch_workspace_bytes(p, shapes_host);
 }
 
-// grad_value only (K1 = launch_quad_backward_reduce is issued by the caller).  out_bf16: grad_value is bfloat16.
-void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *workspace, bool out_bf16)
+// K1 + grad_value.  out_bf16: grad_value is bfloat16.
+void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shapes_host, void *workspace, bool out_bf16)
 {
+    auto k1 = [&]() { if (f) launch_quad_backward_reduce_fused(p, *f); else launch_quad_backward_reduce(p); };
     if (sparse_dest_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_SPARSE", 1)) {
+        k1();
         launch_sparse_dest(p, shapes_host, out_bf16);      // few queries: per-(image, head, level) pass, see msda_sparse.hip
         return;
     }
@@ -716,14 +718,21 @@ void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *wor
     uint32_t *masks = reinterpret_cast<uint32_t *>(ws + kCtlBytes);
     float *partials = reinterpret_cast<float *>(ws + kCtlBytes + mask_bytes(p, pl));
     (void)hipMemsetAsync(counter, 0, kCtlBytes, p.stream);
-    // Encoder calls with bfloat16 gradients: the matrix-core patch pass (msda_patch.hip) produces grad_value; the
-    // kernels below then find the gate word zero and return at once.  Only when bin2_kernel met a sample outside its
-    // cell's reach (gate != 0: the patch pass has returned without writing) does the sorting pass run.
+    // Encoder calls with bfloat16 gradients (msda_patch.hip): cell_backward_kernel does K1's work from LDS-resident
+    // windows and bins the samples, the matrix-core patch pass produces grad_value; the kernels below then find the gate
+    // word zero and return at once.  Only when the binning met a sample outside its cell's reach (gate != 0: the patch
+    // pass has returned without writing) does the sorting pass run.
     const int *gate = nullptr;
     if (patch_workspace_bytes(p, shapes_host) > 0 && ablation_env("RLIPV2_MSDA_PATCH", 1)) {
         int *ctl = counter;
-        launch_patch_dest(p, shapes_host, ctl, ws + round16(kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl)), out_bf16);
+        void *pws = ws + round16(kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl));
+        const bool cell = cell_backward_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_CELL", 1);
+        if (cell) launch_cell_backward(p, f, shapes_host, ctl, pws);
+        else k1();
+        launch_patch_dest(p, shapes_host, ctl, pws, out_bf16, cell);
         gate = ctl + 60;
+    } else {
+        k1();
     }
     hipLaunchKernelGGL(bin_kernel, dim3(p.N * pl.Ts * p.M), dim3(256), pl.Td * 32, p.stream, pl, p.starts,
                        (const float *)p.loc, p.M, p.Lq, masks, gate);

@@ -75,13 +75,18 @@ void launch_window_backward(const Problem &p);
 bool dest_supports(const Problem &p, const int64_t *shapes_host);
 int dest_shapes_consistent(const Problem &p, const int64_t *shapes_host);
 size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host);
-void launch_dest_scatter(const Problem &p, const int64_t *shapes_host, void *workspace, bool out_bf16);
+// the whole backward pass of a call with host shapes: K1 (f != nullptr: with the fused geometry epilogue) + grad_value
+void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shapes_host, void *workspace, bool out_bf16);
 // encoder calls (Lq == S) with bfloat16 gradients: wave-autonomous 4x4-pixel patches on the matrix cores (msda_patch.hip).
 // `ctl` = the zeroed control block of launch_dest_scatter (word 60 = "a sample was out of reach, fall back"),
 // `mask_ws` = patch_workspace_bytes of scratch
 bool patch_supports(const Problem &p, const int64_t *shapes_host);
 size_t patch_workspace_bytes(const Problem &p, const int64_t *shapes_host);
-void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16);
+void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned);
+// ... preceded by cell_backward_kernel: K1's work (grad_sampling_loc / grad_attn_weight, or with `f` the projection row's
+// gradient) from LDS-resident value windows on v_mfma_f32_4x4x4_16B_bf16, plus the binning for the patch pass
+bool cell_backward_supports(const Problem &p, const int64_t *shapes_host);
+void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, int *ctl, void *mask_ws);
 // few queries (decoders): one workgroup per (image, head, level), records sorted by pixel in LDS (msda_sparse.hip)
 bool sparse_dest_supports(const Problem &p, const int64_t *shapes_host);
 void launch_sparse_dest(const Problem &p, const int64_t *shapes_host, bool out_bf16);

@@ -32,6 +32,7 @@
 #include <algorithm>
 
 #include "msda_device.h"
+#include "msda_geometry.h"
 #include "msda_internal.h"
 
 namespace msda {
@@ -82,66 +83,108 @@ __host__ __device__ inline int nb_origin(int l, int pp, int rad, int nb, int cel
 // ------------------------------------------------------------------------------------------------------------------
 // bin2_kernel: one workgroup per (image, cell, head) -- which of the cell's queries touch which patch
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kBinThreads = 1024;              // 128 (query, head) rows of 8 lanes per pass over a cell's 340 queries
-__global__ __launch_bounds__(kBinThreads) void bin2_kernel(PatchPlan pl, const int64_t *__restrict__ starts,
-                                                   const float *__restrict__ loc, const float *__restrict__ aw, int M,
-                                                   int Lq, uint32_t *__restrict__ masks, float *__restrict__ recs,
-                                                   int *__restrict__ ctl)
+#ifdef MSDA_ABLATION
+__device__ unsigned long long cell_ts[16];      // cycle sums over all workgroups (thread 0): phases of cell_backward_kernel
+#define CTS(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = clock64(); atomicAdd(&cell_ts[k], t_ - ts_last); ts_last = t_; } } while (0)
+#else
+#define CTS(k) do { } while (0)
+#endif
+// The binning of one cell's queries, shared by bin2_kernel and cell_backward_kernel.  `tab` = the workgroup's LDS table
+// (PatchPlan::bin_lds bytes), `rng` = [4][4] LDS ints.  Ends with a barrier; table_layout() then gives every thread the
+// table's carve-up and write_masks() sends it to the workspace.
+struct TableLayout { int base[kL], ylo[kL], xlo[kL], ph[kL], pw[kL], total; };
+
+__device__ __forceinline__ TableLayout table_layout(const int (*rng)[4])
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
-    __shared__ int rng[kL][4];                // per level: first / last patch row, first / last patch column in reach
+    TableLayout t;
+    t.total = 0;
+#pragma unroll
+    for (int l = 0; l < kL; ++l) {
+        const int r0 = __builtin_amdgcn_readfirstlane(rng[l][0]), r1 = __builtin_amdgcn_readfirstlane(rng[l][1]);
+        const int r2 = __builtin_amdgcn_readfirstlane(rng[l][2]), r3 = __builtin_amdgcn_readfirstlane(rng[l][3]);
+        t.ylo[l] = r0; t.xlo[l] = r2;
+        t.ph[l] = max(r1 - r0 + 1, 0); t.pw[l] = max(r3 - r2 + 1, 0);
+        if (t.ph[l] == 0 || t.pw[l] == 0) { t.ph[l] = 0; t.pw[l] = 0; }
+        t.base[l] = t.total;
+        t.total += t.ph[l] * t.pw[l] * kSlotWords;
+    }
+    return t;
+}
+
+// BBOX: also the bounding box of every in-level corner per sampled level: box[l] = {x0, y0, -x1, -y1} (LDS, via min)
+template <int THREADS, bool BBOX>
+__device__ __forceinline__ void bin_cell(const PatchPlan &pl, const int64_t *__restrict__ starts,
+                                         const float *__restrict__ loc, const float *__restrict__ aw, int n, int m, int c,
+                                         int M, int Lq, uint32_t *tab, int (*rng)[4], int (*box)[4],
+                                         float *__restrict__ recs, int *__restrict__ ctl, int dbg = 0)
+{
     const int tid = threadIdx.x;
     const int cells = pl.CY * pl.CX;
-    const int m = blockIdx.x % M;
-    const int c = (blockIdx.x / M) % cells;
-    const int n = blockIdx.x / (M * cells);
     const int cy = c / pl.CX, cx = c % pl.CX;
+    unsigned long long ts_last = clock64();
+    (void)ts_last;
     if (tid < 16) rng[tid >> 2][tid & 3] = (tid & 1) ? -1 : (1 << 30);
+    if (BBOX && tid >= 32 && tid < 48) box[(tid - 32) >> 2][tid & 3] = 0x3fffffff;
     __syncthreads();
     // the patches whose neighbourhood contains this cell: a contiguous range of rows and of columns per level
 #pragma unroll
     for (int l = 0; l < kL; ++l) {
-        for (int t = tid; t < pl.PY[l]; t += kBinThreads) {
+        for (int t = tid; t < pl.PY[l]; t += THREADS) {
             const int o = nb_origin(l, t, pl.rad[l], pl.nby[l], pl.CY);
             if (o <= cy && cy < o + pl.nby[l]) { atomicMin(&rng[l][0], t); atomicMax(&rng[l][1], t); }
         }
-        for (int t = tid; t < pl.PX[l]; t += kBinThreads) {
+        for (int t = tid; t < pl.PX[l]; t += THREADS) {
             const int o = nb_origin(l, t, pl.rad[l], pl.nbx[l], pl.CX);
             if (o <= cx && cx < o + pl.nbx[l]) { atomicMin(&rng[l][2], t); atomicMax(&rng[l][3], t); }
         }
     }
     __syncthreads();
-    int base[kL], ylo[kL], xlo[kL], ph[kL], pw[kL], total = 0;
-#pragma unroll
-    for (int l = 0; l < kL; ++l) {
-        ylo[l] = rng[l][0]; xlo[l] = rng[l][2];
-        ph[l] = max(rng[l][1] - rng[l][0] + 1, 0); pw[l] = max(rng[l][3] - rng[l][2] + 1, 0);
-        if (ph[l] == 0 || pw[l] == 0) { ph[l] = 0; pw[l] = 0; }
-        base[l] = total;
-        total += ph[l] * pw[l] * kSlotWords;
-    }
-    for (int i = tid; i < total; i += kBinThreads) tab[i] = 0u;
+    if (BBOX) CTS(8);
+    const TableLayout tl = table_layout(rng);
+    for (int i = tid; i < tl.total; i += THREADS) tab[i] = 0u;
     __syncthreads();
+    if (BBOX) CTS(9);
 
     // 8 lanes read the 128 bytes of one (query, head): lane chunk holds points (2 chunk & 3, +1) of level chunk / 2
     const int chunk = tid & 7, l = chunk >> 1;
-    const int H = pl.H[l], W = pl.W[l];
-    const int tb = base[l], y_lo = ylo[l], x_lo = xlo[l], hh = ph[l], ww = pw[l];
+    auto sel = [l](const int (&v)[kL]) { return l == 0 ? v[0] : l == 1 ? v[1] : l == 2 ? v[2] : v[3]; };   // (no scratch)
+    const int H = sel(pl.H), W = sel(pl.W);
+    const int tb = sel(tl.base), y_lo = sel(tl.ylo), x_lo = sel(tl.xlo), hh = sel(tl.ph), ww = sel(tl.pw);
     bool far = false;
-    for (int j = tid >> 3; j < kCellQ; j += kBinThreads / 8) {
+    int bx0 = 0x3fffffff, by0 = 0x3fffffff, bx1 = -0x3fffffff, by1 = -0x3fffffff;
+    // All of the thread's loads first (every pass of a plain loop waited 3-4 us for its 24 bytes: cycle stamps in
+    // tools/cell_timeline.py), then the arithmetic and the LDS ORs.
+    constexpr int IT = (kCellQ * 8 + THREADS - 1) / THREADS;
+    float4 vv[IT];
+    float2 av[IT];
+    bool have[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int j = (tid >> 3) + it * (THREADS / 8);
         const int lq = j < 256 ? 0 : j < 320 ? 1 : j < 336 ? 2 : 3;
         const int r = j - (lq == 0 ? 0 : lq == 1 ? 256 : lq == 2 ? 320 : 336);
         const int sh = 4 - lq;
         const int iy = (cy << sh) + (r >> sh), ix = (cx << sh) + (r & ((1 << sh) - 1));
-        if (iy >= pl.H[lq] || ix >= pl.W[lq]) continue;
-        const int q = (int)starts[lq] + iy * pl.W[lq] + ix;
+        const int Hq = lq == 0 ? pl.H[0] : lq == 1 ? pl.H[1] : lq == 2 ? pl.H[2] : pl.H[3];
+        const int Wq = lq == 0 ? pl.W[0] : lq == 1 ? pl.W[1] : lq == 2 ? pl.W[2] : pl.W[3];
+        have[it] = j < kCellQ && iy < Hq && ix < Wq;
+        const int q = have[it] ? (int)starts[lq] + iy * Wq + ix : 0;
         const long qm = ((long)n * Lq + q) * M + m;
-        const float4 v = reinterpret_cast<const float4 *>(loc)[qm * 8 + chunk];
-        {   // the group's record for the patch pass: [x0 y0 x1 y1 | x2 y2 x3 y3 | a0 a1 a2 a3], cell-major
-            const float2 a = reinterpret_cast<const float2 *>(aw)[qm * 8 + chunk];
+        vv[it] = reinterpret_cast<const float4 *>(loc)[qm * 8 + chunk];
+        av[it] = reinterpret_cast<const float2 *>(aw)[qm * 8 + chunk];
+    }
+#ifdef MSDA_ABLATION
+    if (BBOX && (MSDA_DBG(dbg) & 16)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CTS(10); }
+#endif
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        if (!have[it]) continue;
+        const int j = (tid >> 3) + it * (THREADS / 8);
+        const float4 v = vv[it];
+        if (!(MSDA_DBG(dbg) & 32)) {   // the group's record for the patch pass: [x0 y0 x1 y1 | x2 y2 x3 y3 | a0 a1 a2 a3], cell-major
             float *rec = recs + ((((size_t)(n * M + m) * kL + l) * cells + c) * kCellQ + j) * 12;
             reinterpret_cast<float4 *>(rec)[chunk & 1] = v;
-            reinterpret_cast<float2 *>(rec + 8)[chunk & 1] = a;
+            reinterpret_cast<float2 *>(rec + 8)[chunk & 1] = av[it];
         }
         const uint32_t bit = 1u << (j & 31);
         const int word = j >> 5;
@@ -152,8 +195,9 @@ __global__ __launch_bounds__(kBinThreads) void bin2_kernel(PatchPlan pl, const i
             const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);   // .cuh:285
             if (!inside) continue;
             const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-            const int ya = max(h_low, 0) >> 2, yb = min(h_low + 1, H - 1) >> 2;
-            const int xa = max(w_low, 0) >> 2, xb = min(w_low + 1, W - 1) >> 2;
+            const int y0 = max(h_low, 0), y1 = min(h_low + 1, H - 1), x0 = max(w_low, 0), x1 = min(w_low + 1, W - 1);
+            if (BBOX) { bx0 = min(bx0, x0); by0 = min(by0, y0); bx1 = max(bx1, x1); by1 = max(by1, y1); }
+            const int ya = y0 >> 2, yb = y1 >> 2, xa = x0 >> 2, xb = x1 >> 2;
             auto mark = [&](int py, int px) {
                 const int ry = py - y_lo, rx = px - x_lo;
                 if ((unsigned)ry < (unsigned)hh && (unsigned)rx < (unsigned)ww)
@@ -169,24 +213,55 @@ __global__ __launch_bounds__(kBinThreads) void bin2_kernel(PatchPlan pl, const i
             }
         }
     }
+    if (BBOX && bx0 <= bx1) {
+        int *b = &box[0][0] + l * 4;
+        atomicMin(b + 0, bx0); atomicMin(b + 1, by0); atomicMin(b + 2, -bx1); atomicMin(b + 3, -by1);
+    }
     if (far) atomicOr(ctl + kFarWord, 1);
+    if (BBOX) CTS(11);
     __syncthreads();
-    // masks[(n, m)][slot of (patch, this cell)][12 words]: every slot of the buffer has exactly one writer
+    if (BBOX) CTS(12);
+}
+
+// masks[(n, m)][slot of (patch, this cell)][12 words]: every slot of the buffer has exactly one writer
+template <int THREADS>
+__device__ __forceinline__ void write_masks(const PatchPlan &pl, const TableLayout &tl, const uint32_t *tab, int n, int m,
+                                            int c, int M, uint32_t *__restrict__ masks)
+{
+    const int tid = threadIdx.x;
+    const int cy = c / pl.CX, cx = c % pl.CX;
     const long nm = (long)n * M + m;
 #pragma unroll
     for (int lv = 0; lv < kL; ++lv) {
-        const int rows = ph[lv] * pw[lv], nb2 = pl.nby[lv] * pl.nbx[lv];
-        for (int i = tid; i < rows * 3; i += kBinThreads) {
+        const int rows = tl.ph[lv] * tl.pw[lv], nb2 = pl.nby[lv] * pl.nbx[lv];
+        for (int i = tid; i < rows * 3; i += THREADS) {
             const int row = i / 3, piece = i - row * 3;
-            const int py = ylo[lv] + row / pw[lv], px = xlo[lv] + row % pw[lv];
+            const int py = tl.ylo[lv] + row / tl.pw[lv], px = tl.xlo[lv] + row % tl.pw[lv];
             const int oy = nb_origin(lv, py, pl.rad[lv], pl.nby[lv], pl.CY);
             const int ox = nb_origin(lv, px, pl.rad[lv], pl.nbx[lv], pl.CX);
             const int k = (cy - oy) * pl.nbx[lv] + (cx - ox);
             const size_t slot = (size_t)nm * pl.slots + pl.sbase[lv] + (size_t)(py * pl.PX[lv] + px) * nb2 + k;
             reinterpret_cast<uint4 *>(masks + slot * kSlotWords)[piece] =
-                reinterpret_cast<const uint4 *>(tab + base[lv] + row * kSlotWords)[piece];
+                reinterpret_cast<const uint4 *>(tab + tl.base[lv] + row * kSlotWords)[piece];
         }
     }
+}
+
+constexpr int kBinThreads = 1024;              // 128 (query, head) rows of 8 lanes per pass over a cell's 340 queries
+__global__ __launch_bounds__(kBinThreads) void bin2_kernel(PatchPlan pl, const int64_t *__restrict__ starts,
+                                                           const float *__restrict__ loc, const float *__restrict__ aw,
+                                                           int M, int Lq, uint32_t *__restrict__ masks,
+                                                           float *__restrict__ recs, int *__restrict__ ctl)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    __shared__ int rng[kL][4];                // per level: first / last patch row, first / last patch column in reach
+    const int cells = pl.CY * pl.CX;
+    const int m = blockIdx.x % M;
+    const int c = (blockIdx.x / M) % cells;
+    const int n = blockIdx.x / (M * cells);
+    bin_cell<kBinThreads, false>(pl, starts, loc, aw, n, m, c, M, Lq, tab, rng, nullptr, recs, ctl);
+    const TableLayout tl = table_layout(rng);
+    write_masks<kBinThreads>(pl, tl, tab, n, m, c, M, masks);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -481,6 +556,287 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// cell_backward_kernel: grad_sampling_loc / grad_attn_weight (or, fused, the gradient of the projection row) of one
+// cell's queries with the value windows in LDS and the channel dot products on v_mfma_f32_4x4x4_16B_bf16 -- plus the
+// binning of bin2_kernel, whose sample geometry it shares.  (Reference semantics: ms_deform_im2col_cuda.cuh:301-403,
+// ms_deform_attn_col2im_bilinear :87-159 for the two gradients.)
+//
+// Round 2's K1 (quad_backward_shared_kernel) gathers every corner row from global memory -- 2.9 GB of 64-byte
+// gathers per batch-4 encoder call at ~64 B/clk/CU of texture path -- and spends 16 VALU instructions per corner on
+// the 8-channel piece of a dot product (8 bf16 unpacks + 8 FMAs) plus a DPP reduction.  Here:
+//   * a workgroup owns one (image, head, cell): the <= 340 queries of a pyramid column sample a compact window of
+//     every level; phase 1 (bin_cell) finds the windows' bounding boxes while it builds the patch masks, phase 2 copies
+//     the windows into LDS once (48 KB budget; a level that does not fit is gathered directly, so any input works);
+//   * a DPP quad owns one query and lane c of the quad owns bilinear CORNER c of the current sample: it reads that
+//     corner's whole 64-byte row from LDS (4 x ds_read_b128, piece order rotated by the quad's index so that the 16
+//     lanes of an LDS group hit 16 different bank quads; window pitch = 2 mod 4 keeps a quad's four rows apart);
+//   * the 16 MFMA blocks of v_mfma_f32_4x4x4_16B_bf16 are exactly the 16 quads of a wave: block = quad, B column j =
+//     corner j's 4 channels, A rows = the query's grad_out channels -> D[., j] = <grad_out, corner j> after 8
+//     instructions per sample, exact products, float32 accumulation, no unpacking and no cross-lane reduction.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kCellThreads = 512;
+constexpr int kWinBytes = 48 * 1024;          // LDS window budget (all levels together)
+constexpr int kZeroBytes = 128;               // zeros in front of the windows: where out-of-level corners read
+constexpr int kMaxWinPx = kWinBytes / 64;
+constexpr int kCellTableMax = 28 * 1024;      // bin table bytes the cell kernel can hold next to the windows
+constexpr unsigned kOobOff = 0xFFFFFF00u;     // buffer offset beyond num_records: the hardware returns zeros
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma444(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, f32x4 c)
+{
+    union { uint32_t u[2]; s16x4 v; } a, b;
+    a.u[0] = a0; a.u[1] = a1; b.u[0] = b0; b.u[1] = b1;
+    return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a.v, b.v, c, 0, 0, 0);
+}
+
+// one sample: this lane's corner row (4 pieces, rotated) -> <grad_out, corner> of the quad's four corners -> the three
+// gradients of the sample (identical in all four lanes)
+__device__ __forceinline__ void cell_sample(const unsigned char *lds, __amdgpu_buffer_rsrc_t vr, const uint4 (&g)[4], float x,
+                                            float y, float w, int H, int W, int wx0, int wy0, int pitch, int wbase,
+                                            unsigned lvl_byte, int row_bytes, int crn, int rot, float &g_a, float &g_x,
+                                            float &g_y, int dbg = 0)
+{
+    const float Hf = (float)H, Wf = (float)W;
+    const float h_im = fmaf(y, Hf, -0.5f), w_im = fmaf(x, Wf, -0.5f);
+    const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);     // .cuh:285 (NaN -> false)
+    const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;
+    const float hf = floorf(hs), wf = floorf(ws);
+    const float lh = hs - hf, lw = ws - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const int iy = (int)hf + (crn >> 1), ix = (int)wf + (crn & 1);
+    const bool ok = inside && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    uint4 v[4];
+    if (MSDA_DBG(dbg) & 4) {                                                   // ablation: no corner reads at all
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = make_uint4(g[t].x + ok, g[t].y, g[t].z, g[t].w);
+    } else if (wbase >= 0) {                                                   // (wave-uniform)
+        const int addr = ok ? wbase + (__mul24(iy - wy0, pitch) + (ix - wx0)) * 64 : 0;     // 0: the zero slot
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(lds + addr + ((t ^ rot) << 4));
+    } else {
+        const unsigned off = ok ? lvl_byte + (unsigned)__mul24(__mul24(iy, W) + ix, row_bytes) : kOobOff;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(vr, off + ((t ^ rot) << 4), 0, 0);
+            v[t] = make_uint4(r.x, r.y, r.z, r.w);
+        }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#ifdef MSDA_CELL_NO_MFMA
+    acc[0] = __uint_as_float(v[0].x ^ v[1].y ^ v[2].z ^ v[3].w);                // ablation build: no MFMAs
+#else
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc = mfma444(g[t].x, g[t].y, v[t].x, v[t].y, acc);
+        acc = mfma444(g[t].z, g[t].w, v[t].z, v[t].w, acc);
+    }
+#endif
+    const float e = acc[0];
+    const float e1 = quad_bcast<0>(e), e2 = quad_bcast<1>(e), e3 = quad_bcast<2>(e), e4 = quad_bcast<3>(e);
+    const float wgt = inside ? w : 0.f;
+    g_a = inside ? hh * (hw * e1 + lw * e2) + lh * (hw * e3 + lw * e4) : 0.f;
+    g_x = Wf * wgt * (hh * (e2 - e1) + lh * (e4 - e3));
+    g_y = Hf * wgt * (hw * (e3 - e1) + lw * (e4 - e2));
+}
+
+// rotate the quad's per-lane data by one lane: lane j takes lane j + 1's registers, so that after l rotations quad lane 0
+// holds level l (the level loop stays a loop: unrolled over levels and read routes the kernel was 36 KB of code and every
+// phase ran 3-4x slower than its instruction count -- instruction-cache misses between workgroups in different phases)
+__device__ __forceinline__ void quad_rotate4(float4 &v)
+{
+    constexpr int R = MSDA_QUAD_PERM(1, 2, 3, 0);
+    v.x = dpp_quad<R>(v.x); v.y = dpp_quad<R>(v.y); v.z = dpp_quad<R>(v.z); v.w = dpp_quad<R>(v.w);
+}
+
+template <int REFDIM>
+__global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
+    PatchPlan pl, const bf16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const float *__restrict__ loc, const float *__restrict__ aw, const bf16_t *__restrict__ grad_out, int N, int S, int M,
+    int Lq, unsigned value_bytes, float *__restrict__ g_loc, float *__restrict__ g_aw, const float *__restrict__ ref,
+    bf16_t *__restrict__ g_qproj, uint32_t *__restrict__ masks, float *__restrict__ recs, int *__restrict__ ctl, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char clds[];       // [zeros | windows | bin table]
+    __shared__ int rng[kL][4];
+    __shared__ int box[kL][4];
+    __shared__ int winfo[kL][8];              // per level: H, W, window x0, y0, pitch, LDS base (< 0: gathered directly), start
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cells = pl.CY * pl.CX, NM = N * M;
+    // (image, head) pairs grouped by XCD (hardware block b runs on XCD b % 8): neighbouring cells share window rows
+    int nm, c;
+    if ((NM & 7) == 0) {
+        const int per = NM >> 3, idx = blockIdx.x >> 3;
+        nm = (blockIdx.x & 7) * per + idx % per;
+        c = idx / per;
+    } else {
+        nm = blockIdx.x % NM;
+        c = blockIdx.x / NM;
+    }
+    const int n = nm / M, m = nm % M;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(clds + kZeroBytes + kWinBytes);
+    if (tid < kZeroBytes / 4) reinterpret_cast<int *>(clds)[tid] = 0;
+    unsigned long long ts_last = clock64();
+    (void)ts_last;
+
+    // ---- phase 1: masks, records, bounding boxes -----------------------------------------------------------------------
+    bin_cell<kCellThreads, true>(pl, starts, loc, aw, n, m, c, M, Lq, tab, rng, box, recs, ctl, dbg);
+    CTS(0);
+    {
+        const TableLayout tl = table_layout(rng);
+        write_masks<kCellThreads>(pl, tl, tab, n, m, c, M, masks);
+    }
+    CTS(1);
+
+    if (MSDA_DBG(dbg) & 1) return;                                             // ablation: binning only
+    // ---- phase 2: the windows of the four levels, smallest first, as long as they fit ----------------------------------
+    int wx0[kL], wy0[kL], wpitch[kL], wbase[kL], wcols[kL], wrows[kL];
+    {
+        int npx[kL];
+#pragma unroll
+        for (int l = 0; l < kL; ++l) {
+            // (wave-uniform: kept in scalar registers)
+            const int x0 = __builtin_amdgcn_readfirstlane(box[l][0]), y0 = __builtin_amdgcn_readfirstlane(box[l][1]);
+            const int x1 = -__builtin_amdgcn_readfirstlane(box[l][2]), y1 = -__builtin_amdgcn_readfirstlane(box[l][3]);
+            const bool any = x0 <= x1 && y0 <= y1;
+            wx0[l] = any ? x0 : 0; wy0[l] = any ? y0 : 0;
+            wcols[l] = any ? x1 - x0 + 1 : 0; wrows[l] = any ? y1 - y0 + 1 : 0;
+            wpitch[l] = wcols[l] + ((2 - wcols[l]) & 3);            // = 2 (mod 4): a quad's four corner rows on four bank quads
+            npx[l] = wpitch[l] * wrows[l];
+            wbase[l] = -1;
+        }
+        int used = 0;
+#pragma unroll
+        for (int round = 0; round < kL; ++round) {                    // smallest unplaced window first
+            int best = -1, bestpx = 0x3fffffff;
+#pragma unroll
+            for (int l = 0; l < kL; ++l) {
+                const bool cand = wbase[l] == -1 && npx[l] < bestpx;
+                best = cand ? l : best; bestpx = cand ? npx[l] : bestpx;
+            }
+#pragma unroll
+            for (int l = 0; l < kL; ++l) {
+                if (l == best) {
+                    if (used + npx[l] <= kMaxWinPx) { wbase[l] = kZeroBytes + used * 64; used += npx[l]; }
+                    else wbase[l] = -2;                               // gathered directly
+                }
+            }
+        }
+    }
+    const int row_bytes = M * 64;
+    const unsigned img_byte = (unsigned)n * (unsigned)S * (unsigned)row_bytes + (unsigned)(m * 64);
+    if (tid == 0) {
+#pragma unroll
+        for (int l = 0; l < kL; ++l) {
+            winfo[l][0] = pl.H[l]; winfo[l][1] = pl.W[l]; winfo[l][2] = wx0[l]; winfo[l][3] = wy0[l];
+            winfo[l][4] = wpitch[l]; winfo[l][5] = wbase[l]; winfo[l][6] = (int)starts[l]; winfo[l][7] = 0;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < kL; ++l) {
+        if (wbase[l] < 0 || wcols[l] == 0) continue;
+        const int W = pl.W[l], start = (int)starts[l];
+        const int pieces = wrows[l] * wcols[l] * 4;
+        const float inv = 1.f / (float)wcols[l];
+        for (int i = tid; i < pieces; i += kCellThreads) {
+            const int pix = i >> 2, piece = i & 3;
+            const int wy = (int)(((float)pix + 0.5f) * inv), wx = pix - wy * wcols[l];
+            const size_t src = (size_t)img_byte + (size_t)(start + (wy0[l] + wy) * W + wx0[l] + wx) * row_bytes + piece * 16;
+            *reinterpret_cast<uint4 *>(clds + wbase[l] + (wy * wpitch[l] + wx) * 64 + piece * 16) =
+                *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(value) + src);
+        }
+    }
+    __syncthreads();
+    CTS(2);
+    if (MSDA_DBG(dbg) & 2) return;                                             // ablation: binning + staging
+
+    // ---- phase 3: a quad per query, 16 queries per wave and task ---------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)value, 0, value_bytes, 0x00020000);
+    const int crn = lane & 3, rot = (lane >> 2) & 3;
+    const int cy = c / pl.CX, cx = c % pl.CX;
+    for (int task = wave; task * 16 < kCellQ; task += kCellThreads / 64) {
+        const int j = task * 16 + (lane >> 2);
+        const int lq = j < 256 ? 0 : j < 320 ? 1 : j < 336 ? 2 : 3;
+        const int r = j - (lq == 0 ? 0 : lq == 1 ? 256 : lq == 2 ? 320 : 336);
+        const int sh = 4 - lq;
+        const int iy = (cy << sh) + (r >> sh), ix = (cx << sh) + (r & ((1 << sh) - 1));
+        const int Hq = lq == 0 ? pl.H[0] : lq == 1 ? pl.H[1] : lq == 2 ? pl.H[2] : pl.H[3];
+        const int Wq = lq == 0 ? pl.W[0] : lq == 1 ? pl.W[1] : lq == 2 ? pl.W[2] : pl.W[3];
+        const int stq = lq == 0 ? (int)starts[0] : lq == 1 ? (int)starts[1] : lq == 2 ? (int)starts[2] : (int)starts[3];
+        const bool live = j < kCellQ && iy < Hq && ix < Wq;          // (a quad is live or dead as a whole)
+        const int q = live ? stq + iy * Wq + ix : 0;
+        const long qm = ((long)n * Lq + q) * M + m;
+        // quad lane c loads level c's 4 points and weights (whole 16-byte vectors, 192 contiguous bytes per quad)
+        const float4 *loc4 = reinterpret_cast<const float4 *>(loc) + qm * 8 + crn * 2;
+        float4 la = loc4[0], lb = loc4[1];
+        float4 wa = reinterpret_cast<const float4 *>(aw)[qm * 4 + crn];
+        uint4 g[4];                                                  // the query's grad_out row, pieces in rotated order
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[t] = reinterpret_cast<const uint4 *>(grad_out + qm * kD)[t ^ rot];
+#ifdef MSDA_ABLATION
+        if (MSDA_DBG(dbg) & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CTS(3); }     // task operands have arrived
+#endif
+        float4 gla = make_float4(0.f, 0.f, 0.f, 0.f), glb = gla, ga = gla;
+#pragma unroll 1
+        for (int l = 0; l < kL; ++l) {
+            const int H = __builtin_amdgcn_readfirstlane(winfo[l][0]), W = __builtin_amdgcn_readfirstlane(winfo[l][1]);
+            const int x0w = __builtin_amdgcn_readfirstlane(winfo[l][2]), y0w = __builtin_amdgcn_readfirstlane(winfo[l][3]);
+            const int pitch = __builtin_amdgcn_readfirstlane(winfo[l][4]), base = __builtin_amdgcn_readfirstlane(winfo[l][5]);
+            const unsigned lvl_byte = img_byte + (unsigned)__mul24(__builtin_amdgcn_readfirstlane(winfo[l][6]), row_bytes);
+            const bool own = crn == l;
+            float a_, x_, y_;
+            // (a scheduling fence per sample: the compiler otherwise hoists every corner read of the level and spills; pairs
+            //  of samples between fences were measured: no faster, scratch in the fused variants)
+            cell_sample(clds, vr, g, quad_bcast<0>(la.x), quad_bcast<0>(la.y), quad_bcast<0>(wa.x), H, W, x0w, y0w, pitch, base,
+                        lvl_byte, row_bytes, crn, rot, a_, x_, y_, dbg);
+            ga.x = own ? a_ : ga.x; gla.x = own ? x_ : gla.x; gla.y = own ? y_ : gla.y;
+            __builtin_amdgcn_sched_barrier(0);
+            cell_sample(clds, vr, g, quad_bcast<0>(la.z), quad_bcast<0>(la.w), quad_bcast<0>(wa.y), H, W, x0w, y0w, pitch, base,
+                        lvl_byte, row_bytes, crn, rot, a_, x_, y_, dbg);
+            ga.y = own ? a_ : ga.y; gla.z = own ? x_ : gla.z; gla.w = own ? y_ : gla.w;
+            __builtin_amdgcn_sched_barrier(0);
+            cell_sample(clds, vr, g, quad_bcast<0>(lb.x), quad_bcast<0>(lb.y), quad_bcast<0>(wa.z), H, W, x0w, y0w, pitch, base,
+                        lvl_byte, row_bytes, crn, rot, a_, x_, y_, dbg);
+            ga.z = own ? a_ : ga.z; glb.x = own ? x_ : glb.x; glb.y = own ? y_ : glb.y;
+            __builtin_amdgcn_sched_barrier(0);
+            cell_sample(clds, vr, g, quad_bcast<0>(lb.z), quad_bcast<0>(lb.w), quad_bcast<0>(wa.w), H, W, x0w, y0w, pitch, base,
+                        lvl_byte, row_bytes, crn, rot, a_, x_, y_, dbg);
+            ga.w = own ? a_ : ga.w; glb.z = own ? x_ : glb.z; glb.w = own ? y_ : glb.w;
+            __builtin_amdgcn_sched_barrier(0);
+            quad_rotate4(la); quad_rotate4(lb); quad_rotate4(wa);        // (after 4 rotations: the lane's own level again)
+        }
+        if (REFDIM == 0) {
+            if (live) {
+                float4 *gl4 = reinterpret_cast<float4 *>(g_loc) + qm * 8 + crn * 2;
+                gl4[0] = gla;
+                gl4[1] = glb;
+                reinterpret_cast<float4 *>(g_aw)[qm * 4 + crn] = ga;
+            }
+        } else if (live) {
+            constexpr int RD = REFDIM == 0 ? 2 : REFDIM;
+            const long row = qm / M;
+            const float a[4] = {wa.x, wa.y, wa.z, wa.w};
+            float gq[4] = {ga.x, ga.y, ga.z, ga.w};
+            const float gl[8] = {gla.x, gla.y, gla.z, gla.w, glb.x, glb.y, glb.z, glb.w};
+            geom::backward<bf16_t, RD>(g_qproj + row * (M * 48), ref + row * (kL * RD), shapes, m, M, crn, a, gq, gl);
+        }
+#ifdef MSDA_ABLATION
+        if (MSDA_DBG(dbg) & 16) CTS(4);                                        // samples + epilogue of the task
+#endif
+    }
+    CTS(5);
+}
+
+#ifdef MSDA_ABLATION
+}  // namespace
+}  // namespace msda
+extern "C" int msda_debug_cell_timeline(void *host, int reset)
+{
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(msda::cell_ts), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(msda::cell_ts), sizeof(msda::cell_ts));
+}
+namespace msda {
+namespace {
+#endif
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 bool make_patch_plan(const Problem &p, const int64_t *hs, PatchPlan &pl)
 {
@@ -569,8 +925,47 @@ size_t patch_workspace_bytes(const Problem &p, const int64_t *shapes_host)
     return mask_bytes(p, pl) + rec_bytes(p, pl);
 }
 
-// ctl: the control block of launch_dest_scatter (zeroed by the caller on the stream), masks: patch_workspace_bytes
-void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16)
+bool cell_backward_supports(const Problem &p, const int64_t *shapes_host)
+{
+    PatchPlan pl;
+    if (!patch_supports(p, shapes_host) || !make_patch_plan(p, shapes_host, pl)) return false;
+    if (pl.bin_lds > kCellTableMax || !quad_supports(p)) return false;      // (buffer addressing limits of the direct route)
+    return true;
+}
+
+// grad_sampling_loc / grad_attn_weight (f == nullptr) or the projection row's gradient (fused geometry) + masks + records
+void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, int *ctl, void *mask_ws)
+{
+    PatchPlan pl;
+    make_patch_plan(p, shapes_host, pl);
+    uint32_t *masks = reinterpret_cast<uint32_t *>(mask_ws);
+    float *recs = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(mask_ws) + mask_bytes(p, pl));
+    const int lds_bytes = kZeroBytes + kWinBytes + pl.bin_lds;
+    const unsigned vbytes = (unsigned)((size_t)p.N * p.S * p.M * kD * 2);
+    const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
+#define MSDA_CELL(RD)                                                                                                 \
+    do {                                                                                                              \
+        static bool attr = false;                                                                                     \
+        if (!attr) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void *)cell_backward_kernel<RD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      kZeroBytes + kWinBytes + kCellTableMax);                                        \
+            attr = true;                                                                                              \
+        }                                                                                                             \
+        hipLaunchKernelGGL((cell_backward_kernel<RD>), grid, block, lds_bytes, p.stream, pl, (const bf16_t *)p.value, \
+                           p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, (const bf16_t *)p.grad_out, \
+                           p.N, p.S, p.M, p.Lq, vbytes, (float *)p.g_loc, (float *)p.g_aw, f ? f->ref : nullptr,      \
+                           (bf16_t *)(f ? f->g_qproj : nullptr), masks, recs, ctl,                                    \
+                           ablation_env("RLIPV2_CELL_DBG", 0));                                                       \
+    } while (0)
+    if (!f) MSDA_CELL(0);
+    else if (f->refdim == 2) MSDA_CELL(2);
+    else MSDA_CELL(4);
+#undef MSDA_CELL
+}
+
+// ctl: the control block of launch_backward_dest (zeroed by the caller on the stream), masks: patch_workspace_bytes;
+// binned: cell_backward_kernel has already written the masks and records
+void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned)
 {
     PatchPlan pl;
     make_patch_plan(p, shapes_host, pl);
@@ -581,8 +976,9 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
         (void)hipFuncSetAttribute((const void *)bin2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(bin2_kernel, dim3(p.N * pl.CY * pl.CX * p.M), dim3(kBinThreads), pl.bin_lds, p.stream, pl, p.starts,
-                       (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);
+    if (!binned)
+        hipLaunchKernelGGL(bin2_kernel, dim3(p.N * pl.CY * pl.CX * p.M), dim3(kBinThreads), pl.bin_lds, p.stream, pl, p.starts,
+                           (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);
     const int grid = pl.items * p.N * p.M;
     static const int wps = ablation_env("RLIPV2_PATCH_WPS", 4);
 #define MSDA_PATCH(OT, WPS)                                                                                          \

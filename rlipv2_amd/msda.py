@@ -59,6 +59,20 @@ def _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_w
         raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
     if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
         raise RuntimeError("expected value [N,S,M,D], sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P]")
+    # the kernels index every operand with the dimensions taken from value / spatial_shapes / sampling_loc: a
+    # mismatched (e.g. un-broadcast) operand would be read out of bounds (the reference does not check either; its
+    # out-of-bounds reads are undefined behaviour -- here they are an error)
+    N, M = value.shape[0], value.shape[2]
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if tuple(sampling_loc.shape) != (N, Lq, M, L, P, 2) or tuple(attn_weight.shape) != (N, Lq, M, L, P):
+        raise RuntimeError(f"sampling_loc {tuple(sampling_loc.shape)} / attn_weight {tuple(attn_weight.shape)} do not match "
+                           f"value {tuple(value.shape)} and {L} levels: expected [{N},{Lq},{M},{L},{P},2] and [{N},{Lq},{M},{L},{P}]")
+    if tuple(spatial_shapes.shape) != (L, 2) or level_start_index.numel() != L:
+        raise RuntimeError("spatial_shapes must be [L, 2] and level_start_index [L]")
+    for name, t in extra:
+        if name == "grad_output" and (t.dim() != 3 or t.shape[0] != N or t.shape[1] != Lq or t.shape[2] != M * value.shape[3]):
+            raise RuntimeError(f"grad_output {tuple(t.shape)} does not match [N, Lq, M*D] = [{N}, {Lq}, {M * value.shape[3]}]")
 
 
 def _dims(value, spatial_shapes, sampling_loc):

@@ -306,6 +306,20 @@ def test_non_contiguous_input_raises():
         msda.ms_deform_attn_forward(v, _to_dev(shapes), _to_dev(starts), _to_dev(loc), _to_dev(aw), 64)
 
 
+def test_mismatched_operand_shapes_raise_instead_of_reading_out_of_bounds():
+    """An un-broadcast sampling_loc ([1, Lq, ...] next to a batch of 2) used to be read out of bounds by the kernels (they
+    take N from value): the wrapper now rejects it, as it rejects a grad_output of the wrong shape."""
+    rng = np.random.default_rng(5)
+    value, shapes, starts, loc, aw, go = random_problem(rng, 2, PYRAMID, 8, 32, 4, 4)
+    dv, ds, dst, dl, da, dg = (_to_dev(t) for t in (value, shapes, starts, loc, aw, go))
+    with pytest.raises(RuntimeError, match="do not match"):
+        msda.ms_deform_attn_forward(dv, ds, dst, dl[:1].contiguous(), da, 64)
+    with pytest.raises(RuntimeError, match="do not match"):
+        msda.ms_deform_attn_forward(dv, ds, dst, dl, da[:, :-1].contiguous(), 64)
+    with pytest.raises(RuntimeError, match="grad_output"):
+        msda.ms_deform_attn_backward(dv, ds, dst, dl, da, dg[:, :-1].contiguous(), 64)
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size (BASELINE config 2: N=4, 800x1333 pyramid) through size-independent properties
 # ---------------------------------------------------------------------------------------------

@@ -6,6 +6,8 @@ mode "model"     : encoder-like: reference point = pixel centre of the query's o
                    (reference: models/deformable_transformer.py:803-815) + offsets
                    k * dir_m / (W_l, H_l), k = 1..P, dir_m the 8 directions of the module's
                    initialisation (models/ops/modules/ms_deform_attn.py:66-74) + N(0, 1 px) jitter.
+mode "init"      : "model" without the jitter: the module exactly as initialised (sampling_offsets.weight = 0, bias = the
+                   direction grid, ms_deform_attn.py:66-74) -- what the random-init train step of bench.py produces.
 mode "decoder"   : Lq box queries: centre ~ U(0.1,0.9), size ~ U(0.05,0.5), offsets scaled by
                    size / (2P) (the 4-d reference-point branch, ms_deform_attn.py:110-112).
 """
@@ -38,7 +40,7 @@ def make_inputs(N, pyramid=PYRAMID_800x1333, M=8, D=32, P=4, Lq=None, mode="mode
     if mode == "uniform":
         Lq = S if Lq is None else Lq
         loc = torch.rand(N, Lq, M, L, P, 2, device=device, generator=g)
-    elif mode == "model":
+    elif mode in ("model", "init"):
         Lq = S
         ref = []
         for (H, W) in pyramid:
@@ -47,7 +49,8 @@ def make_inputs(N, pyramid=PYRAMID_800x1333, M=8, D=32, P=4, Lq=None, mode="mode
             ref.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
         ref = torch.cat(ref, 0)                                                        # [S, 2]
         off = dirs[None, None, :, None, None, :] * steps[None, None, None, None, :, None]
-        off = off + torch.randn(N, Lq, M, L, P, 2, device=device, generator=g)         # pixels
+        jitter = torch.randn(N, Lq, M, L, P, 2, device=device, generator=g)            # pixels
+        off = off + (jitter if mode == "model" else torch.zeros_like(jitter))           # (full [N, Lq, M, L, P, 2] shape)
         loc = ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
     elif mode == "decoder":
         Lq = 300 if Lq is None else Lq

@@ -334,7 +334,10 @@ def run_train_step_bench(args, world, rank, local_rank, device):
                 train.freeze_parameters_without_gradient(step_module, criterion, batch)
             else:
                 synchronizer = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
-                if os.environ.get("RLIPV2_DP_OVERLAP", "1") != "0" and not train.captured_collective_selftest(device):
+                # the 1 / world of the gradient average is applied inside the fused optimiser's kernels (no extra pass
+                # over the 425 MB gradient buffer); the float32-parameter optimiser path scales in the synchronizer
+                synchronizer.scale_in_optimizer = bool(master)
+                if os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1" and not train.captured_collective_selftest(device):
                     # (RCCL only; every other backend is answered "no" without a capture attempt)
                     # (all ranks agree on the verdict) captured collectives do not replay here: flat schedule
                     print("[bench] collectives cannot be captured into the backward graph here (not RCCL, or the self-test "
@@ -468,9 +471,7 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
             "pyramid": PYRAMID_800x1333,
             "parallelism": parallelism,
             "library_tuning": {
-                "miopen": ("find at first use (RLIPV2_MIOPEN_FIND=1)" if os.environ.get("RLIPV2_MIOPEN_FIND", "0") == "1"
-                           else "recorded find-db, lookup only (rlipv2_amd/tuned/miopen)"
-                           if "rlipv2_miopen_db" in os.environ.get("MIOPEN_USER_DB_PATH", "") else "library default"),
+                "miopen": miopen_tuning_report(),
                 "hipblaslt": "recorded solution table, lookup only (rlipv2_amd/tuned/gemm_gfx950.csv)"
                              if os.environ.get("RLIPV2_TUNED_GEMMS", "1") != "0" else "library default",
             },
@@ -524,6 +525,21 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
     print(json.dumps(line), flush=True)
 
 
+def miopen_tuning_report():
+    """What the line may claim about MIOpen's Find results: "recorded find-db" only if the db directory is ours AND its
+    files were recorded for the MIOpen version that is loaded (MIOpen ignores files of another version without a word)."""
+    import rlipv2_amd
+    if os.environ.get("RLIPV2_MIOPEN_FIND", "0") == "1":
+        return "find at first use (RLIPV2_MIOPEN_FIND=1)"
+    st = rlipv2_amd.miopen_db_status()
+    if not st["path"] or "rlipv2_miopen_db" not in st["path"]:
+        return "library default (no recorded find-db in use)"
+    if st["version_match"]:
+        return f"recorded find-db, lookup only (rlipv2_amd/tuned/miopen, recorded for MIOpen {st['recorded_for']} = the loaded library)"
+    return (f"library default: the recorded find-db is for MIOpen {st['recorded_for']}, the loaded library is {st['library']} "
+            "-- MIOpen ignores it (expect ~2 ms/step of split-K workspace kernels)")
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
     arguments>` as a child process and return its exit code.  Counting devices does not initialise the GPU on this
@@ -563,6 +579,9 @@ def main():
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="MIOpen restricted to deterministic convolution solvers (torch.backends.cudnn.deterministic): the one "
+                         "source of run-to-run noise in the step is a MIOpen convolution (tools/nondet_modules.py)")
     ap.add_argument("--padded", action="store_true",
                     help="non-best-case variant: images of (800,1333) and (736,1100) padded into one batch, mask path live")
     ap.add_argument("--var-targets", action="store_true",
@@ -584,6 +603,8 @@ def main():
                          f"--nproc-per-node {args.gpus}, or without RANK in the environment to let bench.py launch its ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.deterministic:
+        torch.backends.cudnn.deterministic = True
     # Development aid for boxes with ONE GPU: RLIPV2_SINGLE_DEVICE=1 puts every rank on cuda:0 and
     # RLIPV2_DIST_BACKEND=gloo carries the collectives over the host (RCCL refuses two ranks per device), so that
     # the multi-rank control flow (broadcast, capture, synchroniser, collectives) runs for real.  Not a benchmark.
@@ -620,7 +641,7 @@ def main():
                               "backward graph on a communication stream: bucket k travels while autograd computes the "
                               "earlier layers); model forward/backward replayed as HIP graphs"
                               if graphed and (world > 1 or os.environ.get("RLIPV2_FORCE_DP") == "1")
-                              and os.environ.get("RLIPV2_DP_OVERLAP", "1") != "0" else
+                              and os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1" else
                               f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
                               "model forward/backward replayed as HIP graphs" if graphed else
                               f"dp{world} (DDP: bucketed RCCL gradient all-reduce overlapped with backward); eager launches"),

@@ -65,6 +65,12 @@ int adamw_grad_sqnorm_bf16(const adamw_tensor *tensors, const adamw_chunk *chunk
 int adamw_step_bf16(const adamw_tensor *tensors, const adamw_chunk *chunks, int n_chunks, const float *sqnorm,
                     float max_norm, const adamw_group *groups, int n_groups, void *stream);
 
+/* As adamw_step_bf16 with every gradient multiplied by grad_scale (> 0) first -- in the norm as in the update.  The
+ * data-parallel step leaves the all-reduced gradients as SUMS and passes grad_scale = 1 / world_size here instead of
+ * making one more pass over the 425 MB gradient buffer (DistributedDataParallel averages, reference main.py:515-517). */
+int adamw_step_scaled_bf16(const adamw_tensor *tensors, const adamw_chunk *chunks, int n_chunks, const float *sqnorm,
+                           float max_norm, float grad_scale, const adamw_group *groups, int n_groups, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

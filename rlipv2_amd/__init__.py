@@ -30,9 +30,18 @@ def use_tuned_miopen_db() -> str | None:
     for name in names:
         with open(_os.path.join(src, name), "rb") as f:
             digest.update(f.read())
-    dst = _os.path.join(tempfile.gettempdir(), "rlipv2_miopen_db_%d_%s" % (_os.getuid(), digest.hexdigest()[:10]))
+    # a per-user cache directory (not a guessable path under a shared /tmp that somebody else could have created):
+    # $XDG_CACHE_HOME or ~/.cache, falling back to the temporary directory; in every case the directory must belong to
+    # this user and be writable by nobody else, otherwise the recorded results are not used
+    base = _os.environ.get("XDG_CACHE_HOME") or _os.path.join(_os.path.expanduser("~"), ".cache")
+    if not _os.path.isdir(_os.path.dirname(base)) or not _os.access(_os.path.dirname(base), _os.W_OK):
+        base = tempfile.gettempdir()
+    dst = _os.path.join(base, "rlipv2_amd", "rlipv2_miopen_db_%d_%s" % (_os.getuid(), digest.hexdigest()[:10]))
     try:
-        _os.makedirs(dst, exist_ok=True)
+        _os.makedirs(dst, mode=0o700, exist_ok=True)
+        st = _os.stat(dst)
+        if st.st_uid != _os.getuid() or (st.st_mode & 0o022):
+            return None
         for name in names:
             target = _os.path.join(dst, name)
             if not _os.path.exists(target):
@@ -43,6 +52,29 @@ def use_tuned_miopen_db() -> str | None:
         return None
     _os.environ["MIOPEN_USER_DB_PATH"] = dst
     return dst
+
+
+def miopen_db_status() -> dict:
+    """What can be known without a profiler about whether MIOpen is really using the recorded Find results: the db files
+    are keyed by device and MIOpen version in their NAMES (gfx950100.HIP.3_5_0_<build>.ufdb.txt) and MIOpen silently
+    ignores files of another version -- then its immediate mode picks the split-K solvers again (about 2 ms per step).
+    Returns {"path", "recorded_for", "library", "version_match"}; version_match False means the db is NOT in effect."""
+    path = _os.environ.get("MIOPEN_USER_DB_PATH", "")
+    out = {"path": path or None, "recorded_for": None, "library": None, "version_match": None}
+    try:
+        import torch
+        v = int(torch.backends.cudnn.version() or 0)             # MIOpen: major * 1e6 + minor * 1e3 + patch
+        out["library"] = "%d_%d_%d" % (v // 1000000, (v // 1000) % 1000, v % 1000)
+    except Exception:                                             # noqa: BLE001 -- reporting only
+        return out
+    if path and _os.path.isdir(path):
+        names = [n for n in _os.listdir(path) if n.endswith(".ufdb.txt")]
+        if names:
+            parts = names[0].split(".")
+            rec = parts[2] if len(parts) > 2 else ""
+            out["recorded_for"] = "_".join(rec.split("_")[:3])
+            out["version_match"] = out["recorded_for"] == out["library"]
+    return out
 
 
 use_tuned_miopen_db()

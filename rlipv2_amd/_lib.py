@@ -32,7 +32,7 @@ EXPORTS = (
     "add_layernorm_supported", "add_layernorm_workspace_bytes", "add_layernorm_forward_bf16",
     "add_layernorm_backward_bf16",
     # include/rlipv2_optim.h
-    "adamw_abi_sizes", "adamw_grad_sqnorm_bf16", "adamw_step_bf16",
+    "adamw_abi_sizes", "adamw_grad_sqnorm_bf16", "adamw_step_bf16", "adamw_step_scaled_bf16",
     # include/rlipv2_alif.h
     "alif_attention_supported", "alif_attention_padded_tv", "alif_attention_forward_bf16",
     "alif_attention_softmax_backward_bf16",
@@ -125,6 +125,8 @@ def lib() -> ctypes.CDLL:
     L.adamw_grad_sqnorm_bf16.restype = i
     L.adamw_step_bf16.argtypes = [vp, vp, i, vp, f32, vp, i, vp]
     L.adamw_step_bf16.restype = i
+    L.adamw_step_scaled_bf16.argtypes = [vp, vp, i, vp, f32, f32, vp, i, vp]
+    L.adamw_step_scaled_bf16.restype = i
     L.alif_attention_supported.argtypes = [i, i, i, i, i]
     L.alif_attention_padded_tv.argtypes = [i]
     L.alif_attention_forward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, f32, i, i, i, i, vp, vp, vp, vp, vp]

@@ -146,11 +146,55 @@ def pointwise_conv_bn(x, conv, bn, relu):
     w.r.t. the weight), the BN shift is the GEMM bias and the ReLU its epilogue, so the separate BN and
     activation passes over the feature map disappear and the weight gradient runs on the token-major MFMA
     kernel (linear.py) instead of MIOpen's split-K path with its float32 workspace zero/cast kernels."""
+    if conv.stride != (1, 1):
+        # a strided 1x1 convolution reads every stride-th pixel: subsample, then the same GEMM (the stages' downsample
+        # branches; their MIOpen weight-gradient solvers were two of the three remaining non-repeatable kernels of the
+        # step, profiles/r03_nondeterminism.txt)
+        x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
     N, C, H, W = x.shape
     scale, bias = bn.folded_vectors(x.dtype)
     w = conv.weight.reshape(conv.out_channels, C) * scale[:, None]
     y = token_linear(x.permute(0, 2, 3, 1).reshape(N * H * W, C), w, bias, relu=relu)
     return y.view(N, H, W, conv.out_channels).permute(0, 3, 1, 2)
+
+
+class RepeatableConv3x3(torch.autograd.Function):
+    """A stride-1, pad-1 3x3 convolution whose input gradient is computed as a FORWARD convolution of the output
+    gradient with the flipped, transposed weight instead of MIOpen's backward-data solver.
+
+    tools/nondet_modules.py (profiles/r03_nondeterminism.txt): with the extra-level convolution replaced, the only kernel
+    of the full-size train step whose result is not repeatable bit for bit is the backward-data solver MIOpen picks for
+    the trunk's 3x3 convolutions (`layer4.x.conv2`); its forward solvers and its weight-gradient solvers are repeatable.
+    Same arithmetic (a correlation with the 180-degree rotated kernel), a repeatable kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.conv2d(x, weight, None, 1, 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.transpose(0, 1).flip(2, 3).contiguous(memory_format=torch.channels_last)
+            dx = F.conv2d(dy, wt, None, 1, 1)
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return dx, dw
+
+
+repeatable_conv_backward = os.environ.get("RLIPV2_REPEATABLE_CONV", "1") != "0"      # (A/B switch)
+
+
+def conv3x3(x, conv):
+    if (repeatable_conv_backward and x.is_cuda and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and conv.kernel_size == (3, 3) and torch.is_grad_enabled()
+            and (x.requires_grad or conv.weight.requires_grad) and not torch.is_autocast_enabled()):
+        return RepeatableConv3x3.apply(x, conv.weight)
+    return conv(x)
 
 
 class Bottleneck(nn.Module):
@@ -171,13 +215,13 @@ class Bottleneck(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last))
         if self.downsample is None:
             idt = x
-        elif fast and self.downsample[0].stride == (1, 1):
-            idt = pointwise_conv_bn(x, self.downsample[0], self.downsample[1], relu=False)   # (layer1.0: BN folded into the GEMM)
+        elif fast and self.downsample[0].kernel_size == (1, 1) and self.downsample[0].padding == (0, 0):
+            idt = pointwise_conv_bn(x, self.downsample[0], self.downsample[1], relu=False)   # (BN folded into the GEMM)
         else:
             idt = self.downsample(x)
         if fast:
             out = pointwise_conv_bn(x, self.conv1, self.bn1, relu=True)
-            out = bn_relu(self.conv2(out), self.bn2)
+            out = bn_relu(conv3x3(out, self.conv2), self.bn2)
             if out.is_contiguous(memory_format=torch.channels_last):
                 return add_relu(pointwise_conv_bn(out, self.conv3, self.bn3, relu=False), idt)
             return F.relu(self.bn3(self.conv3(out)) + idt)

@@ -78,7 +78,8 @@ __device__ __forceinline__ void update_one(float g, float &p, float &m, float &v
 
 __global__ __launch_bounds__(THREADS) void step_kernel(const adamw_tensor *__restrict__ tensors,
                                                        const adamw_chunk *__restrict__ chunks,
-                                                       const float *__restrict__ sqnorm, float max_norm, Groups groups)
+                                                       const float *__restrict__ sqnorm, float max_norm, float grad_scale,
+                                                       Groups groups)
 {
     const adamw_chunk ck = chunks[blockIdx.x];
     const adamw_tensor t = tensors[ck.tensor];
@@ -88,8 +89,10 @@ __global__ __launch_bounds__(THREADS) void step_kernel(const adamw_tensor *__res
     const uint16_t *g = static_cast<const uint16_t *>(t.grad) + begin;
     uint16_t *pb = static_cast<uint16_t *>(t.param) + begin;
     float *p = t.master + begin, *m = t.exp_avg + begin, *v = t.exp_avg_sq + begin;
-    float clip = 1.f;
-    if (max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(*sqnorm) + 1e-6f));
+    // the gradients as stored are SUMS over the data-parallel ranks when the caller deferred the 1 / world scale to this
+    // kernel (grad_scale = 1 / world, otherwise 1): norm and update both see grad_scale * g
+    float clip = grad_scale;
+    if (max_norm > 0.f) clip = grad_scale * fminf(1.f, max_norm / (grad_scale * sqrtf(*sqnorm) + 1e-6f));
     const float step_size = h.step_size;
     int done = 0;
     if (aligned16(g) && aligned16(pb) && aligned16(p) && aligned16(m) && aligned16(v)) {
@@ -149,16 +152,24 @@ extern "C" int adamw_grad_sqnorm_bf16(const adamw_tensor *tensors, const adamw_c
     return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
 }
 
-extern "C" int adamw_step_bf16(const adamw_tensor *tensors, const adamw_chunk *chunks, int n_chunks,
-                               const float *sqnorm, float max_norm, const adamw_group *groups, int n_groups,
-                               void *stream_)
+extern "C" int adamw_step_scaled_bf16(const adamw_tensor *tensors, const adamw_chunk *chunks, int n_chunks,
+                                      const float *sqnorm, float max_norm, float grad_scale, const adamw_group *groups,
+                                      int n_groups, void *stream_)
 {
+    if (!(grad_scale > 0.f)) return MSDA_ERR_BAD_SHAPE;
     if (!tensors || !chunks || !groups || (max_norm > 0.f && !sqnorm)) return MSDA_ERR_NULL_POINTER;
     if (n_chunks < 0 || n_groups < 1 || n_groups > ADAMW_MAX_GROUPS) return MSDA_ERR_BAD_SHAPE;
     Groups g = {};
     for (int i = 0; i < n_groups; ++i) g.g[i] = groups[i];
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n_chunks > 0)
-        hipLaunchKernelGGL(step_kernel, dim3(n_chunks), dim3(THREADS), 0, stream, tensors, chunks, sqnorm, max_norm, g);
+        hipLaunchKernelGGL(step_kernel, dim3(n_chunks), dim3(THREADS), 0, stream, tensors, chunks, sqnorm, max_norm, grad_scale, g);
     return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}
+
+extern "C" int adamw_step_bf16(const adamw_tensor *tensors, const adamw_chunk *chunks, int n_chunks,
+                               const float *sqnorm, float max_norm, const adamw_group *groups, int n_groups,
+                               void *stream_)
+{
+    return adamw_step_scaled_bf16(tensors, chunks, n_chunks, sqnorm, max_norm, 1.f, groups, n_groups, stream_);
 }

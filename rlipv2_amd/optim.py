@@ -103,7 +103,9 @@ class FusedMasterAdamW:
         return self._tables[key]
 
     @torch.no_grad()
-    def step(self, max_norm=0.1):
+    def step(self, max_norm=0.1, grad_scale=1.0):
+        """`grad_scale`: factor on every gradient, applied inside the kernels (norm and update): the data-parallel step
+        hands over the all-reduced SUM with grad_scale = 1 / world instead of scaling its 425 MB buffer first."""
         idx, grads = self._grads()
         if not idx:
             return
@@ -130,8 +132,8 @@ class FusedMasterAdamW:
             st = L.adamw_grad_sqnorm_bf16(t_dev.data_ptr(), c_dev.data_ptr(), n_chunks, self.sqnorm.data_ptr(), stream)
             if st:
                 raise RuntimeError("adamw_grad_sqnorm: " + _lib.strerror(st))
-        st = L.adamw_step_bf16(t_dev.data_ptr(), c_dev.data_ptr(), n_chunks, self.sqnorm.data_ptr(),
-                               float(max_norm) if clip else 0.0, groups, len(pairs), stream)
+        st = L.adamw_step_scaled_bf16(t_dev.data_ptr(), c_dev.data_ptr(), n_chunks, self.sqnorm.data_ptr(),
+                                      float(max_norm) if clip else 0.0, float(grad_scale), groups, len(pairs), stream)
         if st:
             raise RuntimeError("adamw_step: " + _lib.strerror(st))
         # gradient (bf16) read twice (norm + update), master / two moments read + written (f32), bf16 parameter written
@@ -139,7 +141,8 @@ class FusedMasterAdamW:
         roofline.add(n * (2 * (2 if clip else 1) + 3 * 8 + 2))
 
     def grad_norm(self):
-        """sqrt of the squared-norm buffer of the last step (device tensor; no sync)."""
+        """sqrt of the squared-norm buffer of the last step (device tensor; no sync; of the gradients as stored, i.e.
+        before `grad_scale`)."""
         return self.sqnorm.sqrt()
 
     def state_dict(self):

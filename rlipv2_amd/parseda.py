@@ -57,6 +57,26 @@ def default_args(**overrides):
 
 
 
+def _strided_conv_as_gemm(x, conv):
+    """The extra pyramid level's convolution (3x3, stride 2, 2048 -> 256 on the last backbone map: reference
+    models/hoi.py:1946-1951) as im2col + one batched GEMM, token-major result [N, H_out * W_out, C_out].
+
+    Why not MIOpen: its forward solver for this shape is the ONE kernel of the whole train step whose output is not
+    repeatable bit for bit (tools/nondet_modules.py, profiles/r03_nondeterminism.txt) -- it made the loss and with it
+    every gradient differ by 2-5 % between two runs of the same step -- and MIOpen's deterministic mode costs 1.5 s per
+    step.  im2col (`unfold`) + GEMM + col2im (`fold`, a gather) are all repeatable; 1 092 output pixels x 18 432."""
+    N, C, H, W = x.shape
+    kh, kw = conv.kernel_size
+    Ho = (H + 2 * conv.padding[0] - kh) // conv.stride[0] + 1
+    Wo = (W + 2 * conv.padding[1] - kw) // conv.stride[1] + 1
+    cols = F.unfold(x, (kh, kw), padding=conv.padding, stride=conv.stride)          # [N, C * kh * kw, Ho * Wo]
+    w2d = conv.weight.reshape(conv.out_channels, C * kh * kw)
+    y = torch.matmul(w2d, cols)                                                      # [N, C_out, Ho * Wo]
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, -1, 1)
+    return y.transpose(1, 2).contiguous(), (Ho, Wo)
+
+
 class LevelViews(list):
     """Per-level [N, 256, H, W] views of one flattened [N, S, 256] tensor (`.flat`)."""
     flat = None
@@ -393,9 +413,8 @@ class RLIP_ParSeDA(nn.Module):
                 y = token_linear(x.permute(0, 2, 3, 1).reshape(N, H * W, Cin), conv.weight.view(conv.out_channels, Cin),
                                  conv.bias)
             else:
-                y4 = conv(x)                                            # channels-last in, channels-last out
-                N, _, H, W = y4.shape
-                y = y4.permute(0, 2, 3, 1).reshape(N, H * W, y4.shape[1])
+                y, (H, W) = _strided_conv_as_gemm(x, conv)              # [N, H*W, C_out], deterministic
+                N = x.shape[0]
             xs.append(y)
             shapes.append((H, W))
         norms = [proj[1] for proj in self.input_proj]

@@ -123,7 +123,7 @@ class GraphedStep:
     backward graph from those."""
 
     def __init__(self, step_module, model, batch, warmup=3, synchronizer=None, criterion=None, overlap=None):
-        """`overlap` (default: on with a synchronizer, RLIPV2_DP_OVERLAP=0 switches it off): the gradient all-reduce is
+        """`overlap` (RLIPV2_DP_OVERLAP=1; default off until a run on >= 2 GPUs has verified it): the gradient all-reduce is
         bucketed and captured INSIDE the backward graph on a communication stream, each bucket starting as soon as its
         last gradient exists (GradientSynchronizer.hooked) -- averaging overlapped with the rest of the backward pass
         (reference main.py:515-517).  Off: one flat all-reduce after the backward replay."""
@@ -131,7 +131,10 @@ class GraphedStep:
         self.synchronizer = synchronizer
         self.criterion = criterion
         if overlap is None:
-            overlap = os.environ.get("RLIPV2_DP_OVERLAP", "1") != "0"
+            # off by default: captured RCCL collectives have replayed on a 1-rank group only (no multi-GPU box so far);
+            # RLIPV2_DP_OVERLAP=1 selects the overlapped schedule, bench.py additionally runs the captured-collective
+            # self-test on all ranks before using it
+            overlap = os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1"
             if overlap and synchronizer is not None:
                 import torch.distributed as dist                  # only RCCL collectives can be captured into the graph
                 overlap = dist.is_initialized() and dist.get_backend(synchronizer.group) == "nccl"
@@ -203,7 +206,10 @@ class GraphedStep:
             order = [list(self.arrival)]
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(synchronizer.group) > 1:
                 dist.broadcast_object_list(order, src=0, group=synchronizer.group)
-            synchronizer.plan_buckets(order[0])
+            # (one layout per synchronizer: earlier captures have the flat buffer's offsets baked into their copies and
+            #  collectives -- a later capture keeps the plan, whatever order its own gradients arrived in)
+            if not synchronizer.planned:
+                synchronizer.plan_buckets(order[0])
         pool = torch.cuda.graph_pool_handle()
         # "thread_local": other threads of the process may call HIP while we capture -- with a process group
         # alive, RCCL's watchdog thread polls events, which in the default "global" mode invalidates the capture
@@ -266,6 +272,12 @@ class GraphedStep:
         self._deliver()
         self.leaves = None
 
+    @property
+    def grad_scale(self):
+        """factor the optimiser has to apply to `p.grad` (1 / world when the synchronizer leaves the SUM)"""
+        s = self.synchronizer
+        return s.grad_scale if (s is not None and s.scale_in_optimizer) else 1.0
+
     def _deliver(self):
         if self.synchronizer is not None and not self.overlap:
             self.synchronizer.all_reduce()
@@ -310,11 +322,43 @@ class GraphedStepCache:
     @staticmethod
     def bucket(batch):
         samples, text, targets = batch
+        split = text.get("obj_pred_names_sums")
+        split = tuple(int(v) for v in (split.flatten().tolist() if torch.is_tensor(split) else split)) if split is not None else ()
         return (tuple(samples.tensors.shape), str(samples.tensors.dtype), bool(getattr(samples, "no_padding", False)),
-                tuple(text["input_ids"].shape), tuple(len(t["obj_labels"]) for t in targets))
+                tuple(text["input_ids"].shape), tuple(len(t["obj_labels"]) for t in targets),
+                # the (objects, predicates) split of the text rows and the width of the verb labels are baked into a
+                # capture as well: two batches that differ only there must not share a graph
+                split, tuple(tuple(t["verb_labels"].shape) for t in targets))
+
+    def _agree(self, hit):
+        """Data-parallel runs: a capture runs eager warm-up steps and collectives of its own, a replay runs the
+        captured schedule -- ranks that disagree would issue different collectives and hang or reduce mismatched
+        buffers.  Every step all ranks exchange hit / miss (one MIN + MAX pair); all hit: replay, all miss: capture
+        together, mixed: an error that says how to avoid it (pre-capture the buckets collectively with `register`)."""
+        if self.synchronizer is None or not (dist.is_available() and dist.is_initialized()):
+            return
+        group = self.synchronizer.group
+        if dist.get_world_size(group) == 1:
+            return
+        dev = self.synchronizer.flat.device
+        flags = torch.tensor([1 if hit else 0, -1 if hit else 0], device=dev, dtype=torch.int32)   # MIN -> (all hit, -any hit)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
+        all_hit, any_hit = int(flags[0].item()) == 1, int(flags[1].item()) == -1
+        if all_hit or not any_hit:
+            return                                   # everybody replays, or everybody captures (same collectives)
+        raise RuntimeError("GraphedStepCache: the ranks disagree on this step's batch bucket (some have captured it, some "
+                           "have not); a capture issues collectives of its own, so ranks must capture together -- call "
+                           "register(batches) with every bucket of the run on all ranks before training, or pad the "
+                           "batches to common buckets")
+
+    def register(self, batches):
+        """capture every bucket of `batches` now (all ranks call this with batches of the same buckets in the same order)"""
+        for b in batches:
+            self.get(b)
 
     def get(self, batch):
         key = self.bucket(batch)
+        self._agree(key in self.graphs)
         g = self.graphs.pop(key, None)
         if g is None:
             if len(self.graphs) >= self.max_buckets:
@@ -455,6 +499,9 @@ class GradientSynchronizer:
         self.views = [None] * len(self.params)
         self.comm = torch.cuda.Stream(device=p0.device) if p0.is_cuda else None
         self.pending = []
+        self.planned = False                 # plan_buckets() has fixed the layout (captured graphs depend on it)
+        self.scale_in_optimizer = False      # leave the all-reduced SUM; the optimiser multiplies by `grad_scale`
+        self.grad_scale = 1.0
         self.set_buckets([list(range(len(self.params)))])
 
     # ---- layout ---------------------------------------------------------------------------------------------------
@@ -492,7 +539,13 @@ class GradientSynchronizer:
                 cur, size = [], 0
         if cur:
             buckets.append(cur)
+        if self.planned:
+            if [list(b) for b in buckets] != self.buckets:
+                raise RuntimeError("GradientSynchronizer: the bucket layout is already planned (graphs captured on it hold "
+                                   "its offsets); a different plan needs a new synchronizer")
+            return self.buckets
         self.set_buckets(buckets)
+        self.planned = True
         return buckets
 
     # ---- flat schedule --------------------------------------------------------------------------------------------
@@ -526,6 +579,10 @@ class GradientSynchronizer:
 
     def all_reduce(self):
         import torch.distributed as dist
+        if self.scale_in_optimizer:
+            dist.all_reduce(self.flat, group=self.group)
+            self.grad_scale = 1.0 / dist.get_world_size(self.group)
+            return
         if self._avg is None:
             self._avg = self._probe_avg()
         if self._avg:
@@ -594,7 +651,9 @@ class GradientSynchronizer:
             work.wait()
         if self.pending:
             world = self.pending[0][3]
-            if all(buf is part for _, part, buf, _ in self.pending):
+            if self.scale_in_optimizer and all(buf is part for _, part, buf, _ in self.pending):
+                self.grad_scale = 1.0 / world    # the optimiser's kernels multiply: no pass over the buffer here
+            elif all(buf is part for _, part, buf, _ in self.pending):
                 if world > 1:                    # one pass over the flat buffer: SUM -> mean
                     lo, hi = min(self.ranges)[0], max(self.ranges)[1]
                     self.flat[lo:hi].mul_(1.0 / world)
@@ -618,6 +677,7 @@ class _GradHooks:
         self.left = [len(b) for b in s.buckets]
         self.streams = [[] for _ in s.buckets]
         self.got = [False] * len(s.params)
+        self.held = [dict() for _ in s.buckets]          # bucket -> {stream: (views, gradients)} waiting for their copy
         self.handles = [p.register_hook(lambda g, i=i: self._arrived(i, g)) for i, p in enumerate(s.params)]
         return self
 
@@ -630,18 +690,36 @@ class _GradHooks:
             self.order.append(i)
             if self.record_only:
                 return None
-            # copied at once, on the stream autograd hands the gradient over on (the gradient is valid there and its
-            # memory is released in that stream's order -- no cross-stream lifetime to manage, nothing is kept alive)
-            s.views[i].copy_(g)
+            # A gradient is copied on the stream autograd hands it over on (valid there, its memory released in that
+            # stream's order: no cross-stream lifetime to manage) -- but not one copy kernel per parameter (747 launch-
+            # bound kernels inside the backward graph were +2 ms per step at world size 1): the gradients of a bucket
+            # are kept until the bucket is complete and leave as ONE multi-tensor copy per contributing stream.
             k = s.bucket_of[i]
-            if s.comm is not None:
-                cur = torch.cuda.current_stream(s.flat.device)
-                if all(cur != st for st in self.streams[k]):
-                    self.streams[k].append(cur)
+            cur = torch.cuda.current_stream(s.flat.device) if s.comm is not None else None
+            if g.data_ptr() != s.views[i].data_ptr():                 # (already in place: nothing to copy)
+                v = s.views[i]
+                if v.stride() == g.stride() and v.dtype == g.dtype:
+                    self.held[k].setdefault(cur, ([], []))
+                    self.held[k][cur][0].append(v)
+                    self.held[k][cur][1].append(g)
+                else:
+                    v.copy_(g)                                        # layout / dtype differs: its own copy, at once
+            if cur is not None and all(cur != st for st in self.streams[k]):
+                self.streams[k].append(cur)
             self.left[k] -= 1
             if self.left[k] == 0:
+                self._flush(k)
                 s.launch_bucket(k, self.streams[k])
         return None
+
+    def _flush(self, k):
+        """the held gradients of bucket k -> their views, one multi-tensor copy per stream they arrived on"""
+        for st, (views, grads) in self.held[k].items():
+            if not views:
+                continue
+            with (torch.cuda.stream(st) if st is not None else _nullcontext()):
+                torch._foreach_copy_(views, grads)
+        self.held[k] = {}
 
     def __exit__(self, *exc):
         s = self.sync
@@ -659,6 +737,7 @@ class _GradHooks:
                 if all(cur != st for st in self.streams[k]):
                     self.streams[k].append(cur)          # (the zero-fill above ran on this stream)
             if self.left[k] == 0:
+                self._flush(k)
                 s.launch_bucket(k, self.streams[k])
         assert all(n == 0 for n in self.left), self.left
         s.finish()
@@ -878,7 +957,9 @@ def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_
         loss.backward()
         if isinstance(step_module, GraphedStep):
             step_module.backward()
-    if isinstance(optimizer, (MasterWeightAdamW, FusedMasterAdamW)):
+    if isinstance(optimizer, FusedMasterAdamW):
+        optimizer.step(max_norm, grad_scale=float(getattr(step_module, "grad_scale", 1.0)))
+    elif isinstance(optimizer, MasterWeightAdamW):
         optimizer.step(max_norm)
     else:
         if max_norm > 0:

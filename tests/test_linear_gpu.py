@@ -269,3 +269,34 @@ def test_add_row_vector_gradient_matches_broadcast_add():
     y.backward(g)
     ref = g.float().sum((0, 1))
     assert float((row.grad.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@gpu
+def test_fused_adamw_grad_scale_equals_scaling_the_gradients_first():
+    """adamw_step_scaled_bf16 (include/rlipv2_optim.h): the data-parallel step leaves the all-reduced gradient SUM in the
+    flat buffer and hands 1 / world to the optimiser's kernels.  Same update as scaling the gradients in float32 first
+    (to the bf16 rounding of the parameters); clipping sees the scaled norm."""
+    from rlipv2_amd import train
+    torch.manual_seed(3)
+    world = 8
+
+    def make():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Linear(256, 384), torch.nn.Linear(384, 128)).cuda().to(torch.bfloat16)
+        return m, train.FusedMasterAdamW(m)
+
+    grads = [torch.randn(384, 256), torch.randn(384), torch.randn(128, 384), torch.randn(128)]
+    for max_norm in (0.1, 0.0):
+        m1, o1 = make()
+        m2, o2 = make()
+        for _ in range(3):
+            for p, g in zip(m1.parameters(), grads):
+                p.grad = (g * world).cuda().to(torch.bfloat16)                       # the SUM over 8 equal ranks
+            for p, g in zip(m2.parameters(), grads):
+                p.grad = ((g * world).cuda().to(torch.bfloat16).float() / world).to(torch.bfloat16)
+            o1.step(max_norm, grad_scale=1.0 / world)
+            o2.step(max_norm)
+        for p1, p2 in zip(m1.parameters(), m2.parameters()):
+            torch.testing.assert_close(p1.float(), p2.float(), rtol=0, atol=2e-2 * float(p2.float().abs().max()))
+        for a, b in zip(o1.master, o2.master):
+            torch.testing.assert_close(a, b, rtol=2e-2, atol=1e-5)

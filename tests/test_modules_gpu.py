@@ -315,8 +315,14 @@ def test_overlapped_bucketed_all_reduce_inside_the_backward_graph():
     """GraphedStep(overlap=True): tensor hooks + bucketed RCCL all-reduces captured INSIDE the backward graph on a
     communication stream (GradientSynchronizer.hooked) against the flat schedule (one all-reduce after the replay), on
     a 1-rank RCCL group in eval mode.  Same autograd pass, only the delivery of the gradients differs (exactness of
-    the schedule itself: tests/test_dp_cpu.py on 2 gloo ranks); on the device two runs of the SAME step already differ
-    by the atomics of the decoders' attention backward, so the comparison is over all gradients together."""
+    the schedule itself: tests/test_dp_cpu.py on 2 gloo ranks).
+
+    Round 2 compared with a 2 % band because two runs of the SAME step differed by 3.6 %; tools/nondet_modules.py has
+    since named the source: not "atomics of the attention backward" but ONE MIOpen convolution per model size (forward of
+    `input_proj.3.0` at the bench size, of `backbone...layer2.0.conv2` at this size) -- every hand-written kernel,
+    hipBLASLt GEMM and fused attention in the step is bit-repeatable.  With MIOpen restricted to its deterministic
+    solvers this small step is repeatable bit for bit (profiles/r03_nondeterminism.txt), so the schedules are compared
+    to 1e-3 and a second capture of the same schedule must reproduce the first exactly."""
     import torch.distributed as dist
     from rlipv2_amd import parseda, train
     created = False
@@ -327,6 +333,8 @@ def test_overlapped_bucketed_all_reduce_inside_the_backward_graph():
         created = True
     try:
         torch.manual_seed(0)
+        det_before = torch.backends.cudnn.deterministic
+        torch.backends.cudnn.deterministic = True                 # MIOpen: deterministic solvers only (see above)
         margs = parseda.default_args(num_queries=40, enc_layers=4, dec_layers=2)
         model, criterion = train.build_training(margs, device=DEV, with_text_encoder=True)
         train.to_bf16(model)
@@ -362,8 +370,13 @@ def test_overlapped_bucketed_all_reduce_inside_the_backward_graph():
             return (num / sum(float(b.pow(2).sum()) for b in y)) ** 0.5
 
         noise = distance(got["again"][0], got[False][0])        # a second capture of the SAME flat schedule
-        assert distance(got[True][0], got[False][0]) < max(2e-2, 2.0 * noise), (distance(got[True][0], got[False][0]), noise)
+        assert noise <= 1e-6, noise                               # (deterministic convolutions: nothing left to differ)
+        d = distance(got[True][0], got[False][0])
+        assert d <= 1e-3, (d, noise)                              # a wrong or missing bucket would be >= its share of the norm
+        worst = max(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12) for a, b in zip(got[True][0], got[False][0]))
+        assert worst <= 1e-2, worst                               # and no single parameter's gradient is off
     finally:
+        torch.backends.cudnn.deterministic = det_before
         if created:
             dist.destroy_process_group()
 

@@ -969,3 +969,172 @@ def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_
     if guard is not None:
         guard.submit(loss)
     return loss.detach()
+
+
+# ---- BASELINE config 5: mixed-dataset pre-training protocol ----------------------------------------------------------------
+class BatchIterativeSampler:
+    """Batch sampler of the mixed-dataset pre-training (reference datasets/mixed_dataset.py:48-214,
+    `BatchIterativeDistributedSampler`): the concatenation of K datasets is walked in rounds of
+    `len(paradigm)` batches, batch j of a round drawn from dataset `paradigm[j]` -- e.g. "0,1,2,2": one batch of
+    Visual Genome, one of COCO, two of Objects365 -- and every batch is cut across the ranks by stride.  Dataset 0 is
+    the anchor: an epoch is one pass over it (padded to a multiple of the world size, or cut with `drop_last`); the
+    other datasets are reshuffled with the same generator and truncated to as many samples as their share of the
+    rounds needs.  Yields lists of indices into the CONCATENATED dataset.
+
+    Restated from the behaviour (golden: tests/golden/protocol.json, produced by executing the reference class)."""
+
+    def __init__(self, dataset_sizes, batch_size, paradigm, num_replicas=1, rank=0, shuffle=True, seed=0, drop_last=False):
+        if not 0 <= rank < num_replicas:
+            raise ValueError(f"Invalid rank {rank}, rank should be in the interval [0, {num_replicas - 1}]")
+        self.sizes = [int(n) for n in dataset_sizes]
+        self.batch_size = int(batch_size)
+        self.paradigm = [int(d) for d in paradigm.split(",")] if isinstance(paradigm, str) else [int(d) for d in paradigm]
+        self.num_replicas, self.rank = int(num_replicas), int(rank)
+        self.shuffle, self.seed, self.drop_last = bool(shuffle), int(seed), bool(drop_last)
+        self.epoch = 0
+        anchor = self.sizes[0]
+        if self.drop_last and anchor % self.num_replicas != 0:
+            self.num_samples = math.ceil((anchor - self.num_replicas) / self.num_replicas)
+        else:
+            self.num_samples = math.ceil(anchor / self.num_replicas)
+        self.total_size = self.num_samples * self.num_replicas
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        rounds = self.num_samples // self.batch_size if self.drop_last else -(-self.num_samples // self.batch_size)
+        return rounds * len(self.paradigm)
+
+    def __iter__(self):
+        anchor = self.sizes[0]
+        g = torch.Generator()
+        g.manual_seed(self.seed + self.epoch)
+        first = torch.randperm(anchor, generator=g).tolist() if self.shuffle else list(range(anchor))
+        if not self.drop_last:
+            pad = self.total_size - len(first)
+            first += first[:pad] if pad <= len(first) else (first * math.ceil(pad / len(first)))[:pad]
+        else:
+            first = first[:self.total_size]
+        per_dataset, offset = [first], anchor
+        for d, n in enumerate(self.sizes[1:], start=1):
+            order = torch.randperm(n, generator=g).tolist() if self.shuffle else list(range(n))
+            share = sum(1 for p in self.paradigm if p == d)
+            per_dataset.append([i + offset for i in order][:anchor * share])
+            offset += n
+        cursor = [0] * len(per_dataset)
+        out = []
+        for _ in range(math.ceil(self.num_samples / self.batch_size)):
+            take = min(self.num_replicas * self.batch_size, len(per_dataset[0]) - cursor[0])
+            for d in self.paradigm:
+                chunk = per_dataset[d][cursor[d]:cursor[d] + take]
+                out.append(chunk[self.rank::self.num_replicas])
+                cursor[d] += take
+        return iter(out)
+
+
+class AccumulatedUpdate:
+    """`--gradient_strategy gradient_accumulation` of the reference's train loop (engine.py:136-153): the weighted losses
+    of the `len(paradigm)` consecutive batches of a round are SUMMED (not averaged) and one backward pass, one clipping
+    and one optimiser step follow on the last batch of the round; `vanilla` updates on every batch (:161-166).
+
+    Two equivalent forms of the same update:
+      * `add(loss)` -- the reference's own form: keeps the round's autograd graphs alive and runs one backward over the
+        summed loss (what the CPU golden pins, bit for bit in float32);
+      * `add_gradients()` -- for steps whose backward has already run (the graphed step: its backward graph leaves the
+        batch's gradients in static buffers): the parameters' `.grad` are added into float32 accumulators, and the
+        last batch of the round hands the sums to the optimiser.  d(sum of losses) = sum of d(losses): same update,
+        one batch of activations alive at a time."""
+
+    def __init__(self, params, optimizer, paradigm, strategy="gradient_accumulation", max_norm=0.1, clip=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.optimizer = optimizer
+        self.n = len(paradigm.split(",")) if isinstance(paradigm, str) else len(paradigm)
+        if strategy not in ("gradient_accumulation", "vanilla"):
+            raise ValueError(f"unknown gradient_strategy {strategy!r}")
+        if strategy == "gradient_accumulation" and self.n <= 1:
+            raise AssertionError("gradient_accumulation needs an iterative paradigm of more than one dataset")   # engine.py:139
+        self.strategy, self.max_norm = strategy, max_norm
+        self.clip = clip or (lambda ps, m: torch.nn.utils.clip_grad_norm_(ps, m))
+        self.i = 0
+        self.pending = None
+        self.acc = None
+
+    def _step(self):
+        if self.max_norm and self.max_norm > 0:
+            self.clip(self.params, self.max_norm)
+        self.optimizer.step()
+
+    def add(self, loss):
+        """one batch's weighted loss (a scalar with its autograd graph); returns True when the optimiser stepped"""
+        self.i += 1
+        if self.strategy == "vanilla":
+            self.optimizer.zero_grad()
+            loss.backward()
+            self._step()
+            return True
+        pos = self.i % self.n
+        if pos == 1:
+            self.pending = loss
+            return False
+        self.pending = self.pending + loss
+        if pos != 0:
+            return False
+        self.optimizer.zero_grad()
+        self.pending.backward()
+        self.pending = None
+        self._step()
+        return True
+
+    def add_gradients(self, step=None):
+        """the current `.grad` of the parameters is this batch's gradient; `step(params)`: custom clip + optimiser call"""
+        self.i += 1
+        last = self.strategy == "vanilla" or self.i % self.n == 0
+        first = self.strategy == "vanilla" or self.i % self.n == 1
+        if self.strategy == "gradient_accumulation":
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+            if first:
+                self.acc = [g.detach().float().clone() for g in grads]
+            else:
+                torch._foreach_add_(self.acc, [g.detach().float() for g in grads])
+            if not last:
+                return False
+            for p, a in zip(self.params, self.acc):
+                p.grad = a.to(p.dtype)
+            self.acc = None
+        if step is not None:
+            step(self.params)
+        else:
+            self._step()
+        return True
+
+
+def train_round(step_module, criterion, optimizer, batches, paradigm, strategy="gradient_accumulation", max_norm=0.1,
+                autocast_dtype=None, state=None):
+    """One round of the mixed-dataset protocol (BASELINE config 5; reference engine.py:99-166 with
+    --gradient_strategy gradient_accumulation): `batches` = the `len(paradigm)` batches of the round in paradigm order
+    (one per dataset slot, their image sizes and text lists may differ).  Each batch runs forward + backward on its own
+    (one batch of activations alive at a time), the gradients are summed in float32 and ONE clipping + optimiser step
+    closes the round -- the same update as the reference's backward over the summed losses (AccumulatedUpdate).  Returns
+    the list of the batches' weighted losses (device tensors)."""
+    params = [p for p in step_module.parameters() if p.requires_grad]
+    upd = state if state is not None else AccumulatedUpdate(params, optimizer, paradigm, strategy=strategy, max_norm=max_norm)
+
+    def apply(ps):
+        if isinstance(optimizer, (MasterWeightAdamW, FusedMasterAdamW)):
+            optimizer.step(max_norm)
+        else:
+            if max_norm and max_norm > 0:
+                torch.nn.utils.clip_grad_norm_(ps, max_norm, foreach=True)
+            optimizer.step()
+
+    losses = []
+    for samples, text, targets in batches:
+        with torch.autocast(samples.tensors.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
+            outputs = step_module(samples, text, targets)
+        loss = criterion.weighted_sum(criterion(outputs, targets))
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        upd.add_gradients(step=apply)
+        losses.append(loss.detach())
+    return losses

@@ -111,23 +111,47 @@ def test_full_parseda_f32():
             C.close(params[name].grad.cpu(), g[key], 1e-3, 1e-5, "grad " + name)
 
 
-def test_full_parseda_bf16_is_close_to_f32_reference():
-    """bf16 policy: weights / activations / value in bfloat16, sampling geometry, softmax and
-    accumulators in float32.  Not a parity claim -- a sanity band: logits within 5e-2 of the
-    float32 reference's range, boxes within 2e-2."""
+def test_full_parseda_bf16_against_the_f32_reference_golden():
+    """The headline dtype at model level, with a stated tolerance (measured with tools/bf16_parity_probe.py on MI355X,
+    round 3; the margins below are ~1.5-3x the measured values).  bf16 policy: weights / activations / value in bfloat16;
+    sampling geometry, softmax, bilinear weights and accumulators in float32.  Against the float32 reference golden
+    (two images of different size, 5 outputs + first auxiliary layer):
+
+      logits  max |err| <= 2e-2 x max |reference|     (measured: subject / object 4.2e-3, verb 1.24e-2)
+      boxes   max |err| <= 5e-3 absolute               (measured: 8.0e-4 / 1.8e-3)
+      gradients of the golden's loss: cosine with the float32 reference >= 0.88 for the three feature maps and
+      every sentinel parameter (measured: features 0.920-0.990, parameters 0.905-1.000; the low ones are gradients
+      that pass the sampling locations' floor() kinks, which one bf16 rounding of an offset moves across).
+    Parity proper is claimed in float32 (test_full_parseda_f32: logits 1e-3 rel, boxes 1e-4 abs)."""
     g = C.load("parseda")
     model, bb = C.build_small_parseda()
     model = model.to(DEV).to(torch.bfloat16)
     gb = {k: (v.to(torch.bfloat16) if v.dtype == torch.float32 else v) for k, v in g.items()}
     gb["img_mask"] = g["img_mask"]
     mc, out, feats, _ = C.run_small_parseda(model, bb, gb, device=DEV)
+    loss = 0
     for k in C.KEYS:
-        ref = g[k]
-        err = (out[k].float().cpu() - ref).abs().max().item()
-        band = 2e-2 if "boxes" in k else 5e-2 * max(1.0, ref.abs().max().item())
-        assert err < band, (k, err, band)
-    sum(out[k].float().sum() for k in C.KEYS).backward()
-    assert all(torch.isfinite(t.grad.float()).all() for t, _ in feats)
+        for got, ref, what in ((out[k], g[k], k), (out["aux_outputs"][0][k], g["aux0_" + k], "aux " + k)):
+            err = (got.float().cpu() - ref).abs().max().item()
+            tol = 5e-3 if "boxes" in k else 2e-2 * ref.abs().max().item()
+            assert err <= tol, (what, err, tol)
+        loss = loss + (out[k].float() * g["g_" + k].to(DEV)).sum() + (out["aux_outputs"][0][k].float() * g["g_" + k].to(DEV)).sum() * 0.5
+    loss.backward()
+
+    def cosine(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+    for i, (t, _) in enumerate(feats):
+        assert torch.isfinite(t.grad.float()).all()
+        c = cosine(t.grad.float().cpu(), g[f"g_feat{i}"])
+        assert c >= 0.88, (f"g_feat{i}", c)
+    params = dict(model.named_parameters(remove_duplicate=False))
+    for key in g:
+        if key.startswith("gparam_") and g[key].numel():
+            name = key[len("gparam_"):].replace("__", ".")
+            c = cosine(params[name].grad.float().cpu(), g[key])
+            assert c >= 0.88, (name, c)
 
 
 @pytest.mark.parametrize("nd", [2, 4])
@@ -720,3 +744,40 @@ def test_step_roofline_probe_runs_on_the_small_model():
     assert r["bytes"] > 1e8 and r["flops"] > 1e9 and r["aten_ops"] > 100
     assert r["library_bytes"] > 0                      # the ctypes-bound kernels reported their operands
     assert 0 < r["T_mfma_s"] < r["T_mem_s"] < 1.0      # a memory-bound step
+
+
+@pytest.mark.gpu
+def test_config5_mixed_dataset_round_swin_large_with_text_encoder():
+    """BASELINE config 5 (Swin-L + RoBERTa-shaped text encoder, mixed pseudo-SGG pre-training) at a small size: one round
+    of the iterative paradigm "0,1,2" -- three batches of different image sizes and text-list lengths, as three datasets
+    deliver them -- with gradient accumulation (train.train_round; protocol pinned against the reference on the CPU,
+    tests/test_protocol_cpu.py): one optimiser step per round, finite losses, parameters of backbone, text encoder,
+    encoder and decoders all move."""
+    from rlipv2_amd import train
+    torch.manual_seed(0)
+    margs = parseda.default_args(num_queries=40, enc_layers=4, dec_layers=2)       # (fusion layers == decoder layers)
+    model, criterion = train.build_training(margs, device=DEV, with_text_encoder=True, backbone_name="swin_large")
+    train.to_bf16(model)
+    batches = [train.synthetic_batch(2, 256, 320, n_obj=13, n_verb=7, triplets=3, device=DEV, seed=0),
+               train.synthetic_batch(2, 224, 288, n_obj=9, n_verb=5, triplets=2, device=DEV, seed=1),
+               train.synthetic_batch(2, 192, 256, n_obj=17, n_verb=4, triplets=4, device=DEV, seed=2)]
+    for b in batches:
+        b[0].tensors = b[0].tensors.to(torch.bfloat16)
+    step = train.ParSeDATrainStep(model)
+    model.train()
+    train.freeze_parameters_without_gradient(step, criterion, batches[0])
+    opt = train.FusedMasterAdamW(model)
+    watch = {k: None for k in ("backbone", "text_encoder", "transformer.encoder", "ho_decoder", "verb_decoder")}
+    for n, p in model.named_parameters():
+        for k in watch:
+            if watch[k] is None and k in n and p.requires_grad and p.numel() > 64:
+                watch[k] = (n, p, p.detach().float().clone())
+    assert all(v is not None for v in watch.values()), watch
+    steps_before = opt.t
+    losses = train.train_round(step, criterion, opt, batches, "0,1,2")
+    torch.cuda.synchronize()
+    assert len(losses) == 3 and all(bool(torch.isfinite(l)) for l in losses)
+    assert opt.t == steps_before + 1                      # ONE update for the round
+    for k, (n, p, before) in watch.items():
+        assert not torch.equal(p.detach().float(), before), f"{n} did not move"
+        assert bool(torch.isfinite(p.detach().float()).all())

@@ -148,8 +148,14 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
         if isinstance(text, tuple):                       # pre-encoded (reference :569-571)
             text_attention_mask, text_memory, sums = text
             return text_attention_mask, text_memory, sums
-        ids, am = text["input_ids"].to(device), text["attention_mask"].to(device)
-        pooled = self.text_encoder(input_ids=ids, attention_mask=am).pooler_output          # [n_text, 768]
+        cache = getattr(self, "label_cache", None)
+        if cache is not None and not torch.cuda.is_current_stream_capturing():
+            # opt-in (`transformer.label_cache = text_batch.LabelEmbeddingCache()`): identical labels encoded once, and with
+            # a frozen encoder in eval mode served from the table across calls (host-side keys: not inside a capture)
+            pooled = cache.encode(self.text_encoder, text["input_ids"], text["attention_mask"])
+        else:
+            ids, am = text["input_ids"].to(device), text["attention_mask"].to(device)
+            pooled = self.text_encoder(input_ids=ids, attention_mask=am).pooler_output      # [n_text, 768]
         text_memory = pooled[:, None, :]                                                    # [n_text, 1, 768]
         text_attention_mask = ~(text_memory.sum(dim=-1) > 0)                                # Q2
         if text_memory.shape[1] != bs:                                                      # Q12

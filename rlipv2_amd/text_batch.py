@@ -148,3 +148,88 @@ def merge_batch_data(kwargs, use_no_obj_token, use_all_text_labels, negative_tex
     for t, o, s, v in zip(targets, new_obj, new_sub, new_verb):
         t["obj_labels"], t["sub_labels"], t["verb_labels"] = o, s, v
     return kwargs
+
+
+# ---- text encoder input: de-duplication, token-length buckets, label-embedding cache ------------------------------------
+TOKEN_BUCKETS = (4, 8, 12, 16, 24, 32, 48, 64)
+
+
+def bucket_token_length(input_ids, attention_mask, pad_id=1, buckets=TOKEN_BUCKETS):
+    """The tokenizer pads a batch of label texts to its longest member (`padding="longest"`,
+    dab_deformable/deformable_transformer.py:496); a graph-captured step is specific to that width, so every new longest
+    label would cost a capture.  Here the width is cut to the longest real row and padded up to the next bucket
+    (4, 8, 12, 16, ... tokens): a handful of widths for the whole run, and no encoder work on all-padding columns beyond
+    the bucket.  Host-side (the token tensors are built on the host): [n, T] -> [n, T_bucket]."""
+    if input_ids.dim() != 2 or input_ids.shape != attention_mask.shape:
+        raise ValueError("input_ids / attention_mask must be [n_text, T] of the same shape")
+    longest = int(attention_mask.sum(1).max()) if input_ids.numel() else 0
+    width = next((b for b in buckets if b >= longest), longest)
+    T = input_ids.shape[1]
+    if width <= T:
+        return input_ids[:, :width].contiguous(), attention_mask[:, :width].contiguous()
+    pad = width - T
+    return (F.pad(input_ids, (0, pad), value=pad_id), F.pad(attention_mask, (0, pad), value=0))
+
+
+def dedupe_token_rows(input_ids, attention_mask):
+    """Identical label texts (the same token row) are encoded once: -> (unique ids, unique mask, inverse) with
+    `unique[inverse] == rows`, first-occurrence order.  The reference encodes every string of `flat_text`
+    (deformable_transformer.py:490-498), duplicates included; gathering the pooled rows through `inverse` gives the
+    same tensor and, in the backward pass, sums the duplicates' gradients as autograd's index does."""
+    seen, keep, inverse = {}, [], []
+    rows = [tuple(r) for r in (input_ids * attention_mask + (1 - attention_mask) * -1).tolist()]
+    for i, r in enumerate(rows):
+        j = seen.get(r)
+        if j is None:
+            j = seen[r] = len(keep)
+            keep.append(i)
+        inverse.append(j)
+    keep = torch.tensor(keep, dtype=torch.long)
+    return input_ids[keep], attention_mask[keep], torch.tensor(inverse, dtype=torch.long)
+
+
+class LabelEmbeddingCache:
+    """Pooled text-encoder outputs per label text, for runs whose text encoder is FROZEN (`--freeze_text_encoder`,
+    evaluation, zero-shot inference: hoi.py PostProcessHOI paths): the label vocabulary of a dataset is a few hundred
+    strings that recur in every batch, and the 12-layer encoder is ~107 launches per call.  Keyed by the token row; rows
+    not seen before are encoded together in one call (bucketed width), everything else is a gather.  With a trainable
+    encoder the embeddings change every step -- `encode(..., use_cache=False)` then only de-duplicates within the call."""
+
+    def __init__(self, max_entries=65536):
+        self.rows = {}                      # token tuple -> row in self.table
+        self.table = None                   # [entries, hidden] on the encoder's device
+        self.max_entries = max_entries
+        self.hits = self.misses = 0
+
+    def clear(self):
+        self.rows, self.table = {}, None
+
+    def encode(self, text_encoder, input_ids, attention_mask, use_cache=None):
+        """-> pooled embeddings [n_text, hidden] in the rows' order.  `use_cache` default: the encoder has no trainable
+        parameter and is in eval mode (dropout off)."""
+        if use_cache is None:
+            use_cache = (not any(p.requires_grad for p in text_encoder.parameters())) and not text_encoder.training
+        ids_h, am_h = input_ids.cpu(), attention_mask.cpu()
+        uid, uam, inverse = dedupe_token_rows(ids_h, am_h)
+        device = next(text_encoder.parameters()).device
+        if not use_cache:
+            uid, uam = bucket_token_length(uid, uam)
+            pooled = text_encoder(input_ids=uid.to(device), attention_mask=uam.to(device)).pooler_output
+            return pooled[inverse.to(device)]
+        keys = [tuple(r) for r in (uid * uam + (1 - uam) * -1).tolist()]
+        new = [i for i, k in enumerate(keys) if k not in self.rows]
+        self.hits += len(keys) - len(new)
+        self.misses += len(new)
+        if new:
+            if len(self.rows) + len(new) > self.max_entries:
+                self.clear()
+                new = list(range(len(keys)))
+            nid, nam = bucket_token_length(uid[new], uam[new])
+            with torch.no_grad():
+                fresh = text_encoder(input_ids=nid.to(device), attention_mask=nam.to(device)).pooler_output
+            base = 0 if self.table is None else self.table.shape[0]
+            self.table = fresh if self.table is None else torch.cat((self.table, fresh), 0)
+            for j, i in enumerate(new):
+                self.rows[keys[i]] = base + j
+        index = torch.tensor([self.rows[k] for k in keys], dtype=torch.long)[inverse]
+        return self.table[index.to(device)]

@@ -616,6 +616,7 @@ __global__ __launch_bounds__(Geo<TH>::kThreads) void combine_kernel(DestPlan pl,
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 constexpr int kDestTH = 8;                   // destination tile height in use
+constexpr int kDestLdsMax = 96 * 1024;       // dynamic LDS bound of bin_kernel / dest_kernel (2 workgroups per CU stay possible)
 
 bool make_plan(const Problem &p, const int64_t *hs, DestPlan &pl)
 {
@@ -678,7 +679,11 @@ bool dest_supports(const Problem &p, const int64_t *shapes_host)
     if (!quad_supports(p)) return false;                       // K1 is the quad reduce kernel
     DestPlan pl;
     if (!make_plan(p, shapes_host, pl)) return false;
-    if (pl.Ts > kMaxSrcTiles || pl.Td > 4096) return false;    // LDS mask row / bin_kernel's LDS table
+    // LDS: bin_kernel's table is Td * 32 bytes, dest_kernel's carve-up grows with Ts (67 KB for float32 at the 800x1333
+    // pyramid); both are asked for with hipFuncSetAttribute at launch and bounded here -- larger pyramids fall back to the
+    // sorted scatter (msda_window.hip) instead of failing in the middle of a backward pass
+    if (pl.Ts > kMaxSrcTiles || pl.Td > 3072) return false;
+    if (DestLds<float, kDestTH>::bytes(pl.Ts) > kDestLdsMax || DestLds<bf16_t, kDestTH>::bytes(pl.Ts) > kDestLdsMax) return false;
     if ((long)pl.items >= (1L << 30)) return false;
     if (mask_bytes(p, pl) > ((size_t)1 << 31)) return false;
     return true;
@@ -717,7 +722,7 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
     int *counter = reinterpret_cast<int *>(ws);
     uint32_t *masks = reinterpret_cast<uint32_t *>(ws + kCtlBytes);
     float *partials = reinterpret_cast<float *>(ws + kCtlBytes + mask_bytes(p, pl));
-    (void)hipMemsetAsync(counter, 0, kCtlBytes, p.stream);
+    if (hipMemsetAsync(counter, 0, kCtlBytes, p.stream) != hipSuccess) return;   // (the error stays recorded: the ABI reports MSDA_ERR_LAUNCH)
     // Encoder calls with bfloat16 gradients (msda_patch.hip): cell_backward_kernel does K1's work from LDS-resident
     // windows and bins the samples, the matrix-core patch pass produces grad_value; the kernels below then find the gate
     // word zero and return at once.  Only when the binning met a sample outside its cell's reach (gate != 0: the patch
@@ -734,6 +739,13 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
     } else {
         k1();
     }
+    {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax);
+            attr = true;
+        }
+    }
     hipLaunchKernelGGL(bin_kernel, dim3(p.N * pl.Ts * p.M), dim3(256), pl.Td * 32, p.stream, pl, p.starts,
                        (const float *)p.loc, p.M, p.Lq, masks, gate);
     constexpr int TH = kDestTH, kThreads = Geo<TH>::kThreads;
@@ -744,6 +756,13 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
     do {                                                                                                             \
         const int lds_bytes = DestLds<VT, TH>::bytes(pl.Ts);                                                         \
         auto kern = waves == 8 ? dest_kernel<VT, OT, TH, 8> : waves == 6 ? dest_kernel<VT, OT, TH, 6> : dest_kernel<VT, OT, TH, 4>; \
+        static bool attr_set = false;                            /* once per instantiation, not inside every capture */ \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute((const void *)dest_kernel<VT, OT, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax); \
+            (void)hipFuncSetAttribute((const void *)dest_kernel<VT, OT, TH, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax); \
+            (void)hipFuncSetAttribute((const void *)dest_kernel<VT, OT, TH, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax); \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, p.stream, pl, p.starts, (const float *)p.loc, \
                            (const float *)p.aw, (const VT *)p.grad_out, masks, counter, (OT *)p.g_value, partials,  \
                            p.N, p.S, p.M, p.Lq, gate);                                                               \

@@ -1,11 +1,14 @@
-"""Per-kernel HBM traffic (bytes per launch) from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_final_r02.sh."""
+"""Per-kernel HBM traffic (bytes per launch) from the FETCH_SIZE / WRITE_SIZE passes of tools/gpu_final_r0{2,3}.sh."""
 import collections, csv, glob, json, re, sys
 out = sys.argv[1]
 def short(name):
-    m = re.search(r"(dest_kernel|bin_kernel|combine_kernel|quad_backward_shared_kernel<[^>]*>|quad_forward_fused_kernel|quad_forward_kernel)", name)
+    m = re.search(r"(patch_dest_kernel|cell_backward_kernel<[^>]*>|bin2_kernel|dest_kernel|bin_kernel|combine_kernel|"
+                  r"quad_backward_shared_kernel<[^>]*>|quad_forward_fused_kernel|quad_forward_kernel)", name)
     if not m:
         return None
     k = m.group(1)
+    if k.startswith("cell_backward_kernel"):
+        k = "cell_backward_kernel" + ("" if "<0>" in k else "+geometry")
     if k.startswith("quad_backward_shared_kernel"):
         k = "quad_backward_shared_kernel" + ("+geometry" if re.search(r", [24]>", k) else "")
     return k

@@ -67,6 +67,7 @@ struct PatchPlan {                            // by-value kernel argument, built
     int sbase[kL];                            // first mask slot of the level, per (image, head)
     int slots;                                // mask slots per (image, head)
     int parts[kL];                            // waves per patch (1, 2 or 4)
+    int reps[kL];                             // patches per wave, one after the other (only where parts == 1)
     int ibase[kL], nitems[kL];                // workgroups of the level per (image, head); coarsest level first
     int items;
     int bin_lds;                              // bytes of bin2_kernel's LDS table (maximum over the cells)
@@ -314,7 +315,7 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, const f32x
     *reinterpret_cast<uint2 *>(p) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
 }
 
-template <typename OT, int WPS>
+template <typename OT, int WPS, bool MULTI>
 __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
     PatchPlan pl, const int64_t *__restrict__ starts, const float *__restrict__ recs,
     const bf16_t *__restrict__ grad_out, const uint32_t *__restrict__ masks, const int *__restrict__ ctl,
@@ -341,44 +342,58 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
     int l = 0;
 #pragma unroll
     for (int k = 0; k < kL; ++k) l = (it >= pl.ibase[k] && it < pl.ibase[k] + pl.nitems[k]) ? k : l;
-    const int parts = pl.parts[l];
-    const int pi = (it - pl.ibase[l]) * (kWaves / parts) + wave / parts, part = wave % parts;
+    const int parts = pl.parts[l], reps = MULTI ? pl.reps[l] : 1;   // waves per patch | patches per wave (> 1 only with parts == 1)
+    const int part = wave % parts;
+    const int pi0 = ((it - pl.ibase[l]) * (kWaves / parts) + wave / parts) * reps;
     const int PX = pl.PX[l], npatch = pl.PY[l] * PX;
-    const bool active = pi < npatch;
     const int n = nm / M, m = nm % M;
     const int H = pl.H[l], W = pl.W[l];
+    const int nbx = pl.nbx[l], nb2 = pl.nby[l] * nbx, invx = pl.invx[l];
+    const float *rbase = recs + ((size_t)nm * kL + l) * (size_t)(pl.CY * pl.CX) * kCellQ * 12;
+    const float Hf = (float)H, Wf = (float)W;
+    // per-level (start, width) of the query levels, selected per lane below
+    const int st0 = (int)starts[0], st1 = (int)starts[1], st2 = (int)starts[2], st3 = (int)starts[3];
+    const int W0 = pl.W[0], W1 = pl.W[1], W2 = pl.W[2], W3 = pl.W[3];
+    const int kk = lane & 31, half = lane >> 5;
+    const int nq = n * Lq;
+    // transpose-read addresses: lane (p = lane & 15, kg = lane >> 4) supplies row 8 kg + 4 j + (p >> 2), piece p & 3
+    const int p16 = lane & 15, kg = lane >> 4;
+    const unsigned a_rd = lds0 + kOffA + (8 * kg + (p16 >> 2)) * 32 + (p16 & 3) * 8;         // + matrix * 1024 + j * 128
+    const unsigned g_rd = lds0 + kOffG + (8 * kg + (p16 >> 2)) * 64 + (p16 & 3) * 8;         // + tile * 32 + j * 256
+    // This wave's mask words of a patch: slots part, part + parts, ... of the patch's neighbourhood, 12 words each, taken 64
+    // at a time (lane i holds word wbase + i; the next 64 are already travelling).  Word order = (slot, word) order, so a
+    // wave-wide prefix sum of the popcounts puts the candidates in a fixed order.
+    const int nslots = (nb2 - part + parts - 1) / parts, nwords = nslots * kSlotWords;
+    const uint32_t *mrow0 = masks + ((size_t)nm * pl.slots + pl.sbase[l]) * kSlotWords;      // + patch * nb2 * 12
+    auto word_of = [part, parts, nwords](const uint32_t *mrow, int w) -> uint32_t {         // (value captures; inlined)
+        if (w >= nwords) return 0u;
+        const int s = (w * 683) >> 13, wi = w - s * kSlotWords;                              // w / 12 for w < 2048
+        return mrow[(part + s * parts) * kSlotWords + wi];
+    };
+    // A wave that owns several patches in turn (MULTI; fine levels: a few MFMA steps per patch) already holds the first
+    // 128 mask words of its NEXT patch: without them every patch starts with a load latency nothing else of the wave covers.
+    uint32_t pcur = 0u, pnxt = 0u;
+    if (pi0 < npatch) {
+        const uint32_t *mr = mrow0 + (size_t)pi0 * nb2 * kSlotWords;
+        pcur = word_of(mr, lane); pnxt = word_of(mr, 64 + lane);
+    }
+  for (int rep = 0; rep < reps; ++rep) {
+    const int pi = pi0 + rep;
+    const bool active = pi < npatch;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // channels 0-15 | 16-31 of pixel lane & 15
     const int py = active ? pi / PX : 0, px = active ? pi % PX : 0;
 
     if (active) {
-        const int nbx = pl.nbx[l], nb2 = pl.nby[l] * nbx, invx = pl.invx[l];
         const int oy = nb_origin(l, py, pl.rad[l], pl.nby[l], pl.CY), ox = nb_origin(l, px, pl.rad[l], nbx, pl.CX);
-        const uint32_t *mrow = masks + ((size_t)nm * pl.slots + pl.sbase[l] + (size_t)pi * nb2) * kSlotWords;
-        const float *rbase = recs + ((size_t)nm * kL + l) * (size_t)(pl.CY * pl.CX) * kCellQ * 12;
-        const float Hf = (float)H, Wf = (float)W;
+        const uint32_t *mrow = mrow0 + (size_t)pi * nb2 * kSlotWords;
         const float y0f = (float)(py * 4), x0f = (float)(px * 4);
         const bool border = py * 4 + 3 >= H || px * 4 + 3 >= W;
-        // per-level (start, width) of the query levels, selected per lane below
-        const int st0 = (int)starts[0], st1 = (int)starts[1], st2 = (int)starts[2], st3 = (int)starts[3];
-        const int W0 = pl.W[0], W1 = pl.W[1], W2 = pl.W[2], W3 = pl.W[3];
-        const int kk = lane & 31, half = lane >> 5;
-        const int nq = n * Lq;
-        // transpose-read addresses: lane (p = lane & 15, kg = lane >> 4) supplies row 8 kg + 4 j + (p >> 2), piece p & 3
-        const int p16 = lane & 15, kg = lane >> 4;
-        const unsigned a_rd = lds0 + kOffA + (8 * kg + (p16 >> 2)) * 32 + (p16 & 3) * 8;     // + matrix * 1024 + j * 128
-        const unsigned g_rd = lds0 + kOffG + (8 * kg + (p16 >> 2)) * 64 + (p16 & 3) * 8;     // + tile * 32 + j * 256
-
-        // This wave's mask words: slots part, part + parts, ... of the patch's neighbourhood, 12 words each, taken 64 at
-        // a time (lane i holds word wbase + i; the next 64 are already travelling).  Word order = (slot, word) order, so
-        // a wave-wide prefix sum of the popcounts puts the candidates in a fixed order.
-        const int nslots = (nb2 - part + parts - 1) / parts, nwords = nslots * kSlotWords;
-        auto word_of = [&](int w) -> uint32_t {              // (captures scalars only; inlined)
-            if (w >= nwords) return 0u;
-            const int s = (w * 683) >> 13, wi = w - s * kSlotWords;      // w / 12 for w < 2048
-            return mrow[(part + s * parts) * kSlotWords + wi];
-        };
         int wbase = 0;
-        uint32_t cur = word_of(lane), nxt = word_of(64 + lane);
+        uint32_t cur = pcur, nxt = pnxt;
+        if (rep + 1 < reps && pi + 1 < npatch) {
+            const uint32_t *mr = mrow + (size_t)nb2 * kSlotWords;
+            pcur = word_of(mr, lane); pnxt = word_of(mr, 64 + lane);
+        }
         int head = 0, tail = 0;
         bool exhausted = nwords <= 0;
         int avail_c = 0;                                   // the step whose operands are in flight / in registers
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
                     wbase += 64;
                     if (wbase >= nwords) { exhausted = true; break; }
                     cur = nxt;
-                    nxt = word_of(wbase + 64 + lane);
+                    nxt = word_of(mrow, wbase + 64 + lane);
                     continue;
                 }
                 if (head > 0) {                           // carry the < 32 left-over entries to the front
@@ -554,6 +569,7 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
             store4<OT>(dst + 16, acc1);
         }
     }
+  }   // patches of this wave
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -873,7 +889,10 @@ bool make_patch_plan(const Problem &p, const int64_t *hs, PatchPlan &pl)
         const double steps = (double)p.Lq * 3.5 / ((double)pl.PY[l] * pl.PX[l]) / kStep;
         pl.parts[l] = steps > 16.0 ? 4 : steps > 6.0 ? 2 : 1;
         pl.ibase[l] = items;
-        const int per = kWaves / pl.parts[l];
+        // (experiment, off by default: on the fine levels -- a patch is 2-3 MFMA steps -- a wave takes several patches in
+        //  turn with the mask words of the next one prefetched, instead of 4x as many waves that start with an exposed load)
+        pl.reps[l] = (pl.parts[l] == 1 && steps < 4.0) ? ablation_env("RLIPV2_PATCH_REPS", 1) : 1;
+        const int per = kWaves / pl.parts[l] * pl.reps[l];
         pl.nitems[l] = (pl.PY[l] * pl.PX[l] + per - 1) / per;
         items += pl.nitems[l];
     }
@@ -981,12 +1000,15 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
                            (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);
     const int grid = pl.items * p.N * p.M;
     static const int wps = ablation_env("RLIPV2_PATCH_WPS", 4);
-#define MSDA_PATCH(OT, WPS)                                                                                          \
-    hipLaunchKernelGGL((patch_dest_kernel<OT, WPS>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, pl,   \
+bool multi = false;
+    for (int l = 0; l < kL; ++l) multi = multi || pl.reps[l] > 1;
+#define MSDA_PATCH(OT, WPS, MULTI)                                                                                   \
+    hipLaunchKernelGGL((patch_dest_kernel<OT, WPS, MULTI>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, pl, \
                        p.starts, (const float *)recs, (const bf16_t *)p.grad_out, masks,                            \
                        (const int *)ctl, (OT *)p.g_value, p.N, p.S, p.M, p.Lq, ablation_env("RLIPV2_PATCH_DBG", 0))
-    if (out_bf16) { if (wps == 5) MSDA_PATCH(bf16_t, 5); else MSDA_PATCH(bf16_t, 4); }
-    else { if (wps == 5) MSDA_PATCH(float, 5); else MSDA_PATCH(float, 4); }
+    if (multi) { if (out_bf16) MSDA_PATCH(bf16_t, 4, true); else MSDA_PATCH(float, 4, true); }
+    else if (out_bf16) { if (wps == 5) MSDA_PATCH(bf16_t, 5, false); else MSDA_PATCH(bf16_t, 4, false); }
+    else { if (wps == 5) MSDA_PATCH(float, 5, false); else MSDA_PATCH(float, 4, false); }
 #undef MSDA_PATCH
 }
 

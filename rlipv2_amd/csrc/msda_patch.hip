@@ -655,6 +655,93 @@ __device__ __forceinline__ void cell_sample(const unsigned char *lds, __amdgpu_b
     g_y = Hf * wgt * (hw * (e3 - e1) + lw * (e4 - e2));
 }
 
+// <grad_out, corner row> of THIS lane's corner of a sample whose corner base / validity mask are given (the dot-product
+// half of cell_sample)
+__device__ __forceinline__ float cell_corner_dot(const unsigned char *lds, __amdgpu_buffer_rsrc_t vr, const uint4 (&g)[4],
+                                                 bool staged, int base, int delta, int okmask, int crn, int rot)
+{
+    const bool ok = (okmask >> crn) & 1;
+    uint4 v[4];
+    if (staged) {
+        const int addr = ok ? base + delta : 0;                                  // 0: the zero slot
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const uint4 *>(lds + addr + ((t ^ rot) << 4));
+    } else {
+        const unsigned off = ok ? (unsigned)base + (unsigned)delta : kOobOff;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(vr, off + ((t ^ rot) << 4), 0, 0);
+            v[t] = make_uint4(r.x, r.y, r.z, r.w);
+        }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc = mfma444(g[t].x, g[t].y, v[t].x, v[t].y, acc);
+        acc = mfma444(g[t].z, g[t].w, v[t].z, v[t].w, acc);
+    }
+    return acc[0];
+}
+
+// One level of a task with the sample geometry computed ONCE per quad: quad lane p owns POINT p of the level (the four
+// points in parallel instead of every lane repeating each sample's ~25 geometry instructions), the quad fetches a
+// sample's corner base and validity mask with two DPP moves, lane p keeps the four dots of ITS sample and evaluates the
+// reference's formulas once.  Same arithmetic on the same operands as cell_sample: bit-identical results.
+// `la` / `lb` / `wa`: quad lane 0 holds the level (after the rotations of the level loop).
+__device__ __forceinline__ void cell_level_shared(const unsigned char *lds, __amdgpu_buffer_rsrc_t vr, const uint4 (&g)[4],
+                                                  const float4 &la, const float4 &lb, const float4 &wa, int H, int W, int wx0,
+                                                  int wy0, int pitch, int wbase, unsigned lvl_byte, int row_bytes, int crn,
+                                                  int rot, float4 &ra, float4 &rb, float4 &rw)
+{
+    // this lane's point of the level
+    const float x0 = quad_bcast<0>(la.x), x1 = quad_bcast<0>(la.z), x2 = quad_bcast<0>(lb.x), x3 = quad_bcast<0>(lb.z);
+    const float y0 = quad_bcast<0>(la.y), y1 = quad_bcast<0>(la.w), y2 = quad_bcast<0>(lb.y), y3 = quad_bcast<0>(lb.w);
+    const float w0 = quad_bcast<0>(wa.x), w1 = quad_bcast<0>(wa.y), w2 = quad_bcast<0>(wa.z), w3 = quad_bcast<0>(wa.w);
+    const float x = crn == 0 ? x0 : crn == 1 ? x1 : crn == 2 ? x2 : x3;
+    const float y = crn == 0 ? y0 : crn == 1 ? y1 : crn == 2 ? y2 : y3;
+    const float w = crn == 0 ? w0 : crn == 1 ? w1 : crn == 2 ? w2 : w3;
+    const float Hf = (float)H, Wf = (float)W;
+    const float h_im = fmaf(y, Hf, -0.5f), w_im = fmaf(x, Wf, -0.5f);
+    const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);     // .cuh:285 (NaN -> false)
+    const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;
+    const float hf = floorf(hs), wf = floorf(ws);
+    const float lh = hs - hf, lw = ws - wf, hh = 1.f - lh, hw = 1.f - lw;
+    const int ih = (int)hf, iw = (int)wf;
+    const bool yok0 = inside && (unsigned)ih < (unsigned)H, yok1 = inside && (unsigned)(ih + 1) < (unsigned)H;
+    const bool xok0 = (unsigned)iw < (unsigned)W, xok1 = (unsigned)(iw + 1) < (unsigned)W;
+    const int okmask = (yok0 && xok0 ? 1 : 0) | (yok0 && xok1 ? 2 : 0) | (yok1 && xok0 ? 4 : 0) | (yok1 && xok1 ? 8 : 0);
+    const bool staged = wbase >= 0;                                               // (wave-uniform)
+    // base of the sample's top-left corner (may lie outside the window / level: only valid corners are read) and this
+    // lane's corner offset from it
+    const int base = staged ? wbase + (__mul24(ih - wy0, pitch) + (iw - wx0)) * 64
+                            : (int)(lvl_byte + (unsigned)__mul24(__mul24(ih, W) + iw, row_bytes));
+    const int delta = staged ? ((crn >> 1) * pitch + (crn & 1)) * 64 : ((crn >> 1) * W + (crn & 1)) * row_bytes;
+    float e1 = 0.f, e2 = 0.f, e3 = 0.f, e4 = 0.f;                                 // the dots of THIS lane's sample
+#define MSDA_CELL_SHARED_SAMPLE(S)                                                                                      \
+    {                                                                                                                   \
+        const int b_ = __builtin_amdgcn_update_dpp(0, base, MSDA_QUAD_PERM(S, S, S, S), 0xf, 0xf, true);              \
+        const int m_ = __builtin_amdgcn_update_dpp(0, okmask, MSDA_QUAD_PERM(S, S, S, S), 0xf, 0xf, true);            \
+        const float e = cell_corner_dot(lds, vr, g, staged, b_, delta, m_, crn, rot);                                  \
+        const float d1 = quad_bcast<0>(e), d2 = quad_bcast<1>(e), d3 = quad_bcast<2>(e), d4 = quad_bcast<3>(e);        \
+        const bool mine = crn == S;                                                                                     \
+        e1 = mine ? d1 : e1; e2 = mine ? d2 : e2; e3 = mine ? d3 : e3; e4 = mine ? d4 : e4;                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }
+    MSDA_CELL_SHARED_SAMPLE(0)
+    MSDA_CELL_SHARED_SAMPLE(1)
+    MSDA_CELL_SHARED_SAMPLE(2)
+    MSDA_CELL_SHARED_SAMPLE(3)
+#undef MSDA_CELL_SHARED_SAMPLE
+    const float wgt = inside ? w : 0.f;
+    const float a_ = inside ? hh * (hw * e1 + lw * e2) + lh * (hw * e3 + lw * e4) : 0.f;
+    const float gx = Wf * wgt * (hh * (e2 - e1) + lh * (e4 - e3));
+    const float gy = Hf * wgt * (hw * (e3 - e1) + lw * (e4 - e2));
+    // point p's results live in lane p: the level's vectors for its owner lane
+    ra = make_float4(quad_bcast<0>(gx), quad_bcast<0>(gy), quad_bcast<1>(gx), quad_bcast<1>(gy));
+    rb = make_float4(quad_bcast<2>(gx), quad_bcast<2>(gy), quad_bcast<3>(gx), quad_bcast<3>(gy));
+    rw = make_float4(quad_bcast<0>(a_), quad_bcast<1>(a_), quad_bcast<2>(a_), quad_bcast<3>(a_));
+}
+
 // rotate the quad's per-lane data by one lane: lane j takes lane j + 1's registers, so that after l rotations quad lane 0
 // holds level l (the level loop stays a loop: unrolled over levels and read routes the kernel was 36 KB of code and every
 // phase ran 3-4x slower than its instruction count -- instruction-cache misses between workgroups in different phases)
@@ -664,7 +751,7 @@ __device__ __forceinline__ void quad_rotate4(float4 &v)
     v.x = dpp_quad<R>(v.x); v.y = dpp_quad<R>(v.y); v.z = dpp_quad<R>(v.z); v.w = dpp_quad<R>(v.w);
 }
 
-template <int REFDIM>
+template <int REFDIM, bool SHARED>
 __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
     PatchPlan pl, const bf16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ aw, const bf16_t *__restrict__ grad_out, int N, int S, int M,
@@ -798,6 +885,13 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
             const int pitch = __builtin_amdgcn_readfirstlane(winfo[l][4]), base = __builtin_amdgcn_readfirstlane(winfo[l][5]);
             const unsigned lvl_byte = img_byte + (unsigned)__mul24(__builtin_amdgcn_readfirstlane(winfo[l][6]), row_bytes);
             const bool own = crn == l;
+            if (SHARED) {                        // (experiment, off by default: geometry once per quad)
+                float4 ra, rb, rw;
+                cell_level_shared(clds, vr, g, la, lb, wa, H, W, x0w, y0w, pitch, base, lvl_byte, row_bytes, crn, rot, ra, rb, rw);
+                if (own) { gla = ra; glb = rb; ga = rw; }
+                quad_rotate4(la); quad_rotate4(lb); quad_rotate4(wa);
+                continue;
+            }
             float a_, x_, y_;
             // (a scheduling fence per sample: the compiler otherwise hoists every corner read of the level and spills; pairs
             //  of samples between fences were measured: no faster, scratch in the fused variants)
@@ -962,23 +1056,26 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
     const int lds_bytes = kZeroBytes + kWinBytes + pl.bin_lds;
     const unsigned vbytes = (unsigned)((size_t)p.N * p.S * p.M * kD * 2);
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
-#define MSDA_CELL(RD)                                                                                                 \
+    static const int shared = ablation_env("RLIPV2_CELL_SHARED", 0);
+#define MSDA_CELL_K(RD, SH)                                                                                           \
     do {                                                                                                              \
         static bool attr = false;                                                                                     \
         if (!attr) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)cell_backward_kernel<RD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void *)cell_backward_kernel<RD, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       kZeroBytes + kWinBytes + kCellTableMax);                                        \
             attr = true;                                                                                              \
         }                                                                                                             \
-        hipLaunchKernelGGL((cell_backward_kernel<RD>), grid, block, lds_bytes, p.stream, pl, (const bf16_t *)p.value, \
+        hipLaunchKernelGGL((cell_backward_kernel<RD, SH>), grid, block, lds_bytes, p.stream, pl, (const bf16_t *)p.value, \
                            p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, (const bf16_t *)p.grad_out, \
                            p.N, p.S, p.M, p.Lq, vbytes, (float *)p.g_loc, (float *)p.g_aw, f ? f->ref : nullptr,      \
                            (bf16_t *)(f ? f->g_qproj : nullptr), masks, recs, ctl,                                    \
                            ablation_env("RLIPV2_CELL_DBG", 0));                                                       \
     } while (0)
+#define MSDA_CELL(RD) do { if (shared) MSDA_CELL_K(RD, true); else MSDA_CELL_K(RD, false); } while (0)
     if (!f) MSDA_CELL(0);
     else if (f->refdim == 2) MSDA_CELL(2);
     else MSDA_CELL(4);
+#undef MSDA_CELL_K
 #undef MSDA_CELL
 }
 

@@ -22,7 +22,7 @@ def load_golden(name):
 
 
 MSDA_GOLDEN_CASES = ["testpy_d2", "testpy_d30", "testpy_d32", "testpy_d64", "testpy_d71",
-                     "model_enc", "model_dec"]
+                     "model_enc", "model_dec", "pyr_enc", "pyr_dec"]
 
 
 @pytest.fixture(params=MSDA_GOLDEN_CASES)

@@ -15,6 +15,7 @@ Cases
                (N1 M2 D2 Lq2 L2 P2, shapes (6,4),(3,2), torch.manual_seed(3)), and the same
                recipe with D in {30, 32, 64, 71} (test.py:89-90, the values small enough to
                store).
+* pyr_*      : the same recipe on the pyramid (20,27),(10,14),(5,7),(3,4) of SURVEY 8c
 * model_*    : M8 D32 L4 P4 on a 4-level pyramid, Lq = S ("encoder") and Lq = 50
                ("decoder"), with sampling locations that leave [0,1], sit exactly on pixel
                centres / borders, and hit the -1 / H boundary cases of
@@ -86,10 +87,10 @@ def testpy_case(core, D, tag):
     save_case(core, tag, value, shapes, loc, aw, grad_out)
 
 
-def model_case(core, Lq_mode, tag, seed):
+def model_case(core, Lq_mode, tag, seed, shapes=((10, 14), (5, 7), (3, 4), (2, 2)), N=2):
     rng = np.random.default_rng(seed)
-    N, M, D, L, P = 2, 8, 32, 4, 4
-    shapes = np.array([(10, 14), (5, 7), (3, 4), (2, 2)], dtype=np.int64)
+    M, D, L, P = 8, 32, 4, 4
+    shapes = np.array(shapes, dtype=np.int64)
     S = int((shapes[:, 0] * shapes[:, 1]).sum())
     Lq = S if Lq_mode == "enc" else 50
     value = rng.standard_normal((N, S, M, D)).astype(np.float32)
@@ -114,8 +115,8 @@ def model_case(core, Lq_mode, tag, seed):
         loc[0, 1, 1, l, 1] = (1.0, 1.0)                      # opposite corner
         loc[0, 1, 2, l, 2] = ((W - 0.5) / W, (H - 0.5) / H)  # last pixel centre
         loc[0, 1, 3, l, 3] = (3.0, -2.0)                     # far outside
-        loc[1, 2, 4, l, 0] = (1.0 + 0.49 / W, 0.5)           # w_im just below W
-        loc[1, 2, 5, l, 1] = (0.5, -0.49 / H)                # h_im just above -1
+        loc[N - 1, 2, 4, l, 0] = (1.0 + 0.49 / W, 0.5)       # w_im just below W
+        loc[N - 1, 2, 5, l, 1] = (0.5, -0.49 / H)            # h_im just above -1
     loc = loc.astype(np.float32)
     logits = rng.standard_normal((N, Lq, M, L * P))
     aw = np.exp(logits - logits.max(-1, keepdims=True))
@@ -133,6 +134,11 @@ def main():
         testpy_case(core, D, f"testpy_d{D}")
     model_case(core, "enc", "model_enc", seed=11)
     model_case(core, "dec", "model_dec", seed=12)
+    # the pyramid SURVEY 8c names -- (20,27),(10,14),(5,7),(3,4): 2 x 2 cells of 16 x 16 level-0 pixels, a ragged last
+    # cell row / column on every level; the encoder case with one image to keep the file small
+    pyr = ((20, 27), (10, 14), (5, 7), (3, 4))
+    model_case(core, "enc", "pyr_enc", seed=13, shapes=pyr, N=1)
+    model_case(core, "dec", "pyr_dec", seed=14, shapes=pyr, N=2)
 
 
 if __name__ == "__main__":

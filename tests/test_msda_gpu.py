@@ -136,7 +136,7 @@ def test_golden_f32_all_variants(case):
         close32(gl[keep], g["g_loc_f32"][keep])
 
 
-@pytest.mark.parametrize("case", ["model_enc", "model_dec", "testpy_d32", "testpy_d71"])
+@pytest.mark.parametrize("case", ["model_enc", "model_dec", "pyr_enc", "pyr_dec", "testpy_d32", "testpy_d71"])
 def test_golden_bf16_all_variants(case):
     g = load_golden(case)
     N, S, M, D = g["value"].shape

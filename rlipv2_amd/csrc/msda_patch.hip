@@ -657,7 +657,10 @@ __device__ __forceinline__ void cell_sample(const unsigned char *lds, __amdgpu_b
 
 // <grad_out, corner row> of THIS lane's corner of a sample whose corner base / validity mask are given (the dot-product
 // half of cell_sample)
-__device__ __forceinline__ float cell_corner_dot(const unsigned char *lds, __amdgpu_buffer_rsrc_t vr, const uint4 (&g)[4],
+// SWAP: the value row is the A operand and grad_out the B operand -- D[i][j] = <corner i, grad_out> in EVERY lane j, so
+// the four dots arrive in acc[0..3] of each lane without the four DPP broadcasts (same products, same sums).
+template <bool SWAP>
+__device__ __forceinline__ f32x4 cell_corner_dot(const unsigned char *lds, __amdgpu_buffer_rsrc_t vr, const uint4 (&g)[4],
                                                  bool staged, int base, int delta, int okmask, int crn, int rot)
 {
     const bool ok = (okmask >> crn) & 1;
@@ -677,10 +680,15 @@ __device__ __forceinline__ float cell_corner_dot(const unsigned char *lds, __amd
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        acc = mfma444(g[t].x, g[t].y, v[t].x, v[t].y, acc);
-        acc = mfma444(g[t].z, g[t].w, v[t].z, v[t].w, acc);
+        if (SWAP) {
+            acc = mfma444(v[t].x, v[t].y, g[t].x, g[t].y, acc);
+            acc = mfma444(v[t].z, v[t].w, g[t].z, g[t].w, acc);
+        } else {
+            acc = mfma444(g[t].x, g[t].y, v[t].x, v[t].y, acc);
+            acc = mfma444(g[t].z, g[t].w, v[t].z, v[t].w, acc);
+        }
     }
-    return acc[0];
+    return acc;
 }
 
 // One level of a task with the sample geometry computed ONCE per quad: quad lane p owns POINT p of the level (the four
@@ -688,6 +696,7 @@ __device__ __forceinline__ float cell_corner_dot(const unsigned char *lds, __amd
 // sample's corner base and validity mask with two DPP moves, lane p keeps the four dots of ITS sample and evaluates the
 // reference's formulas once.  Same arithmetic on the same operands as cell_sample: bit-identical results.
 // `la` / `lb` / `wa`: quad lane 0 holds the level (after the rotations of the level loop).
+template <bool SWAP>
 __device__ __forceinline__ void cell_level_shared(const unsigned char *lds, __amdgpu_buffer_rsrc_t vr, const uint4 (&g)[4],
                                                   const float4 &la, const float4 &lb, const float4 &wa, int H, int W, int wx0,
                                                   int wy0, int pitch, int wbase, unsigned lvl_byte, int row_bytes, int crn,
@@ -721,8 +730,9 @@ __device__ __forceinline__ void cell_level_shared(const unsigned char *lds, __am
     {                                                                                                                   \
         const int b_ = __builtin_amdgcn_update_dpp(0, base, MSDA_QUAD_PERM(S, S, S, S), 0xf, 0xf, true);              \
         const int m_ = __builtin_amdgcn_update_dpp(0, okmask, MSDA_QUAD_PERM(S, S, S, S), 0xf, 0xf, true);            \
-        const float e = cell_corner_dot(lds, vr, g, staged, b_, delta, m_, crn, rot);                                  \
-        const float d1 = quad_bcast<0>(e), d2 = quad_bcast<1>(e), d3 = quad_bcast<2>(e), d4 = quad_bcast<3>(e);        \
+        const f32x4 e = cell_corner_dot<SWAP>(lds, vr, g, staged, b_, delta, m_, crn, rot);                            \
+        const float d1 = SWAP ? e[0] : quad_bcast<0>(e[0]), d2 = SWAP ? e[1] : quad_bcast<1>(e[0]);                    \
+        const float d3 = SWAP ? e[2] : quad_bcast<2>(e[0]), d4 = SWAP ? e[3] : quad_bcast<3>(e[0]);                    \
         const bool mine = crn == S;                                                                                     \
         e1 = mine ? d1 : e1; e2 = mine ? d2 : e2; e3 = mine ? d3 : e3; e4 = mine ? d4 : e4;                             \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
@@ -751,7 +761,9 @@ __device__ __forceinline__ void quad_rotate4(float4 &v)
     v.x = dpp_quad<R>(v.x); v.y = dpp_quad<R>(v.y); v.z = dpp_quad<R>(v.z); v.w = dpp_quad<R>(v.w);
 }
 
-template <int REFDIM, bool SHARED>
+// MODE (experiments, ablation build only): 0 = the product kernel, 1 = sample geometry once per quad
+// (cell_level_shared), 2 = that + the operand swap of cell_corner_dot
+template <int REFDIM, int MODE>
 __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
     PatchPlan pl, const bf16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ aw, const bf16_t *__restrict__ grad_out, int N, int S, int M,
@@ -885,9 +897,9 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
             const int pitch = __builtin_amdgcn_readfirstlane(winfo[l][4]), base = __builtin_amdgcn_readfirstlane(winfo[l][5]);
             const unsigned lvl_byte = img_byte + (unsigned)__mul24(__builtin_amdgcn_readfirstlane(winfo[l][6]), row_bytes);
             const bool own = crn == l;
-            if (SHARED) {                        // (experiment, off by default: geometry once per quad)
+            if (MODE != 0) {                     // (experiment, off by default: geometry once per quad)
                 float4 ra, rb, rw;
-                cell_level_shared(clds, vr, g, la, lb, wa, H, W, x0w, y0w, pitch, base, lvl_byte, row_bytes, crn, rot, ra, rb, rw);
+                cell_level_shared<MODE == 2>(clds, vr, g, la, lb, wa, H, W, x0w, y0w, pitch, base, lvl_byte, row_bytes, crn, rot, ra, rb, rw);
                 if (own) { gla = ra; glb = rb; ga = rw; }
                 quad_rotate4(la); quad_rotate4(lb); quad_rotate4(wa);
                 continue;
@@ -1056,22 +1068,30 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
     const int lds_bytes = kZeroBytes + kWinBytes + pl.bin_lds;
     const unsigned vbytes = (unsigned)((size_t)p.N * p.S * p.M * kD * 2);
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
-    static const int shared = ablation_env("RLIPV2_CELL_SHARED", 0);
-#define MSDA_CELL_K(RD, SH)                                                                                           \
+    static const int mode = ablation_env("RLIPV2_CELL_SHARED", 0);
+#define MSDA_CELL_K(RD, MODE)                                                                                         \
     do {                                                                                                              \
         static bool attr = false;                                                                                     \
         if (!attr) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)cell_backward_kernel<RD, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void *)cell_backward_kernel<RD, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       kZeroBytes + kWinBytes + kCellTableMax);                                        \
             attr = true;                                                                                              \
         }                                                                                                             \
-        hipLaunchKernelGGL((cell_backward_kernel<RD, SH>), grid, block, lds_bytes, p.stream, pl, (const bf16_t *)p.value, \
+        hipLaunchKernelGGL((cell_backward_kernel<RD, MODE>), grid, block, lds_bytes, p.stream, pl, (const bf16_t *)p.value, \
                            p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, (const bf16_t *)p.grad_out, \
                            p.N, p.S, p.M, p.Lq, vbytes, (float *)p.g_loc, (float *)p.g_aw, f ? f->ref : nullptr,      \
                            (bf16_t *)(f ? f->g_qproj : nullptr), masks, recs, ctl,                                    \
                            ablation_env("RLIPV2_CELL_DBG", 0));                                                       \
     } while (0)
-#define MSDA_CELL(RD) do { if (shared) MSDA_CELL_K(RD, true); else MSDA_CELL_K(RD, false); } while (0)
+#ifdef MSDA_ABLATION
+#define MSDA_CELL(RD)                                                                                                 \
+    do {                                                                                                              \
+        if (mode == 1) MSDA_CELL_K(RD, 1); else if (mode == 2) MSDA_CELL_K(RD, 2); else MSDA_CELL_K(RD, 0);           \
+    } while (0)
+#else
+#define MSDA_CELL(RD) MSDA_CELL_K(RD, 0)
+#endif
+    (void)mode;
     if (!f) MSDA_CELL(0);
     else if (f->refdim == 2) MSDA_CELL(2);
     else MSDA_CELL(4);

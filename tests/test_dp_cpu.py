@@ -219,3 +219,53 @@ def test_bucketed_overlapped_all_reduce_two_ranks(tmp_path, wide):
     gmax = max(float(v.abs().max()) for v in ref.values())
     worst = max(float((ref[n] - dp[n]).abs().max()) / max(1e-3 * gmax, float(ref[n].abs().max())) for n in ref)
     assert worst < 2e-3, worst
+
+
+def _agree_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rlipv2_amd import train
+        net = torch.nn.Linear(6, 3)
+        sync = train.GradientSynchronizer(list(net.parameters()))
+        cache = train.GraphedStepCache(None, None, synchronizer=sync)
+        res = {}
+        for name, hit in (("all_hit", True), ("all_miss", False), ("mixed", rank == 0)):
+            try:
+                cache._agree(hit)
+                res[name] = "ok"
+            except RuntimeError as e:
+                res[name] = "raised: " + str(e)[:60]
+        # the SUM route of the fused optimiser: the buffer keeps the sum, the factor is handed over
+        sync.scale_in_optimizer = True
+        g = torch.Generator().manual_seed(3 + rank)
+        grads = [torch.randn(p.shape, generator=g) for p in net.parameters()]
+        views = sync(grads)
+        res["sum"] = ([v.clone() for v in views], [x.clone() for x in grads], sync.grad_scale)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capture_decision_is_collective_and_sum_route_two_ranks():
+    """GraphedStepCache._agree: all ranks hit -> replay, all miss -> capture together, mixed -> every rank raises (instead
+    of one rank capturing -- collectives of its own -- while the other replays: a hang).  GradientSynchronizer with
+    scale_in_optimizer: the flat buffer holds the SUM over ranks and grad_scale = 1 / world goes to the optimiser."""
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 400) + 61
+    shared = mp.Manager().dict()
+    procs = [mp.Process(target=_agree_worker, args=(r, 2, port, shared)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert shared[r]["all_hit"] == "ok" and shared[r]["all_miss"] == "ok"
+        assert shared[r]["mixed"].startswith("raised: GraphedStepCache"), shared[r]["mixed"]
+    (v0, g0, s0), (v1, g1, s1) = shared[0]["sum"], shared[1]["sum"]
+    assert s0 == s1 == 0.5
+    for a, b, x, y in zip(v0, v1, g0, g1):
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a, x + y)

@@ -113,7 +113,10 @@ __device__ __forceinline__ TableLayout table_layout(const int (*rng)[4])
 }
 
 // BBOX: also the bounding box of every in-level corner per sampled level: box[l] = {x0, y0, -x1, -y1} (LDS, via min)
-template <int THREADS, bool BBOX>
+// SCALAR_STARTS (experiment): level_start_index read as four scalars and selected per lane -- `starts[lq]` with a per-lane
+// lq is a vector load whose result the NEXT load's address needs: the "loads up front" below were in fact chained by up to
+// four full memory latencies (s_waitcnt vmcnt(0) before the dependent address, visible in the device assembly).
+template <int THREADS, bool BBOX, bool SCALAR_STARTS = false>
 __device__ __forceinline__ void bin_cell(const PatchPlan &pl, const int64_t *__restrict__ starts,
                                          const float *__restrict__ loc, const float *__restrict__ aw, int n, int m, int c,
                                          int M, int Lq, uint32_t *tab, int (*rng)[4], int (*box)[4],
@@ -156,6 +159,11 @@ __device__ __forceinline__ void bin_cell(const PatchPlan &pl, const int64_t *__r
     // All of the thread's loads first (every pass of a plain loop waited 3-4 us for its 24 bytes: cycle stamps in
     // tools/cell_timeline.py), then the arithmetic and the LDS ORs.
     constexpr int IT = (kCellQ * 8 + THREADS - 1) / THREADS;
+    // (readfirstlane: opaque scalars -- the compiler otherwise folds the select chain back into the indexed vector load)
+    const int sst0 = SCALAR_STARTS ? __builtin_amdgcn_readfirstlane((int)starts[0]) : 0;
+    const int sst1 = SCALAR_STARTS ? __builtin_amdgcn_readfirstlane((int)starts[1]) : 0;
+    const int sst2 = SCALAR_STARTS ? __builtin_amdgcn_readfirstlane((int)starts[2]) : 0;
+    const int sst3 = SCALAR_STARTS ? __builtin_amdgcn_readfirstlane((int)starts[3]) : 0;
     float4 vv[IT];
     float2 av[IT];
     bool have[IT];
@@ -169,7 +177,8 @@ __device__ __forceinline__ void bin_cell(const PatchPlan &pl, const int64_t *__r
         const int Hq = lq == 0 ? pl.H[0] : lq == 1 ? pl.H[1] : lq == 2 ? pl.H[2] : pl.H[3];
         const int Wq = lq == 0 ? pl.W[0] : lq == 1 ? pl.W[1] : lq == 2 ? pl.W[2] : pl.W[3];
         have[it] = j < kCellQ && iy < Hq && ix < Wq;
-        const int q = have[it] ? (int)starts[lq] + iy * Wq + ix : 0;
+        const int stq = !SCALAR_STARTS ? (int)starts[lq] : lq == 0 ? sst0 : lq == 1 ? sst1 : lq == 2 ? sst2 : sst3;
+        const int q = have[it] ? stq + iy * Wq + ix : 0;
         const long qm = ((long)n * Lq + q) * M + m;
         vv[it] = reinterpret_cast<const float4 *>(loc)[qm * 8 + chunk];
         av[it] = reinterpret_cast<const float2 *>(aw)[qm * 8 + chunk];
@@ -406,8 +415,19 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
                 if (__builtin_amdgcn_ballot_w64(cur != 0u) == 0ull) {
                     wbase += 64;
                     if (wbase >= nwords) { exhausted = true; break; }
-                    cur = nxt;
-                    nxt = word_of(mrow, wbase + 64 + lane);
+                    if (MULTI) {
+                        // (experiment) the load NOT in a branch: the plain form below merges `0` and the loaded word in a
+                        // phi, and the compiler waits for the load right where it is issued (s_waitcnt vmcnt(0) + v_mov in
+                        // the device assembly) -- one exposed memory latency per 64 mask words instead of a prefetch.
+                        // Clamped address, the words beyond the end masked when they become `cur`.
+                        cur = (wbase + lane < nwords) ? nxt : 0u;
+                        const int wn = min(wbase + 64 + lane, nwords - 1);
+                        const int sn = (wn * 683) >> 13;
+                        nxt = mrow[(part + sn * parts) * kSlotWords + (wn - sn * kSlotWords)];
+                    } else {
+                        cur = nxt;
+                        nxt = word_of(mrow, wbase + 64 + lane);
+                    }
                     continue;
                 }
                 if (head > 0) {                           // carry the < 32 left-over entries to the front
@@ -762,7 +782,8 @@ __device__ __forceinline__ void quad_rotate4(float4 &v)
 }
 
 // MODE (experiments, ablation build only): 0 = the product kernel, 1 = sample geometry once per quad
-// (cell_level_shared), 2 = that + the operand swap of cell_corner_dot
+// (cell_level_shared), 2 = that + the operand swap of cell_corner_dot, 3 = that + the window copies issued up front
+// + level starts as scalars in the binning
 template <int REFDIM, int MODE>
 __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
     PatchPlan pl, const bf16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
@@ -793,7 +814,7 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
     (void)ts_last;
 
     // ---- phase 1: masks, records, bounding boxes -----------------------------------------------------------------------
-    bin_cell<kCellThreads, true>(pl, starts, loc, aw, n, m, c, M, Lq, tab, rng, box, recs, ctl, dbg);
+    bin_cell<kCellThreads, true, (MODE >= 3)>(pl, starts, loc, aw, n, m, c, M, Lq, tab, rng, box, recs, ctl, dbg);
     CTS(0);
     {
         const TableLayout tl = table_layout(rng);
@@ -845,6 +866,46 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
             winfo[l][4] = wpitch[l]; winfo[l][5] = wbase[l]; winfo[l][6] = (int)starts[l]; winfo[l][7] = 0;
         }
     }
+    if (MODE >= 3) {
+        // (experiment) every copy of the thread, all levels, issued before the first LDS store: the loop below waits a
+        // full memory latency per pass (6 passes for a full 48 KB window: the 13-15 k cycles of the timeline)
+        int cnt[kL + 1];
+        cnt[0] = 0;
+#pragma unroll
+        for (int l = 0; l < kL; ++l) cnt[l + 1] = cnt[l] + (wbase[l] >= 0 ? wrows[l] * wcols[l] * 4 : 0);
+        constexpr int IT = kMaxWinPx * 4 / kCellThreads;               // pieces per thread when the budget is full
+        static_assert(IT * kCellThreads == kMaxWinPx * 4, "staging passes");
+        static_assert(IT == 6, "the copies below are written out six times");
+        const int total = cnt[kL];
+        // (index clamped instead of a branch around the load -- an empty cell reads pixel (0, 0) of its level for nothing --
+        //  so that the six loads stay back to back; the stores are predicated)
+        auto piece_of = [&](int k, int &dst) -> const uint4 * {
+            const int i = min(tid + k * kCellThreads, max(total - 1, 0));
+            const int l = (i >= cnt[1] ? 1 : 0) + (i >= cnt[2] ? 1 : 0) + (i >= cnt[3] ? 1 : 0);
+            auto sel = [l](int a0, int a1, int a2, int a3) { return l == 0 ? a0 : l == 1 ? a1 : l == 2 ? a2 : a3; };
+            const int local = i - sel(cnt[0], cnt[1], cnt[2], cnt[3]);
+            const int cols = max(sel(wcols[0], wcols[1], wcols[2], wcols[3]), 1);
+            const int pix = local >> 2, piece = local & 3;
+            const int wy = (int)(((float)pix + 0.5f) * (1.f / (float)cols)), wx = pix - wy * cols;
+            const int W = sel(pl.W[0], pl.W[1], pl.W[2], pl.W[3]);
+            const int start = sel((int)starts[0], (int)starts[1], (int)starts[2], (int)starts[3]);
+            const int gy = sel(wy0[0], wy0[1], wy0[2], wy0[3]) + wy, gx = sel(wx0[0], wx0[1], wx0[2], wx0[3]) + wx;
+            const size_t src = (size_t)img_byte + (size_t)(start + gy * W + gx) * row_bytes + piece * 16;
+            dst = max(sel(wbase[0], wbase[1], wbase[2], wbase[3]), 0) +
+                  (wy * sel(wpitch[0], wpitch[1], wpitch[2], wpitch[3]) + wx) * 64 + piece * 16;
+            return reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(value) + src);
+        };
+        int d0, d1, d2, d3, d4, d5;
+        const uint4 *s0 = piece_of(0, d0), *s1 = piece_of(1, d1), *s2 = piece_of(2, d2);
+        const uint4 *s3 = piece_of(3, d3), *s4 = piece_of(4, d4), *s5 = piece_of(5, d5);
+        const uint4 v0 = *s0, v1 = *s1, v2 = *s2, v3 = *s3, v4 = *s4, v5 = *s5;
+        if (tid < total) *reinterpret_cast<uint4 *>(clds + d0) = v0;
+        if (tid + kCellThreads < total) *reinterpret_cast<uint4 *>(clds + d1) = v1;
+        if (tid + 2 * kCellThreads < total) *reinterpret_cast<uint4 *>(clds + d2) = v2;
+        if (tid + 3 * kCellThreads < total) *reinterpret_cast<uint4 *>(clds + d3) = v3;
+        if (tid + 4 * kCellThreads < total) *reinterpret_cast<uint4 *>(clds + d4) = v4;
+        if (tid + 5 * kCellThreads < total) *reinterpret_cast<uint4 *>(clds + d5) = v5;
+    } else
 #pragma unroll
     for (int l = 0; l < kL; ++l) {
         if (wbase[l] < 0 || wcols[l] == 0) continue;
@@ -875,7 +936,10 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
         const int iy = (cy << sh) + (r >> sh), ix = (cx << sh) + (r & ((1 << sh) - 1));
         const int Hq = lq == 0 ? pl.H[0] : lq == 1 ? pl.H[1] : lq == 2 ? pl.H[2] : pl.H[3];
         const int Wq = lq == 0 ? pl.W[0] : lq == 1 ? pl.W[1] : lq == 2 ? pl.W[2] : pl.W[3];
-        const int stq = lq == 0 ? (int)starts[0] : lq == 1 ? (int)starts[1] : lq == 2 ? (int)starts[2] : (int)starts[3];
+        // (MODE >= 3: from LDS -- the compiler folds the plain select chain into the vector load starts[lq], whose
+        //  latency then sits IN FRONT of the task's operand loads: two memory round trips per task instead of one)
+        const int stq = MODE >= 3 ? winfo[lq][6]      // (the level starts are in LDS for the level loop anyway)
+                      : lq == 0 ? (int)starts[0] : lq == 1 ? (int)starts[1] : lq == 2 ? (int)starts[2] : (int)starts[3];
         const bool live = j < kCellQ && iy < Hq && ix < Wq;          // (a quad is live or dead as a whole)
         const int q = live ? stq + iy * Wq + ix : 0;
         const long qm = ((long)n * Lq + q) * M + m;
@@ -899,7 +963,7 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
             const bool own = crn == l;
             if (MODE != 0) {                     // (experiment, off by default: geometry once per quad)
                 float4 ra, rb, rw;
-                cell_level_shared<MODE == 2>(clds, vr, g, la, lb, wa, H, W, x0w, y0w, pitch, base, lvl_byte, row_bytes, crn, rot, ra, rb, rw);
+                cell_level_shared<MODE >= 2>(clds, vr, g, la, lb, wa, H, W, x0w, y0w, pitch, base, lvl_byte, row_bytes, crn, rot, ra, rb, rw);
                 if (own) { gla = ra; glb = rb; ga = rw; }
                 quad_rotate4(la); quad_rotate4(lb); quad_rotate4(wa);
                 continue;
@@ -1086,7 +1150,8 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
 #ifdef MSDA_ABLATION
 #define MSDA_CELL(RD)                                                                                                 \
     do {                                                                                                              \
-        if (mode == 1) MSDA_CELL_K(RD, 1); else if (mode == 2) MSDA_CELL_K(RD, 2); else MSDA_CELL_K(RD, 0);           \
+        if (mode == 1) MSDA_CELL_K(RD, 1); else if (mode == 2) MSDA_CELL_K(RD, 2);                                    \
+        else if (mode == 3) MSDA_CELL_K(RD, 3); else MSDA_CELL_K(RD, 0);                                              \
     } while (0)
 #else
 #define MSDA_CELL(RD) MSDA_CELL_K(RD, 0)
@@ -1117,7 +1182,7 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
                            (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);
     const int grid = pl.items * p.N * p.M;
     static const int wps = ablation_env("RLIPV2_PATCH_WPS", 4);
-bool multi = false;
+bool multi = ablation_env("RLIPV2_PATCH_MULTI", 0) != 0;      // (the experimental instantiation, also with 1 patch per wave)
     for (int l = 0; l < kL; ++l) multi = multi || pl.reps[l] > 1;
 #define MSDA_PATCH(OT, WPS, MULTI)                                                                                   \
     hipLaunchKernelGGL((patch_dest_kernel<OT, WPS, MULTI>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, pl, \

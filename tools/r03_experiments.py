@@ -1,6 +1,8 @@
 """The default-off experiments of round 3, one A/B table (ablation build: the switches are read there only):
-    RLIPV2_CELL_SHARED = 1 | 2   cell_backward_kernel: sample geometry once per quad | + operand swap of the dot MFMAs
-    RLIPV2_PATCH_REPS  = 2..8    patch_dest_kernel: patches per wave on the fine levels
+    RLIPV2_CELL_SHARED = 1 | 2 | 3  cell_backward_kernel: sample geometry once per quad | + operand swap of the dot MFMAs |
+                                    + level starts not through a dependent vector load, window copies issued up front
+    RLIPV2_PATCH_MULTI = 1          patch_dest_kernel: the experimental instantiation (mask-word prefetch not in a branch)
+    RLIPV2_PATCH_REPS  = 2..8       that + several patches per wave on the fine levels
 Every arm must reproduce the default's three gradients bit for bit (B0 signature and fused geometry); the whole backward
 is timed with HIP events.
     make -C rlipv2_amd/csrc ablation && RLIPV2_LIB_PATH=$PWD/tools/_build/librlipv2_msda_ablation.so python tools/r03_experiments.py
@@ -15,12 +17,15 @@ from rlipv2_amd import msda  # noqa: E402
 from tools.msda_inputs import PYRAMID_800x1333, make_inputs  # noqa: E402
 from tools.patch_check import timed  # noqa: E402
 
-ARMS = [("default", {}), ("shared", {"RLIPV2_CELL_SHARED": "1"}), ("shared+swap", {"RLIPV2_CELL_SHARED": "2"}),
-        ("reps2", {"RLIPV2_PATCH_REPS": "2"}), ("reps3", {"RLIPV2_PATCH_REPS": "3"}), ("reps4", {"RLIPV2_PATCH_REPS": "4"}),
-        ("reps8", {"RLIPV2_PATCH_REPS": "8"}),
-        ("shared+swap, reps2", {"RLIPV2_CELL_SHARED": "2", "RLIPV2_PATCH_REPS": "2"}),
-        ("shared+swap, reps4", {"RLIPV2_CELL_SHARED": "2", "RLIPV2_PATCH_REPS": "4"})]
-KEYS = ("RLIPV2_CELL_SHARED", "RLIPV2_PATCH_REPS")
+ARMS = [("default", {}), ("cell 1 shared", {"RLIPV2_CELL_SHARED": "1"}), ("cell 2 +swap", {"RLIPV2_CELL_SHARED": "2"}),
+        ("cell 3 +loads", {"RLIPV2_CELL_SHARED": "3"}),
+        ("patch multi1", {"RLIPV2_PATCH_MULTI": "1"}),
+        ("patch reps2", {"RLIPV2_PATCH_REPS": "2"}), ("patch reps3", {"RLIPV2_PATCH_REPS": "3"}),
+        ("patch reps4", {"RLIPV2_PATCH_REPS": "4"}), ("patch reps8", {"RLIPV2_PATCH_REPS": "8"}),
+        ("cell 3, multi1", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_MULTI": "1"}),
+        ("cell 3, reps2", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_REPS": "2"}),
+        ("cell 3, reps4", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_REPS": "4"})]
+KEYS = ("RLIPV2_CELL_SHARED", "RLIPV2_PATCH_REPS", "RLIPV2_PATCH_MULTI")
 
 
 def set_arm(env):
@@ -73,7 +78,7 @@ def main():
     for arm, (name, env) in enumerate(ARMS):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), str(arm)], capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
-            print(f"{name:22s} FAILED rc={r.returncode}: {r.stderr[-400:]}", flush=True)
+            print(f"{name:16s} FAILED rc={r.returncode}: {r.stderr[-400:]}", flush=True)
             continue
         out = torch.load(f"/tmp/r03_arm_{arm}.pt")
         if base is None:
@@ -82,7 +87,7 @@ def main():
             same = all(torch.equal(x, y) for x, y in zip(res, base[case][0]))
             finite = all(bool(torch.isfinite(x).all()) for x in res)
             worst = max(float((x - y).abs().max() / y.abs().max().clamp_min(1e-30)) for x, y in zip(res, base[case][0]))
-            print(f"{name:22s} {case:18s} {t:8.1f} us (default {base[case][1]:8.1f})  equal bits {same}  finite {finite}  "
+            print(f"{name:16s} {case:18s} {t:8.1f} us (default {base[case][1]:8.1f})  equal bits {same}  finite {finite}  "
                   f"max rel diff {worst:.2e}", flush=True)
 
 

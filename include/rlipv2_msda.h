@@ -133,6 +133,16 @@ int msda_backward_ex(int variant, int dtype,
  * concurrent calls on different streams need different workspaces. */
 size_t msda_backward_workspace_bytes(int dtype, const int64_t *spatial_shapes_host,
                                      int N, int S, int M, int D, int L, int Lq, int P);
+/* Diagnostics (host only, no device work): the launch plan of the encoder backward's cell + patch route for a pyramid
+ * -- for every level H, W, patches (rows, columns), neighbourhood radius and extent in cells, reciprocal of the extent,
+ * first mask slot, waves per patch, patches per wave, first workgroup item and item count; then cells (rows, columns),
+ * mask slots per (image, head), items per (image, head), bytes of the binning table.  `out` receives
+ * 4 * MSDA_PLAN_LEVEL_FIELDS + MSDA_PLAN_TAIL_FIELDS int32 values, level-major.  Returns the count written, 0 when the
+ * problem does not take that route (then msda_backward_ws uses the sorting pass), -1 when out_len is too small. */
+#define MSDA_PLAN_LEVEL_FIELDS 14
+#define MSDA_PLAN_TAIL_FIELDS 5
+int msda_backward_plan_info(int dtype, const int64_t *spatial_shapes_host,
+                            int N, int S, int M, int D, int L, int Lq, int P, int32_t *out, int out_len);
 int msda_backward_ws(int variant, int dtype,
                      const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
                      const int64_t *spatial_shapes_host,

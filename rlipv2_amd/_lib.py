@@ -24,6 +24,7 @@ EXPORTS = (
     "msda_forward", "msda_backward", "msda_forward_ex", "msda_backward_ex", "msda_check_im2col_step",
     "msda_algorithmic_bytes", "msda_strerror", "msda_abi_version", "msda_variant_name", "msda_pick_variant",
     "msda_prepare_forward", "msda_prepare_backward", "msda_backward_workspace_bytes", "msda_backward_ws",
+    "msda_backward_plan_info",
     "msda_fused_supported", "msda_fused_forward", "msda_fused_backward_ws",
     # include/rlipv2_linear.h
     "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
@@ -77,6 +78,8 @@ def lib() -> ctypes.CDLL:
     L.msda_backward_ex.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp]
     L.msda_backward_workspace_bytes.argtypes = [i, vp, *dims]
     L.msda_backward_workspace_bytes.restype = ctypes.c_size_t
+    L.msda_backward_plan_info.argtypes = [i, vp, *dims, vp, i]
+    L.msda_backward_plan_info.restype = i
     L.msda_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.msda_backward_ws.restype = i
     for f in (L.msda_forward, L.msda_backward, L.msda_forward_ex, L.msda_backward_ex):

@@ -222,6 +222,17 @@ size_t msda_backward_workspace_bytes(int dtype, const int64_t *spatial_shapes_ho
     return dest_workspace_bytes(p, spatial_shapes_host);
 }
 
+int msda_backward_plan_info(int dtype, const int64_t *spatial_shapes_host, int N, int S, int M, int D, int L, int Lq, int P,
+                            int32_t *out, int out_len)
+{
+    static_assert(MSDA_PLAN_LEVEL_FIELDS == 14 && MSDA_PLAN_TAIL_FIELDS == 5, "plan layout of patch_plan_info");
+    if (validate(dtype, N, S, M, D, L, Lq, P) != MSDA_OK || !spatial_shapes_host) return 0;
+    if ((long)N * S * M * D == 0 || (long)N * Lq * M * L * P == 0) return 0;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    return patch_plan_info(p, spatial_shapes_host, out, out_len);
+}
+
 int msda_backward_ws(int variant, int dtype, const void *value, const int64_t *spatial_shapes,
                      const int64_t *level_start, const int64_t *spatial_shapes_host, const void *sampling_loc,
                      const void *attn_weight, const void *grad_out, int N, int S, int M, int D, int L, int Lq, int P,

@@ -86,6 +86,8 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
 // ... preceded by cell_backward_kernel: K1's work (grad_sampling_loc / grad_attn_weight, or with `f` the projection row's
 // gradient) from LDS-resident value windows on v_mfma_f32_4x4x4_16B_bf16, plus the binning for the patch pass
 bool cell_backward_supports(const Problem &p, const int64_t *shapes_host);
+// the plan of the cell + patch route as int32 values (include/rlipv2_msda.h: msda_backward_plan_info); 0 = route not taken
+int patch_plan_info(const Problem &p, const int64_t *shapes_host, int32_t *out, int out_len);
 void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, int *ctl, void *mask_ws);
 // few queries (decoders): one workgroup per (image, head, level), records sorted by pixel in LDS (msda_sparse.hip)
 bool sparse_dest_supports(const Problem &p, const int64_t *shapes_host);

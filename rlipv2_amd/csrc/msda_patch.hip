@@ -1114,6 +1114,22 @@ size_t patch_workspace_bytes(const Problem &p, const int64_t *shapes_host)
     return mask_bytes(p, pl) + rec_bytes(p, pl);
 }
 
+int patch_plan_info(const Problem &p, const int64_t *shapes_host, int32_t *out, int out_len)
+{
+    PatchPlan pl;
+    if (!patch_supports(p, shapes_host) || !make_patch_plan(p, shapes_host, pl)) return 0;
+    constexpr int kFields = 14, kTail = 5;
+    if (!out || out_len < kL * kFields + kTail) return -1;
+    for (int l = 0; l < kL; ++l) {
+        const int v[kFields] = {pl.H[l], pl.W[l], pl.PY[l], pl.PX[l], pl.rad[l], pl.nby[l], pl.nbx[l], pl.invx[l],
+                                pl.sbase[l], pl.parts[l], pl.reps[l], pl.ibase[l], pl.nitems[l], 16 >> l};
+        for (int k = 0; k < kFields; ++k) out[l * kFields + k] = v[k];
+    }
+    int32_t *t = out + kL * kFields;
+    t[0] = pl.CY; t[1] = pl.CX; t[2] = pl.slots; t[3] = pl.items; t[4] = pl.bin_lds;
+    return kL * kFields + kTail;
+}
+
 bool cell_backward_supports(const Problem &p, const int64_t *shapes_host)
 {
     PatchPlan pl;

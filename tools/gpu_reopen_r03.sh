@@ -1,0 +1,13 @@
+#!/bin/bash
+# First call after the GPU pool reopens (round 3): the GPU test suite on the product library, the A/B table of the
+# default-off experiment arms (ablation build; every arm must reproduce the default's gradients bit for bit), one bench line.
+#   gpurun --timeout 2400 -- 'bash tools/gpu_reopen_r03.sh'
+OUT=$GRAFT_REPO_ROOT/gpurun_out/reopen_r03
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+( timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt )
+tail -5 $OUT/pytest_gpu.txt
+( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; timeout 900 python tools/r03_experiments.py > $OUT/experiments.txt 2>&1 )
+cat $OUT/experiments.txt
+timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
+tail -c 1500 $OUT/bench_line.json

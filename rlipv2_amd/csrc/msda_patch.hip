@@ -611,6 +611,11 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
 //     corner j's 4 channels, A rows = the query's grad_out channels -> D[., j] = <grad_out, corner j> after 8
 //     instructions per sample, exact products, float32 accumulation, no unpacking and no cross-lane reduction.
 // ------------------------------------------------------------------------------------------------------------------
+// What the product build runs (the other modes / instantiations are the measured arms of tools/r03_experiments.py; they
+// become the default here, in one place, once a GPU run has shown them bit-identical and faster):
+constexpr int kCellMode = 0;                  // cell_backward_kernel<., MODE>
+constexpr int kPatchMulti = 0;                // patch_dest_kernel<., ., MULTI>
+constexpr int kPatchReps = 1;                 // patches per wave on the fine levels (MULTI only)
 constexpr int kCellThreads = 512;
 constexpr int kWinBytes = 48 * 1024;          // LDS window budget (all levels together)
 constexpr int kZeroBytes = 128;               // zeros in front of the windows: where out-of-level corners read
@@ -1061,7 +1066,7 @@ bool make_patch_plan(const Problem &p, const int64_t *hs, PatchPlan &pl)
         pl.ibase[l] = items;
         // (experiment, off by default: on the fine levels -- a patch is 2-3 MFMA steps -- a wave takes several patches in
         //  turn with the mask words of the next one prefetched, instead of 4x as many waves that start with an exposed load)
-        pl.reps[l] = (pl.parts[l] == 1 && steps < 4.0) ? ablation_env("RLIPV2_PATCH_REPS", 1) : 1;
+        pl.reps[l] = (pl.parts[l] == 1 && steps < 4.0) ? ablation_env("RLIPV2_PATCH_REPS", kPatchReps) : 1;
         const int per = kWaves / pl.parts[l] * pl.reps[l];
         pl.nitems[l] = (pl.PY[l] * pl.PX[l] + per - 1) / per;
         items += pl.nitems[l];
@@ -1148,7 +1153,7 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
     const int lds_bytes = kZeroBytes + kWinBytes + pl.bin_lds;
     const unsigned vbytes = (unsigned)((size_t)p.N * p.S * p.M * kD * 2);
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
-    static const int mode = ablation_env("RLIPV2_CELL_SHARED", 0);
+    static const int mode = ablation_env("RLIPV2_CELL_SHARED", kCellMode);
 #define MSDA_CELL_K(RD, MODE)                                                                                         \
     do {                                                                                                              \
         static bool attr = false;                                                                                     \
@@ -1170,7 +1175,7 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
         else if (mode == 3) MSDA_CELL_K(RD, 3); else MSDA_CELL_K(RD, 0);                                              \
     } while (0)
 #else
-#define MSDA_CELL(RD) MSDA_CELL_K(RD, 0)
+#define MSDA_CELL(RD) MSDA_CELL_K(RD, kCellMode)
 #endif
     (void)mode;
     if (!f) MSDA_CELL(0);
@@ -1198,7 +1203,7 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
                            (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);
     const int grid = pl.items * p.N * p.M;
     static const int wps = ablation_env("RLIPV2_PATCH_WPS", 4);
-bool multi = ablation_env("RLIPV2_PATCH_MULTI", 0) != 0;      // (the experimental instantiation, also with 1 patch per wave)
+bool multi = ablation_env("RLIPV2_PATCH_MULTI", kPatchMulti) != 0;      // (the experimental instantiation, also with 1 patch per wave)
     for (int l = 0; l < kL; ++l) multi = multi || pl.reps[l] > 1;
 #define MSDA_PATCH(OT, WPS, MULTI)                                                                                   \
     hipLaunchKernelGGL((patch_dest_kernel<OT, WPS, MULTI>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, pl, \

@@ -77,8 +77,12 @@ typedef enum msda_variant {
     MSDA_VARIANT_WINDOW = 3,    /* D = 32, L*P = 16: LDS-staged sampling windows per query tile */
     MSDA_VARIANT_DEST = 4,      /* backward only, D = 32, L*P = 16: destination-stationary grad_value (no float atomics,
                                    deterministic); needs a workspace and a host copy of spatial_shapes: msda_backward_ws */
-    MSDA_VARIANT_COARSE = 5     /* forward only, bfloat16, D = 32, L*P = 16, Lq >= 4096: direct gathers for the fine levels,
+    MSDA_VARIANT_COARSE = 5,    /* forward only, bfloat16, D = 32, L*P = 16, Lq >= 4096: direct gathers for the fine levels,
                                    the rows of the coarse levels resident in LDS per (image, head) workgroup */
+    MSDA_VARIANT_CELL = 6       /* forward only, through msda_forward_hs only (needs the host copy of the level shapes),
+                                   bfloat16, D = 32, L = P = 4, Lq == S: per-cell sampling windows in LDS, bilinear sums
+                                   on the matrix cores (csrc/msda_patch.hip: cell_forward_kernel).  EXPERIMENTAL: never
+                                   picked by MSDA_VARIANT_AUTO */
 } msda_variant;
 
 /* Replaces ms_deform_attn_forward (reference models/ops/src/ms_deform_attn.h:36-53,
@@ -100,6 +104,17 @@ int msda_backward(int dtype,
                   int N, int S, int M, int D, int L, int Lq, int P,
                   void *grad_value, void *grad_sampling_loc, void *grad_attn_weight,
                   void *stream);
+
+/* msda_forward_ex with a HOST copy of spatial_shapes (int64 [L, 2], same values as the device tensor; NULL: exactly
+ * msda_forward_ex).  Variants whose launch geometry depends on the pyramid need it: MSDA_VARIANT_CELL (returns
+ * MSDA_ERR_BAD_VARIANT without it or when the problem is not a bfloat16 encoder call with Lq == S; MSDA_ERR_BAD_SHAPE
+ * when sum(H_l * W_l) != S). */
+int msda_forward_hs(int variant, int dtype,
+                    const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                    const int64_t *spatial_shapes_host,
+                    const void *sampling_loc, const void *attn_weight,
+                    int N, int S, int M, int D, int L, int Lq, int P,
+                    void *out, void *stream);
 
 /* Flag OR-ed into the `variant` argument of msda_backward_ex: the caller has already zero-filled
  * grad_value on `stream`, skip the memset inside (lets a profiler time the kernel alone). */

@@ -15,16 +15,16 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 # enum msda_dtype / msda_variant (include/rlipv2_msda.h)
 MSDA_F32, MSDA_F64, MSDA_BF16 = 0, 1, 2
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_QUAD, VARIANT_WINDOW, VARIANT_DEST, VARIANT_COARSE = 0, 1, 2, 3, 4, 5
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_QUAD, VARIANT_WINDOW, VARIANT_DEST, VARIANT_COARSE, VARIANT_CELL = 0, 1, 2, 3, 4, 5, 6
 VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "quad": VARIANT_QUAD, "window": VARIANT_WINDOW,
-            "dest": VARIANT_DEST, "coarse": VARIANT_COARSE}
+            "dest": VARIANT_DEST, "coarse": VARIANT_COARSE, "cell": VARIANT_CELL}
 FLAG_GRAD_VALUE_ZEROED, FLAG_GRAD_VALUE_BF16 = 0x100, 0x200
 
 EXPORTS = (
     "msda_forward", "msda_backward", "msda_forward_ex", "msda_backward_ex", "msda_check_im2col_step",
     "msda_algorithmic_bytes", "msda_strerror", "msda_abi_version", "msda_variant_name", "msda_pick_variant",
     "msda_prepare_forward", "msda_prepare_backward", "msda_backward_workspace_bytes", "msda_backward_ws",
-    "msda_backward_plan_info",
+    "msda_backward_plan_info", "msda_forward_hs",
     "msda_fused_supported", "msda_fused_forward", "msda_fused_backward_ws",
     # include/rlipv2_linear.h
     "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
@@ -78,6 +78,8 @@ def lib() -> ctypes.CDLL:
     L.msda_backward_ex.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp]
     L.msda_backward_workspace_bytes.argtypes = [i, vp, *dims]
     L.msda_backward_workspace_bytes.restype = ctypes.c_size_t
+    L.msda_forward_hs.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *dims, vp, vp]
+    L.msda_forward_hs.restype = i
     L.msda_backward_plan_info.argtypes = [i, vp, *dims, vp, i]
     L.msda_backward_plan_info.restype = i
     L.msda_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp, ctypes.c_size_t, vp]

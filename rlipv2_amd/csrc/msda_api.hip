@@ -78,6 +78,7 @@ const char *msda_variant_name(int variant)
         case MSDA_VARIANT_WINDOW: return "window";
         case MSDA_VARIANT_DEST: return "dest";
         case MSDA_VARIANT_COARSE: return "coarse";
+        case MSDA_VARIANT_CELL: return "cell";
         default: return "?";
     }
 }
@@ -220,6 +221,29 @@ size_t msda_backward_workspace_bytes(int dtype, const int64_t *spatial_shapes_ho
     Problem p{};
     p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
     return dest_workspace_bytes(p, spatial_shapes_host);
+}
+
+int msda_forward_hs(int variant, int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                    const int64_t *spatial_shapes_host, const void *sampling_loc, const void *attn_weight, int N, int S,
+                    int M, int D, int L, int Lq, int P, void *out, void *stream)
+{
+    if (variant != MSDA_VARIANT_CELL)
+        return msda_forward_ex(variant, dtype, value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L,
+                               Lq, P, out, stream);
+    const int st = validate(dtype, N, S, M, D, L, Lq, P);
+    if (st != MSDA_OK) return st;
+    if (!spatial_shapes_host) return MSDA_ERR_BAD_VARIANT;
+    if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !out) return MSDA_ERR_NULL_POINTER;
+    if (!(aligned16(value) && aligned16(sampling_loc) && aligned16(attn_weight) && aligned16(out))) return MSDA_ERR_ALIGNMENT;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.loc = sampling_loc; p.aw = attn_weight;
+    p.out = out; p.stream = (hipStream_t)stream;
+    if (L > 0 && !dest_shapes_consistent(p, spatial_shapes_host)) return MSDA_ERR_BAD_SHAPE;
+    if (!cell_forward_supports(p, spatial_shapes_host)) return MSDA_ERR_BAD_VARIANT;
+    (void)hipGetLastError();
+    launch_cell_forward(p, spatial_shapes_host);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
 }
 
 int msda_backward_plan_info(int dtype, const int64_t *spatial_shapes_host, int N, int S, int M, int D, int L, int Lq, int P,

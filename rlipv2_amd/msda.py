@@ -127,9 +127,16 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream().cuda_stream
-        st = L.msda_forward_ex(_variant_fwd, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
-                               level_start_index.data_ptr(), loc.data_ptr(), aw.data_ptr(),
-                               N, S, M, D, nL, Lq, P, out.data_ptr(), stream)
+        if _variant_fwd == _lib.VARIANT_CELL:       # (explicit, experimental: needs the host copy of the level shapes)
+            hs = host_shapes(spatial_shapes)
+            hs_arr = (ctypes.c_int64 * len(hs))(*hs) if hs is not None else None
+            st = L.msda_forward_hs(_variant_fwd, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                                   level_start_index.data_ptr(), hs_arr, loc.data_ptr(), aw.data_ptr(),
+                                   N, S, M, D, nL, Lq, P, out.data_ptr(), stream)
+        else:
+            st = L.msda_forward_ex(_variant_fwd, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                                   level_start_index.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                                   N, S, M, D, nL, Lq, P, out.data_ptr(), stream)
     if st:
         _raise(st)
     roofline.add(_lib.algorithmic_bytes(_DTYPES[value.dtype], False, N, S, M, D, nL, Lq, P))

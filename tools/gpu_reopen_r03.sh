@@ -9,5 +9,7 @@ cd $GRAFT_REPO_ROOT
 tail -5 $OUT/pytest_gpu.txt
 ( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; timeout 900 python tools/r03_experiments.py > $OUT/experiments.txt 2>&1 )
 cat $OUT/experiments.txt
+( RLIPV2_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_msda_cell_forward_gpu.py -q -m gpu > $OUT/pytest_cell_forward.txt 2>&1; timeout 300 python tools/cell_forward_check.py >> $OUT/pytest_cell_forward.txt 2>&1 )
+tail -25 $OUT/pytest_cell_forward.txt
 timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 tail -c 1500 $OUT/bench_line.json

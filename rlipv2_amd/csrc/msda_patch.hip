@@ -1028,324 +1028,46 @@ namespace msda {
 namespace {
 #endif
 
-// ------------------------------------------------------------------------------------------------------------------
-// cell_forward_kernel (explicit variant MSDA_VARIANT_CELL; written while no GPU was available: NOT yet validated on
-// hardware, never picked automatically): the FORWARD pass of an encoder call (Lq == S, bfloat16) from LDS-resident value
-// windows with the bilinear sums on the matrix cores.  (Reference semantics: ms_deform_im2col_cuda.cuh:237-299, the
-// bilinear interpolation :33-84.)
-//
-//   out[q, ch] = sum over the 16 samples s of  sum over the 4 corners c of  (attn_s * tent weight_{s,c}) * value[corner, ch]
-//
-// per sample a [1 x 4] x [4 x 32] product -- the shape of v_mfma_f32_4x4x4_16B_bf16 once the four corner rows are turned
-// into "4 corners of one channel per lane", which is what ds_read_b64_tr_b16 does with rows addressed independently:
-//   * a workgroup owns one (image, head, cell) like cell_backward_kernel; the levels are processed one after the other,
-//     each from its own window (60 KB budget): bounding box of every corner the cell's in-range samples touch, INCLUDING
-//     corners one pixel outside the level -- those pixels and two extra rows are staged as zeros, so that neither corner
-//     validity nor out-of-range samples need a branch or a mask in the inner loop;
-//   * geometry once per sample: lane (query qi = lane >> 2, point = lane & 3) computes its sample of the current level --
-//     4 corner weights x attention weight, split into bfloat16 hi + lo (2^-16 relative), and the window address of the
-//     top-left corner -- and leaves them in a 32-byte record in the wave's own LDS;
-//   * products: a 16-lane group owns one query (4 queries per wave step), the 4 MFMA blocks of the group own 4 channels
-//     each.  A operand: row 0 = hi weights, row 1 = lo weights (rows 2, 3 unused), read from the record; B operand: one
-//     transposing read per 16 channels, lane p addressing corner p >> 2, piece p & 3; D[0][ch] + D[1][ch] is the sample's
-//     contribution, accumulated over the level's 4 samples in the MFMA accumulator and over the levels in one register
-//     per (query, channel half);
-//   * a level whose window does not fit is summed by plain loads and FMAs (correct for any input, slow).
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int kFwdWinBytes = 60 * 1024;
-constexpr int kFwdMaxPx = kFwdWinBytes / 64;
-constexpr int kFwdRec = 32;                               // bytes per (query, sample) record: hi01 hi23 lo01 lo23 base - - -
-constexpr int kFwdWaveScratch = 16 * kP * kFwdRec;        // 16 queries x 4 samples
-constexpr int kFwdGroups = 3;                             // groups of 16 queries per wave: 8 waves x 48 >= 340
-constexpr int kFwdCopies = 8;                             // window pieces per thread: 960 px x 4 pieces / 512 threads
-constexpr int kFwdLds = kFwdWinBytes + (kCellThreads / 64) * kFwdWaveScratch;
-static_assert(kFwdGroups * (kCellThreads / 64) * 16 >= kCellQ, "every query of a cell has a lane group");
-static_assert(kFwdCopies * kCellThreads >= kFwdMaxPx * 4, "staging copies");
-
-__device__ __forceinline__ int dpp_min_step_impl(int v, int other) { return v < other ? v : other; }
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_min(int v)
-{
-    return dpp_min_step_impl(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ int wave_min_last(int v)             // minimum over the wave, valid in lane 63 (DPP, no LDS)
-{
-    v = dpp_min<0x111, 0xf>(v);
-    v = dpp_min<0x112, 0xf>(v);
-    v = dpp_min<0x114, 0xf>(v);
-    v = dpp_min<0x118, 0xf>(v);
-    v = dpp_min<0x142, 0xa>(v);
-    v = dpp_min<0x143, 0xc>(v);
-    return v;
-}
-
-__device__ __forceinline__ s16x4 lds_tr_read32(unsigned addr)    // the same read 32 bytes further (second channel half)
+// ---- cell_forward_kernel: source in msda_cell_forward.inc (shared with the host-side lane-level model) ----------------
+__device__ __forceinline__ s16x4 lds_tr_read32(unsigned addr)    // lds_tr_read 32 bytes further (second channel half)
 {
     s16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:32" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
-
-// query j of cell (cy, cx): row index within its image, and whether it exists
-// (twelve separate opaque scalars, not a struct: see the kernel)
-#define MSDA_LS_PARAMS int lsH0, int lsH1, int lsH2, int lsH3, int lsW0, int lsW1, int lsW2, int lsW3, int lsS0, int lsS1, int lsS2, int lsS3
-#define MSDA_LS_ARGS lsH0, lsH1, lsH2, lsH3, lsW0, lsW1, lsW2, lsW3, lsS0, lsS1, lsS2, lsS3
-__device__ __forceinline__ int cell_query(MSDA_LS_PARAMS, int cy, int cx, int j, bool &live)
-{
-    const int lq = j < 256 ? 0 : j < 320 ? 1 : j < 336 ? 2 : 3;
-    const int r = j - (lq == 0 ? 0 : lq == 1 ? 256 : lq == 2 ? 320 : 336);
-    const int sh = 4 - lq;
-    const int iy = (cy << sh) + (r >> sh), ix = (cx << sh) + (r & ((1 << sh) - 1));
-    const int Hq = lq == 0 ? lsH0 : lq == 1 ? lsH1 : lq == 2 ? lsH2 : lsH3;
-    const int Wq = lq == 0 ? lsW0 : lq == 1 ? lsW1 : lq == 2 ? lsW2 : lsW3;
-    const int stq = lq == 0 ? lsS0 : lq == 1 ? lsS1 : lq == 2 ? lsS2 : lsS3;
-    live = j < kCellQ && iy < Hq && ix < Wq;
-    return live ? stq + iy * Wq + ix : 0;
-}
-
-__global__ __launch_bounds__(kCellThreads, 4) void cell_forward_kernel(
-    PatchPlan pl, const bf16_t *__restrict__ value, const int64_t *__restrict__ starts, const float *__restrict__ loc,
-    const float *__restrict__ aw, int N, int S, int M, int Lq, bf16_t *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char flds[];       // [window | 8 x records of a wave]
-    __shared__ int box[kL][4];                // per level: x0, y0, -x1, -y1 of every corner in reach (LDS integer min)
-    __shared__ int winfo[kL][12];             // per level: H, W, x0, y0, cols, rows, pitch, start, staged
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cells = pl.CY * pl.CX, NM = N * M;
-    int nm, c;
-    if ((NM & 7) == 0) {                      // (the (image, head) pairs of an XCD stay together, like the backward)
-        const int per = NM >> 3, idx = blockIdx.x >> 3;
-        nm = (blockIdx.x & 7) * per + idx % per;
-        c = idx / per;
-    } else {
-        nm = blockIdx.x % NM;
-        c = blockIdx.x / NM;
-    }
-    if (c >= cells) return;
-    const int n = nm / M, m = nm % M;
-    const int cy = c / pl.CX, cx = c % pl.CX;
-    // (opaque scalars, each its own variable: the compiler folds a select chain over starts[...] into a per-lane vector load
-    //  in front of everything else, and one over pl.H[...] -- or over the fields of a local struct -- into an indexed read
-    //  of a scratch copy)
-    const int lsH0 = __builtin_amdgcn_readfirstlane(pl.H[0]), lsH1 = __builtin_amdgcn_readfirstlane(pl.H[1]);
-    const int lsH2 = __builtin_amdgcn_readfirstlane(pl.H[2]), lsH3 = __builtin_amdgcn_readfirstlane(pl.H[3]);
-    const int lsW0 = __builtin_amdgcn_readfirstlane(pl.W[0]), lsW1 = __builtin_amdgcn_readfirstlane(pl.W[1]);
-    const int lsW2 = __builtin_amdgcn_readfirstlane(pl.W[2]), lsW3 = __builtin_amdgcn_readfirstlane(pl.W[3]);
-    const int lsS0 = __builtin_amdgcn_readfirstlane((int)starts[0]), lsS1 = __builtin_amdgcn_readfirstlane((int)starts[1]);
-    const int lsS2 = __builtin_amdgcn_readfirstlane((int)starts[2]), lsS3 = __builtin_amdgcn_readfirstlane((int)starts[3]);
-    if (tid < 16) box[tid >> 2][tid & 3] = 0x3fffffff;
-
-    // ---- phase 0: this lane's samples -- point (lane & 3) of every level of query (lane >> 2) of its 3 groups ----------
-    const int qi = lane >> 2, pt = lane & 3;
-    int sidx[kFwdGroups];                     // index of the lane's level-0 sample in sampling_loc (float2) / attn_weight; -1: no query
-    float2 bxy[kFwdGroups][kL];               // (bounding boxes only; the level loop reads its samples again, from L2)
-#pragma unroll
-    for (int G = 0; G < kFwdGroups; ++G) {
-        bool live;
-        const int q = cell_query(MSDA_LS_ARGS, cy, cx, (G * (kCellThreads / 64) + wave) * 16 + qi, live);
-        const int qm = (n * Lq + q) * M + m;                          // (< 2^27: cell_forward_supports)
-        sidx[G] = live ? qm * 16 + pt : -1;
-#pragma unroll
-        for (int l = 0; l < kL; ++l) {
-            const float2 v = reinterpret_cast<const float2 *>(loc)[max(sidx[G], 0) + l * 4];
-            bxy[G][l] = live ? v : make_float2(-4.f, -4.f);           // (a dead lane's samples are out of range of every level)
-        }
-    }
-    __syncthreads();                          // box initialised
-#pragma unroll
-    for (int l = 0; l < kL; ++l) {
-        const float Hf = (float)(l == 0 ? lsH0 : l == 1 ? lsH1 : l == 2 ? lsH2 : lsH3);
-        const float Wf = (float)(l == 0 ? lsW0 : l == 1 ? lsW1 : l == 2 ? lsW2 : lsW3);
-        int bx0 = 0x3fffffff, by0 = 0x3fffffff, nx1 = 0x3fffffff, ny1 = 0x3fffffff;
-#pragma unroll
-        for (int G = 0; G < kFwdGroups; ++G) {
-            const float h_im = fmaf(bxy[G][l].y, Hf, -0.5f), w_im = fmaf(bxy[G][l].x, Wf, -0.5f);
-            const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);   // .cuh:285 (NaN -> false)
-            const int iy = (int)floorf(inside ? h_im : 0.f), ix = (int)floorf(inside ? w_im : 0.f);
-            if (inside) {                     // corners (ix, ix + 1) x (iy, iy + 1), NOT clipped to the level
-                bx0 = min(bx0, ix); by0 = min(by0, iy); nx1 = min(nx1, -(ix + 1)); ny1 = min(ny1, -(iy + 1));
-            }
-        }
-        bx0 = wave_min_last(bx0); by0 = wave_min_last(by0); nx1 = wave_min_last(nx1); ny1 = wave_min_last(ny1);
-        if (lane == 63) {
-            atomicMin(&box[l][0], bx0); atomicMin(&box[l][1], by0); atomicMin(&box[l][2], nx1); atomicMin(&box[l][3], ny1);
-        }
-    }
-    __syncthreads();
-    if (tid < kL) {
-        const int l = tid;
-        const int x0 = box[l][0], y0 = box[l][1], x1 = -box[l][2], y1 = -box[l][3];
-        const bool any = x0 <= x1 && y0 <= y1;
-        const int cols = any ? x1 - x0 + 1 : 2, rows = any ? y1 - y0 + 1 : 0;
-        const int pitch = cols + ((2 - cols) & 3);                 // = 2 (mod 4): the four corner rows of a read on 4 bank groups
-        const int Hl = l == 0 ? lsH0 : l == 1 ? lsH1 : l == 2 ? lsH2 : lsH3;
-        const int Wl = l == 0 ? lsW0 : l == 1 ? lsW1 : l == 2 ? lsW2 : lsW3;
-        winfo[l][0] = Hl; winfo[l][1] = Wl; winfo[l][2] = any ? x0 : 0; winfo[l][3] = any ? y0 : 0;
-        winfo[l][4] = cols; winfo[l][5] = rows; winfo[l][6] = pitch;
-        winfo[l][7] = l == 0 ? lsS0 : l == 1 ? lsS1 : l == 2 ? lsS2 : lsS3;
-        winfo[l][8] = pitch * (rows + 2) <= kFwdMaxPx ? 1 : 0;     // (+ 2: the zero rows out-of-range samples read)
-    }
-    __syncthreads();
-
-    unsigned char *scr = flds + kFwdWinBytes + wave * kFwdWaveScratch;
-    const unsigned win0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)flds;
-    const int row_bytes = M * 64;
-    const size_t img_byte = ((size_t)n * S * M + m) * 64;
-    const int g4 = lane >> 4, p16 = lane & 15, r4 = lane & 3, crn = p16 >> 2;
-    float accl[kFwdGroups][4], acch[kFwdGroups][4];                // [group][query 4 t + g4]: channel p16 | 16 + p16
-#pragma unroll
-    for (int G = 0; G < kFwdGroups; ++G)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { accl[G][t] = 0.f; acch[G][t] = 0.f; }
-
-#pragma unroll 1
-    for (int l = 0; l < kL; ++l) {
-        const int H = __builtin_amdgcn_readfirstlane(winfo[l][0]), W = __builtin_amdgcn_readfirstlane(winfo[l][1]);
-        const int x0 = __builtin_amdgcn_readfirstlane(winfo[l][2]), y0 = __builtin_amdgcn_readfirstlane(winfo[l][3]);
-        const int cols = __builtin_amdgcn_readfirstlane(winfo[l][4]), rows = __builtin_amdgcn_readfirstlane(winfo[l][5]);
-        const int pitch = __builtin_amdgcn_readfirstlane(winfo[l][6]), start = __builtin_amdgcn_readfirstlane(winfo[l][7]);
-        const bool staged = __builtin_amdgcn_readfirstlane(winfo[l][8]) != 0;
-        // this lane's samples of the level (in flight during the staging)
-        float sx[kFwdGroups], sy[kFwdGroups], sa[kFwdGroups];
-#pragma unroll
-        for (int G = 0; G < kFwdGroups; ++G) {
-            const int i = max(sidx[G], 0) + l * 4;
-            const float2 v = reinterpret_cast<const float2 *>(loc)[i];
-            const float a = aw[i];
-            sx[G] = sidx[G] >= 0 ? v.x : -4.f;
-            sy[G] = sidx[G] >= 0 ? v.y : -4.f;
-            sa[G] = sidx[G] >= 0 ? a : 0.f;
-        }
-        if (l > 0) __syncthreads();                                // the previous level's window is no longer read
-        if (staged) {
-            // ---- the window: (rows + 2) x cols pixels, 4 pieces of 16 bytes each; every load of the thread first ------
-            const int total = (rows + 2) * cols * 4;
-            const float inv = 1.f / (float)cols;
-            auto piece_of = [&](int k, int &dst, bool &real) __attribute__((always_inline)) -> const uint4 * {
-                const int i = min(tid + k * kCellThreads, total - 1);
-                const int pix = i >> 2, piece = i & 3;
-                const int wy = (int)(((float)pix + 0.5f) * inv), wx = pix - wy * cols;
-                const int gy = y0 + wy, gx = x0 + wx;
-                real = wy < rows && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;    // else: a zero pixel
-                dst = (wy * pitch + wx) * 64 + piece * 16;
-                const size_t src = img_byte + (size_t)(start + (real ? gy * W + gx : 0)) * row_bytes + piece * 16;
-                return reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(value) + src);
-            };
-            int d0, d1, d2, d3, d4, d5, d6, d7;
-            bool r0, r1, r2, r3, r4_, r5, r6, r7;
-            const uint4 *s0 = piece_of(0, d0, r0), *s1 = piece_of(1, d1, r1), *s2 = piece_of(2, d2, r2);
-            const uint4 *s3 = piece_of(3, d3, r3), *s4 = piece_of(4, d4, r4_), *s5 = piece_of(5, d5, r5);
-            const uint4 *s6 = piece_of(6, d6, r6), *s7 = piece_of(7, d7, r7);
-            const uint4 v0 = *s0, v1 = *s1, v2 = *s2, v3 = *s3, v4 = *s4, v5 = *s5, v6 = *s6, v7 = *s7;
-            // (a mask per component, not `real ? v : zero`: the compiler turns a select between two 16-byte values into a
-            //  scratch array indexed by the condition -- and waits for every load right where it is issued to fill it)
-            auto keep = [](const uint4 &v, bool real) __attribute__((always_inline)) {
-                const uint32_t mk = real ? 0xffffffffu : 0u;
-                return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
-            };
-            if (tid < total) *reinterpret_cast<uint4 *>(flds + d0) = keep(v0, r0);
-            if (tid + kCellThreads < total) *reinterpret_cast<uint4 *>(flds + d1) = keep(v1, r1);
-            if (tid + 2 * kCellThreads < total) *reinterpret_cast<uint4 *>(flds + d2) = keep(v2, r2);
-            if (tid + 3 * kCellThreads < total) *reinterpret_cast<uint4 *>(flds + d3) = keep(v3, r3);
-            if (tid + 4 * kCellThreads < total) *reinterpret_cast<uint4 *>(flds + d4) = keep(v4, r4_);
-            if (tid + 5 * kCellThreads < total) *reinterpret_cast<uint4 *>(flds + d5) = keep(v5, r5);
-            if (tid + 6 * kCellThreads < total) *reinterpret_cast<uint4 *>(flds + d6) = keep(v6, r6);
-            if (tid + 7 * kCellThreads < total) *reinterpret_cast<uint4 *>(flds + d7) = keep(v7, r7);
-        }
-        __syncthreads();
-        const float Hf = (float)H, Wf = (float)W;
-        const int zero_base = rows * pitch * 64;                   // top-left of the 2 x 2 zero pixels out-of-range samples read
-        const int delta = ((crn >> 1) * pitch + (crn & 1)) * 64 + r4 * 8;   // this lane's corner row and 8-byte piece
-#pragma unroll
-        for (int G = 0; G < kFwdGroups; ++G) {
-            // ---- this lane's sample of the level -> record ------------------------------------------------------------
-            {
-                const float h_im = fmaf(sy[G], Hf, -0.5f), w_im = fmaf(sx[G], Wf, -0.5f);
-                const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);
-                const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;
-                const float hf = floorf(hs), wf = floorf(ws);
-                const float lh = hs - hf, lw = ws - wf, hh = 1.f - lh, hw = 1.f - lw;
-                const float a = inside ? sa[G] : 0.f;
-                const float w1 = hh * hw * a, w2 = hh * lw * a, w3 = lh * hw * a, w4 = lh * lw * a;   // TL TR BL BR (.cuh:47-50)
-                uint32_t hi01, lo01, hi23, lo23;
-                split_pair(w1, w2, hi01, lo01);
-                split_pair(w3, w4, hi23, lo23);
-                const int iy = (int)hf, ix = (int)wf;
-                // staged: byte offset of the top-left corner in the window; direct: the corner's coordinates + 1 (0xffffffff:
-                // out of range)
-                const int base = staged ? (inside ? ((iy - y0) * pitch + (ix - x0)) * 64 : zero_base)
-                                        : (inside ? ((iy + 1) << 16) | (ix + 1) : -1);
-                unsigned char *rec = scr + (qi * kP + pt) * kFwdRec;
-                *reinterpret_cast<uint4 *>(rec) = make_uint4(hi01, hi23, lo01, lo23);
-                *reinterpret_cast<int *>(rec + 16) = base;
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-            // ---- 4 queries per step: lane group g4 owns query 4 t + g4 of the group -------------------------------------
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const unsigned char *rec0 = scr + ((4 * t + g4) * kP) * kFwdRec;
-                if (staged) {
-                    f32x4 c0 = {accl[G][t], 0.f, 0.f, 0.f}, c1 = {acch[G][t], 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int sidx = 0; sidx < kP; ++sidx) {
-                        const unsigned char *rec = rec0 + sidx * kFwdRec;
-                        const uint2 A = *reinterpret_cast<const uint2 *>(rec + (r4 & 1) * 8);   // row 0: hi, row 1: lo
-                        const int base = *reinterpret_cast<const int *>(rec + 16);
-                        const unsigned addr = win0 + (unsigned)(base + delta);
-                        s16x4 b0 = lds_tr_read(addr), b1 = lds_tr_read32(addr);
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) : : "memory");
-                        union { uint32_t u[2]; s16x4 v; } a;
-                        a.u[0] = A.x; a.u[1] = A.y;
-                        c0 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a.v, b0, c0, 0, 0, 0);
-                        c1 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a.v, b1, c1, 0, 0, 0);
-                    }
-                    accl[G][t] = c0[0] + c0[1];
-                    acch[G][t] = c1[0] + c1[1];
-                } else {
-                    // the level does not fit: channel p16 / 16 + p16 of the four corners straight from memory (a real loop:
-                    // unrolled, this fallback was three quarters of the kernel's code)
-                    float suml = 0.f, sumh = 0.f;
-#pragma unroll 1
-                    for (int k = 0; k < kP * 4; ++k) {
-                        const int sidx = k >> 2, cc = k & 3;
-                        const unsigned char *rec = rec0 + sidx * kFwdRec;
-                        const uint32_t whi = reinterpret_cast<const uint32_t *>(rec)[cc >> 1];        // hi01 | hi23
-                        const uint32_t wlo = reinterpret_cast<const uint32_t *>(rec)[2 + (cc >> 1)];  // lo01 | lo23
-                        const float w = (cc & 1) ? bf16_hi(whi) + bf16_hi(wlo) : bf16_lo(whi) + bf16_lo(wlo);
-                        const int base = *reinterpret_cast<const int *>(rec + 16);
-                        const int gx = (base & 0xffff) - 1 + (cc & 1), gy = (base >> 16) - 1 + (cc >> 1);
-                        const bool ok = base != -1 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                        const bf16_t *row = reinterpret_cast<const bf16_t *>(
-                            reinterpret_cast<const unsigned char *>(value) + img_byte +
-                            (size_t)(start + (ok ? gy * W + gx : 0)) * row_bytes);
-                        const float vl = ok ? __uint_as_float((uint32_t)row[p16] << 16) : 0.f;
-                        const float vh = ok ? __uint_as_float((uint32_t)row[16 + p16] << 16) : 0.f;
-                        suml = fmaf(w, vl, suml);
-                        sumh = fmaf(w, vh, sumh);
-                    }
-                    accl[G][t] += suml;
-                    acch[G][t] += sumh;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-        }
-    }
-
-    // ---- out: lane (g4, p16) holds channels p16 and 16 + p16 of query 4 t + g4 of every group -----------------------------
-#pragma unroll
-    for (int G = 0; G < kFwdGroups; ++G)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            bool live;
-            const int q = cell_query(MSDA_LS_ARGS, cy, cx, (G * (kCellThreads / 64) + wave) * 16 + 4 * t + g4, live);
-            if (live) {
-                bf16_t *o = out + (((long)n * Lq + q) * M + m) * kD;
-                o[p16] = (bf16_t)(cvt_pk_bf16(accl[G][t], 0.f) & 0xffffu);
-                o[16 + p16] = (bf16_t)(cvt_pk_bf16(acch[G][t], 0.f) & 0xffffu);
-            }
-        }
-}
+#define MSDA_DEVFN __device__ __forceinline__
+#define MSDA_KERNEL_BOUNDS(T, W) __global__ __launch_bounds__(T, W)
+#define MSDA_LDS_DYNAMIC(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define MSDA_LDS_STATIC(type, name, dims) __shared__ type name dims
+#define MSDA_TID threadIdx.x
+#define MSDA_BID blockIdx.x
+#define MSDA_READFIRSTLANE(x) __builtin_amdgcn_readfirstlane(x)
+#define MSDA_UPDATE_DPP(old, v, ctrl, row_mask) __builtin_amdgcn_update_dpp(old, v, ctrl, row_mask, 0xf, false)
+#define MSDA_SYNCTHREADS() __syncthreads()
+#define MSDA_LDS_ATOMIC_MIN(p, v) atomicMin(p, v)
+#define MSDA_LDS_ADDR(p) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(p))
+#define MSDA_WAVE_FENCE() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define MSDA_TR_READ_PAIR(b0, b1, addr)                                                                              \
+    do {                                                                                                              \
+        b0 = lds_tr_read(addr); b1 = lds_tr_read32(addr);                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) : : "memory");                                      \
+    } while (0)
+#define MSDA_MFMA444(a, b, c) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0)
+#include "msda_cell_forward.inc"
+#undef MSDA_DEVFN
+#undef MSDA_KERNEL_BOUNDS
+#undef MSDA_LDS_DYNAMIC
+#undef MSDA_LDS_STATIC
+#undef MSDA_TID
+#undef MSDA_BID
+#undef MSDA_READFIRSTLANE
+#undef MSDA_UPDATE_DPP
+#undef MSDA_SYNCTHREADS
+#undef MSDA_LDS_ATOMIC_MIN
+#undef MSDA_LDS_ADDR
+#undef MSDA_WAVE_FENCE
+#undef MSDA_TR_READ_PAIR
+#undef MSDA_MFMA444
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 bool make_patch_plan(const Problem &p, const int64_t *hs, PatchPlan &pl)

@@ -35,6 +35,19 @@
 #include "msda_geometry.h"
 #include "msda_internal.h"
 
+// The few constructs a host compiler cannot take (inline assembly, dynamic LDS declarations, LDS byte addresses) go through
+// these macros: tools/emu/ compiles THIS FILE for the CPU against a lane-level model of the workgroup (MSDA_EMU) to check
+// the kernels' logic without a GPU.  For hipcc they expand to exactly what stood here before (device assembly unchanged).
+#ifndef MSDA_EMU
+#define MSDA_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#define MSDA_LDS_BYTE_ADDR(p) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(p))
+#define MSDA_ASM_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MSDA_ASM_FENCE() asm volatile("" ::: "memory")
+// where the lanes of ONE wave hand data to each other through LDS with nothing but program order in between (the wave runs
+// in lock step and its LDS operations complete in order): nothing to do on the hardware, a wave barrier in the host model
+#define MSDA_WAVE_LDS_SYNC() do { } while (0)
+#endif
+
 namespace msda {
 
 namespace {
@@ -184,7 +197,7 @@ __device__ __forceinline__ void bin_cell(const PatchPlan &pl, const int64_t *__r
         av[it] = reinterpret_cast<const float2 *>(aw)[qm * 8 + chunk];
     }
 #ifdef MSDA_ABLATION
-    if (BBOX && (MSDA_DBG(dbg) & 16)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CTS(10); }
+    if (BBOX && (MSDA_DBG(dbg) & 16)) { MSDA_ASM_WAIT_VM(); CTS(10); }
 #endif
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(kBinThreads) void bin2_kernel(PatchPlan pl, const i
                                                            int M, int Lq, uint32_t *__restrict__ masks,
                                                            float *__restrict__ recs, int *__restrict__ ctl)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    MSDA_DYNAMIC_LDS(uint32_t, tab);
     __shared__ int rng[kL][4];                // per level: first / last patch row, first / last patch column in reach
     const int cells = pl.CY * pl.CX;
     const int m = blockIdx.x % M;
@@ -292,12 +305,14 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)       // DPP row shift
     return v;
 }
 
+#ifndef MSDA_EMU
 __device__ __forceinline__ s16x4 lds_tr_read(unsigned addr)
 {
     s16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+#endif
 
 // two floats -> packed bfloat16 pair (round to nearest even: v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b)
@@ -330,12 +345,12 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
     const bf16_t *__restrict__ grad_out, const uint32_t *__restrict__ masks, const int *__restrict__ ctl,
     OT *__restrict__ g_value, int N, int S, int M, int Lq, int dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    MSDA_DYNAMIC_LDS(unsigned char, lds);
     if (ctl[kFarWord] != 0) return;                       // a far sample: the sorting pass of msda_dest.hip takes the call
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     unsigned char *wl = lds + wave * kWaveLds;
     uint16_t *list = reinterpret_cast<uint16_t *>(wl + kOffList);
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)wl;
+    const unsigned lds0 = MSDA_LDS_BYTE_ADDR(wl);
 
     // ---- item: (image, head) group by XCD (hardware block b runs on XCD b % 8), coarsest level first -----------------
     const int NM = N * M;
@@ -434,7 +449,9 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
                     const int left = tail - head;
                     int v = 0;
                     if (lane < left) v = list[head + lane];
+                    MSDA_WAVE_LDS_SYNC();
                     if (lane < left) list[lane] = (uint16_t)v;
+                    MSDA_WAVE_LDS_SYNC();
                     head = 0; tail = left;
                 }
                 const int cnt = __popc(cur);
@@ -456,6 +473,7 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
                     }
                     cur = 0u;
                 }
+                MSDA_WAVE_LDS_SYNC();
                 tail += total;
             }
             // ---- operands of the NEXT step start travelling (software pipeline: one step of loads in flight) ------------
@@ -537,6 +555,7 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
             uint4 *grow = reinterpret_cast<uint4 *>(wl + kOffG + kk * 64 + half * 32);
             grow[0] = g0;
             grow[1] = g1;
+            MSDA_WAVE_LDS_SYNC();
             // operands: G^T tiles (channels 0-15 | 16-31) and the four A^T matrices, 8 consecutive groups per lane
             union Frag { bf16x8 v; s16x4 h[2]; };
             Frag gt0, gt1, at0, at1, at2, at3;
@@ -546,13 +565,16 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
             at1.h[0] = lds_tr_read(a_rd + 1024); at1.h[1] = lds_tr_read(a_rd + 1024 + 128);
             at2.h[0] = lds_tr_read(a_rd + 2048); at2.h[1] = lds_tr_read(a_rd + 2048 + 128);
             at3.h[0] = lds_tr_read(a_rd + 3072); at3.h[1] = lds_tr_read(a_rd + 3072 + 128);
+            MSDA_WAVE_LDS_SYNC();
             // (the wait names the fragments so that the scheduler cannot lift an MFMA above it: the compiler does not
             //  know that the transpose-reads' results are still in flight)
+#ifndef MSDA_EMU
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(gt0.h[0]), "+v"(gt0.h[1]), "+v"(gt1.h[0]), "+v"(gt1.h[1]), "+v"(at0.h[0]), "+v"(at0.h[1]),
                            "+v"(at1.h[0]), "+v"(at1.h[1]), "+v"(at2.h[0]), "+v"(at2.h[1]), "+v"(at3.h[0]), "+v"(at3.h[1])
                          :
                          : "memory");
+#endif
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at0.v, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at0.v, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at1.v, acc0, 0, 0, 0);
@@ -796,7 +818,7 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
     int Lq, unsigned value_bytes, float *__restrict__ g_loc, float *__restrict__ g_aw, const float *__restrict__ ref,
     bf16_t *__restrict__ g_qproj, uint32_t *__restrict__ masks, float *__restrict__ recs, int *__restrict__ ctl, int dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char clds[];       // [zeros | windows | bin table]
+    MSDA_DYNAMIC_LDS(unsigned char, clds);    // [zeros | windows | bin table]
     __shared__ int rng[kL][4];
     __shared__ int box[kL][4];
     __shared__ int winfo[kL][8];              // per level: H, W, window x0, y0, pitch, LDS base (< 0: gathered directly), start
@@ -956,7 +978,7 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t) g[t] = reinterpret_cast<const uint4 *>(grad_out + qm * kD)[t ^ rot];
 #ifdef MSDA_ABLATION
-        if (MSDA_DBG(dbg) & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CTS(3); }     // task operands have arrived
+        if (MSDA_DBG(dbg) & 16) { MSDA_ASM_WAIT_VM(); CTS(3); }     // task operands have arrived
 #endif
         float4 gla = make_float4(0.f, 0.f, 0.f, 0.f), glb = gla, ga = gla;
 #pragma unroll 1
@@ -1029,15 +1051,17 @@ namespace {
 #endif
 
 // ---- cell_forward_kernel: source in msda_cell_forward.inc (shared with the host-side lane-level model) ----------------
+#ifndef MSDA_EMU
 __device__ __forceinline__ s16x4 lds_tr_read32(unsigned addr)    // lds_tr_read 32 bytes further (second channel half)
 {
     s16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:32" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+#endif
 #define MSDA_DEVFN __device__ __forceinline__
 #define MSDA_KERNEL_BOUNDS(T, W) __global__ __launch_bounds__(T, W)
-#define MSDA_LDS_DYNAMIC(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define MSDA_LDS_DYNAMIC(name) MSDA_DYNAMIC_LDS(unsigned char, name)
 #define MSDA_LDS_STATIC(type, name, dims) __shared__ type name dims
 #define MSDA_TID threadIdx.x
 #define MSDA_BID blockIdx.x
@@ -1045,13 +1069,17 @@ __device__ __forceinline__ s16x4 lds_tr_read32(unsigned addr)    // lds_tr_read 
 #define MSDA_UPDATE_DPP(old, v, ctrl, row_mask) __builtin_amdgcn_update_dpp(old, v, ctrl, row_mask, 0xf, false)
 #define MSDA_SYNCTHREADS() __syncthreads()
 #define MSDA_LDS_ATOMIC_MIN(p, v) atomicMin(p, v)
-#define MSDA_LDS_ADDR(p) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(p))
-#define MSDA_WAVE_FENCE() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define MSDA_LDS_ADDR(p) MSDA_LDS_BYTE_ADDR(p)
+#define MSDA_WAVE_FENCE() do { __builtin_amdgcn_wave_barrier(); MSDA_ASM_FENCE(); } while (0)
+#ifndef MSDA_EMU
 #define MSDA_TR_READ_PAIR(b0, b1, addr)                                                                              \
     do {                                                                                                              \
         b0 = lds_tr_read(addr); b1 = lds_tr_read32(addr);                                                            \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) : : "memory");                                      \
     } while (0)
+#else
+#define MSDA_TR_READ_PAIR(b0, b1, addr) do { b0 = lds_tr_read(addr); b1 = lds_tr_read32(addr); } while (0)
+#endif
 #define MSDA_MFMA444(a, b, c) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0)
 #include "msda_cell_forward.inc"
 #undef MSDA_DEVFN

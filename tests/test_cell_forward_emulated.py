@@ -73,6 +73,8 @@ def run_emulator(exe, tmp_path, pyr, starts, S, M, value, loc, aw):
 @pytest.mark.parametrize("name,pyr,M,spread", [
     ("windows of every level in LDS, 2 x 2 cells", [(20, 27), (10, 14), (5, 7), (3, 4)], 2, (1.5, 1.5, 1.0, 0.7)),
     ("level 0 too wide for the window budget: plain-load route", [(30, 40), (15, 20), (8, 10), (4, 5)], 1, (25.0, 2.0, 1.0, 0.7)),
+    ("ragged pyramid (sizes not halving exactly), wide offsets on the coarse levels", [(25, 34), (13, 17), (7, 9), (4, 5)], 1,
+     (2.0, 3.0, 3.0, 3.0)),
 ])
 def test_device_source_on_the_lane_level_model(emulator, tmp_path, name, pyr, M, spread):
     pyr, starts, S, value, loc, aw = make_problem(pyr, M, spread, seed=11)

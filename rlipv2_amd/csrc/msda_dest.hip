@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void bin_kernel(DestPlan pl, const int64_t *__
                                                   const float *__restrict__ loc, int M, int Lq,
                                                   uint32_t *__restrict__ masks, const int *__restrict__ gate)
 {
-    extern __shared__ uint32_t bmask[];               // [Td][8]
+    MSDA_DYNAMIC_LDS_PLAIN(uint32_t, bmask);          // [Td][8]
     if (gate && *gate == 0) return;                   // the patch pass of msda_patch.hip has taken the call
     const int tid = threadIdx.x;
     const int m = blockIdx.x % M;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
     const VT *__restrict__ grad_out, const uint32_t *__restrict__ masks, int *__restrict__ counter,
     OT *__restrict__ g_value, float *__restrict__ partials, int N, int S, int M, int Lq, const int *__restrict__ gate)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    MSDA_DYNAMIC_LDS(unsigned char, lds);
     if (gate && *gate == 0) return;                   // the patch pass of msda_patch.hip has taken the call
     typedef DestLds<VT, TH> LD;
     typedef Geo<TH> G;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
             int *hist = hist0 + (c0 & 1) * LD::kHistInts;
             const Fetch me = nxt;
 #ifdef MSDA_DEST_TIMELINE
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MSDA_ASM_WAIT_VM();
             DTS(12);
 #endif
             {   // the next pass's operands start travelling now

@@ -6,6 +6,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The few constructs a host compiler cannot take (inline assembly, dynamic LDS declarations, LDS byte addresses, LDS-DMA) go
+// through these macros: tools/emu/ compiles the kernel FILES for the CPU against a lane-level model of the workgroup
+// (-DMSDA_EMU, tools/emu/stub/hip/hip_runtime.h defines them there) to check the kernels' logic without a GPU.  For hipcc
+// they expand to exactly what stood in the kernels before (device assembly unchanged).
+#ifndef MSDA_EMU
+#define MSDA_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#define MSDA_DYNAMIC_LDS_ALIGNED(type, name, n) extern __shared__ __attribute__((aligned(n))) type name[]
+#define MSDA_DYNAMIC_LDS_PLAIN(type, name) extern __shared__ type name[]
+#define MSDA_LDS_BYTE_ADDR(p) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(p))
+#define MSDA_ASM_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MSDA_ASM_FENCE() asm volatile("" ::: "memory")
+#define MSDA_ASM_OPAQUE(x) asm volatile("" : "+v"(x))
+// one LDS-DMA instruction: lane i copies 16 bytes from ITS global address to lds_base (wave-uniform) + 16 i
+#define MSDA_GLOBAL_LOAD_LDS16(src, lds_base)                                                                        \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),                          \
+                                     (__attribute__((address_space(3))) void *)(lds_base), 16, 0, 0)
+// where the lanes of ONE wave hand data to each other through LDS with nothing but program order in between (the wave runs
+// in lock step and its LDS operations complete in order): nothing to do on the hardware, a wave barrier in the host model
+#define MSDA_WAVE_LDS_SYNC() do { } while (0)
+#endif
+
 namespace msda {
 
 typedef uint16_t bf16_t;  // raw bfloat16 storage

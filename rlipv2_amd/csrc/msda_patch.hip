@@ -35,19 +35,6 @@
 #include "msda_geometry.h"
 #include "msda_internal.h"
 
-// The few constructs a host compiler cannot take (inline assembly, dynamic LDS declarations, LDS byte addresses) go through
-// these macros: tools/emu/ compiles THIS FILE for the CPU against a lane-level model of the workgroup (MSDA_EMU) to check
-// the kernels' logic without a GPU.  For hipcc they expand to exactly what stood here before (device assembly unchanged).
-#ifndef MSDA_EMU
-#define MSDA_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
-#define MSDA_LDS_BYTE_ADDR(p) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(p))
-#define MSDA_ASM_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define MSDA_ASM_FENCE() asm volatile("" ::: "memory")
-// where the lanes of ONE wave hand data to each other through LDS with nothing but program order in between (the wave runs
-// in lock step and its LDS operations complete in order): nothing to do on the hardware, a wave barrier in the host model
-#define MSDA_WAVE_LDS_SYNC() do { } while (0)
-#endif
-
 namespace msda {
 
 namespace {

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(BLOCK, 4) void quad_forward_coarse_kernel(
     const float *__restrict__ ref, int N, int S, int M, int Lq, int wgs_per_pair, unsigned value_bytes,
     bf16_t *__restrict__ out, float *__restrict__ loc_save, float *__restrict__ aw_save, int max_staged)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char coarse_lds[];
+    MSDA_DYNAMIC_LDS(unsigned char, coarse_lds);
     const int tid = threadIdx.x;
     // XCD-aware placement (hardware block b runs on XCD b % 8): all workgroups of one (image, head) pair on ONE XCD,
     // so that an XCD's L2 holds the fine-level rows of pairs / 8 pairs only.  Bijective for any grid; speed only.
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kTileW *TH * 4, WAVES) void tile_forward_kernel(
     constexpr int ROWB = kD * (int)sizeof(VT);
     constexpr int PPR = ROWB / 16;                                   // 16-byte pieces per pixel row
     constexpr int MAXPX = (kWinBytes - kZeroSlot - kWinSlack) / ROWB;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char tile_lds[];
+    MSDA_DYNAMIC_LDS_ALIGNED(unsigned char, tile_lds, 1024);
     unsigned char *win = tile_lds;
     int *box = reinterpret_cast<int *>(tile_lds + kWinBytes);        // [4 levels][x0, y0, -x1, -y1] (all via min)
 
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kTileW *TH * 4, WAVES) void tile_forward_kernel(
         // Everything below is derived from an opaque copy of the thread id: otherwise the compiler hoists
         // the per-thread address arithmetic of all four levels out of the item loop and spills it.
         int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
+        MSDA_ASM_OPAQUE(tid);
         const int sub = tid & 3, ql = tid >> 2;
         // own level (= quad lane): dimensions for the bounding box
         const int Hs = (int)shapes[2 * sub], Ws = (int)shapes[2 * sub + 1];
@@ -655,9 +655,7 @@ __global__ __launch_bounds__(kTileW *TH * 4, WAVES) void tile_forward_kernel(
                     const int wx = pxi - wy * ww[l];
                     const unsigned off = lvl_byte + (unsigned)__mul24(wy * W + wx, row_bytes) + (unsigned)(part * 16);
                     const unsigned char *src = reinterpret_cast<const unsigned char *>(value) + off;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(win + wbase[l] + i0 * 16),
-                                                     16, 0, 0);
+                    MSDA_GLOBAL_LOAD_LDS16(src, win + wbase[l] + i0 * 16);
                 }
                 // a stretch is rounded up to whole 64-piece DMA waves so that the next one cannot be overrun
                 used += (npx * PPR + 63) / 64 * 64 / PPR;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void sparse_dest_kernel(SparsePlan pl, co
                                                                const VT *__restrict__ grad_out, OT *__restrict__ g_value,
                                                                int N, int S, int M)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    MSDA_DYNAMIC_LDS(unsigned char, lds);
     constexpr int ROWB = Row<VT>::kBytes, PPR = ROWB / 16;
     unsigned char *grow = lds;
     uint2 *rec = reinterpret_cast<uint2 *>(lds + pl.off_rec);          // {record id, weight} sorted by pixel

@@ -10,9 +10,6 @@
 #define MSDA_ABLATION 1
 #include <hip/hip_runtime.h>
 
-inline emu_s16x4 lds_tr_read(unsigned addr) { return emu_tr_read(addr, 0); }
-inline emu_s16x4 lds_tr_read32(unsigned addr) { return emu_tr_read(addr, 32); }
-
 #include "../../rlipv2_amd/csrc/msda_patch.hip"
 
 namespace msda {

@@ -58,7 +58,7 @@ struct Group {
     alignas(16) unsigned char guard_hi[16 << 20];
     Barrier bar;
     Wave waves[kMaxThreads / 64];
-    int block_idx = 0, block_dim = 0;
+    int block_idx = 0, block_dim = 0, grid_dim = 0;
 };
 
 inline Group *&group() { static Group *g = new Group; return g; }
@@ -145,7 +145,7 @@ template <typename F> inline void launch(unsigned grid, unsigned block, F body)
     if (block > (unsigned)kMaxThreads) { std::fprintf(stderr, "emu: block of %u threads\n", block); std::abort(); }
     for (unsigned b = 0; b < grid; ++b) {
         std::memset(g->lds, 0xa5, sizeof(g->lds));                 // LDS starts as garbage
-        g->block_idx = (int)b; g->block_dim = (int)block;
+        g->block_idx = (int)b; g->block_dim = (int)block; g->grid_dim = (int)grid;
         g->bar.reset((int)block);
         std::vector<std::thread> th;
         th.reserve(block);
@@ -164,6 +164,11 @@ template <typename F> inline void launch(unsigned grid, unsigned block, F body)
 #define __launch_bounds__(...)
 #define __shared__ static
 #define MSDA_DYNAMIC_LDS(type, name) type *name = reinterpret_cast<type *>(emu::group()->lds)
+#define MSDA_DYNAMIC_LDS_ALIGNED(type, name, n) MSDA_DYNAMIC_LDS(type, name)
+#define MSDA_DYNAMIC_LDS_PLAIN(type, name) MSDA_DYNAMIC_LDS(type, name)
+#define MSDA_ASM_OPAQUE(x) do { } while (0)
+#define MSDA_GLOBAL_LOAD_LDS16(src, lds_base)                                                                        \
+    std::memcpy(emu::lds_ptr(MSDA_LDS_BYTE_ADDR(lds_base) + 16u * (unsigned)emu::lane()), (src), 16)
 #define MSDA_LDS_BYTE_ADDR(p) ((unsigned)((const unsigned char *)(p) - emu::group()->lds))
 #define MSDA_ASM_WAIT_VM() do { } while (0)
 #define MSDA_ASM_FENCE() do { } while (0)
@@ -173,6 +178,7 @@ struct emu_idx { int x, y, z; };
 #define threadIdx (emu_idx{emu::tid_ref(), 0, 0})
 #define blockIdx (emu_idx{emu::group()->block_idx, 0, 0})
 #define blockDim (emu_idx{emu::group()->block_dim, 1, 1})
+#define gridDim (emu_idx{emu::group()->grid_dim, 1, 1})
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 typedef void *hipStream_t;
 typedef int hipError_t;
@@ -180,6 +186,7 @@ constexpr int hipSuccess = 0;
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 0;
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 #define HIP_SYMBOL(x) x
 template <typename T> inline hipError_t hipMemcpyToSymbol(T &sym, const void *src, size_t n) { std::memcpy(&sym, src, n); return 0; }
 template <typename T> inline hipError_t hipMemcpyFromSymbol(void *dst, const T &sym, size_t n) { std::memcpy(dst, &sym, n); return 0; }
@@ -189,6 +196,10 @@ template <typename T> inline hipError_t hipMemcpyFromSymbol(void *dst, const T &
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct uint2 { uint32_t x, y; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+inline int2 make_int2(int x, int y) { return {x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 inline float2 make_float2(float x, float y) { return {x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
@@ -199,11 +210,13 @@ inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); retu
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((uint64_t)(a & 0xffffffu) * (b & 0xffffffu)); }
 inline int __mul24(int a, int b) { return (int)((int64_t)((a << 8) >> 8) * ((b << 8) >> 8)); }
 inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
 inline unsigned long long clock64() { return 0; }
+inline float __expf(float x) { return expf(x); }      // (the device's fast exp: a few ulp apart; tolerances of the tests cover it)
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
@@ -214,6 +227,20 @@ inline float min(float a, float b) { return fminf(a, b); }
 inline float max(float a, float b) { return fmaxf(a, b); }
 inline void __syncthreads() { emu::group()->bar.wait(); }
 template <typename T> inline T __shfl_xor(T v, int mask, int = 64) { return emu::shfl_xor(v, mask); }
+template <typename T> inline T emu_shfl_from(T v, int src)      // every lane names its source lane (out of range: itself)
+{
+    uint64_t u = 0;
+    std::memcpy(&u, &v, sizeof(T));
+    emu::publish(emu::WAVE, u);
+    const uint64_t o = emu::wave().slot[(src >= 0 && src < 64) ? src : emu::lane()][0];
+    T r;
+    std::memcpy(&r, &o, sizeof(T));
+    emu::done(emu::WAVE);
+    return r;
+}
+template <typename T> inline T __shfl(T v, int src, int = 64) { return emu_shfl_from(v, src & 63); }
+template <typename T> inline T __shfl_up(T v, unsigned d, int = 64) { return emu_shfl_from(v, emu::lane() - (int)d); }
+template <typename T> inline T __shfl_down(T v, unsigned d, int = 64) { return emu_shfl_from(v, emu::lane() + (int)d); }
 
 template <typename T> inline T emu_atomic_rmw(T *p, T v, T (*op)(T, T))
 {
@@ -226,6 +253,9 @@ inline int atomicMin(int *p, int v) { return emu_atomic_rmw<int>(p, v, [](int a,
 inline int atomicMax(int *p, int v) { return emu_atomic_rmw<int>(p, v, [](int a, int b) { return a > b ? a : b; }); }
 inline int atomicOr(int *p, int v) { return emu_atomic_rmw<int>(p, v, [](int a, int b) { return a | b; }); }
 inline uint32_t atomicOr(uint32_t *p, uint32_t v) { return emu_atomic_rmw<uint32_t>(p, v, [](uint32_t a, uint32_t b) { return a | b; }); }
+inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return emu_atomic_rmw<uint32_t>(p, v, [](uint32_t a, uint32_t b) { return a + b; }); }
+inline uint32_t atomicMax(uint32_t *p, uint32_t v) { return emu_atomic_rmw<uint32_t>(p, v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+inline uint32_t atomicMin(uint32_t *p, uint32_t v) { return emu_atomic_rmw<uint32_t>(p, v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
 inline int atomicAdd(int *p, int v) { return emu_atomic_rmw<int>(p, v, [](int a, int b) { return a + b; }); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
 {
@@ -315,3 +345,7 @@ template <typename V> inline emu_f32x4 emu_mfma16(V a, V b, emu_f32x4 c)
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma16(a, b, c)
+
+// the two inline-assembly helpers of msda_patch.hip
+inline emu_s16x4 lds_tr_read(unsigned addr) { return emu_tr_read(addr, 0); }
+inline emu_s16x4 lds_tr_read32(unsigned addr) { return emu_tr_read(addr, 32); }

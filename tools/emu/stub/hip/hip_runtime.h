@@ -15,6 +15,8 @@
 //   raw_buffer_load_b128         offset >= num_records returns zeros
 #pragma once
 #include <atomic>
+#include <barrier>
+#include <memory>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -28,18 +30,10 @@
 
 namespace emu {
 
-struct Barrier {
-    std::mutex m;
-    std::condition_variable cv;
-    int n = 1, count = 0, gen = 0;
-    void reset(int n_) { n = n_; count = 0; }
-    void wait()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        const int g = gen;
-        if (++count == n) { count = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
-    }
+struct Barrier {                                   // std::barrier (futex-based, no thundering-herd mutex) behind reset()
+    std::unique_ptr<std::barrier<>> b;
+    void reset(int n) { b = std::make_unique<std::barrier<>>(n); }
+    void wait() { b->arrive_and_wait(); }
 };
 
 constexpr int kMaxThreads = 1024, kLdsBytes = 160 * 1024;

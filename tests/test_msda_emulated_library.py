@@ -158,3 +158,87 @@ def test_goldens_bfloat16(lib, case):
     if case == "model_enc":
         out = lib.run("cell", None, BF16, g)[0]
         np.testing.assert_allclose(out, ref_out, rtol=2.0 ** -7, atol=1e-3 * float(np.abs(ref_out).max()))
+
+
+def _encoder_problem(pyr, N, M, seed, uniform=False):
+    rng = np.random.default_rng(seed)
+    pyr = np.asarray(pyr, dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
+    S = int((pyr[:, 0] * pyr[:, 1]).sum())
+    ref = []
+    for H, W in pyr:
+        ys, xs = np.meshgrid((np.arange(H) + 0.5) / H, (np.arange(W) + 0.5) / W, indexing="ij")
+        ref.append(np.stack([xs.ravel(), ys.ravel()], -1))
+    ref = np.concatenate(ref, 0)                                                     # [S, 2]
+    value = bf16_val(bf16_bits(rng.standard_normal((N, S, M, 32)) * 0.5)).astype(np.float32)
+    grad_out = bf16_val(bf16_bits(rng.standard_normal((N, S, M * 32)))).astype(np.float32)
+    return pyr, starts, S, ref, value, grad_out, rng
+
+
+def test_fused_geometry_route_of_the_train_step(lib):
+    """msda_fused_forward / msda_fused_backward_ws on a bfloat16 encoder call (the route FusedMSDeformAttnFunction takes in
+    the train step: geometry as prologue of the gather kernel and as epilogue of cell_backward_kernel, grad_value from
+    patch_dest_kernel) against the oracle fed with float64 locations / weights from the same projection rows."""
+    M, L, P = 2, 4, 4
+    pyr, starts, S, ref2, value, grad_out, rng = _encoder_problem([(20, 27), (10, 14), (5, 7), (3, 4)], 1, M, seed=21)
+    N, Lq = 1, S
+    qproj = rng.standard_normal((N, Lq, M * L * P * 3))
+    qproj[..., :M * L * P * 2] *= 2.0                                                # offsets of a few pixels
+    qproj = bf16_val(bf16_bits(qproj)).astype(np.float32)
+    ref = np.ascontiguousarray(np.broadcast_to(ref2[None, :, None, :], (N, Lq, L, 2)), dtype=np.float32)
+    vb, qb, gob = bf16_bits(value), bf16_bits(qproj), bf16_bits(grad_out)
+    dims = (N, S, M, 32, L, Lq, P)
+    p = lambda a: a.ctypes.data                                                       # noqa: E731
+    Lb = lib.L
+    assert Lb.msda_fused_supported(BF16, p(pyr), 2, *dims) == 2
+    out = np.zeros((N, Lq, M * 32), dtype=np.uint16)
+    loc = np.full((N, Lq, M, L, P, 2), np.nan, dtype=np.float32)
+    aw = np.full((N, Lq, M, L, P), np.nan, dtype=np.float32)
+    assert Lb.msda_fused_forward(BF16, p(vb), p(pyr), p(starts), p(qb), p(ref), 2, *dims, p(out), p(loc), p(aw), None) == 0
+    ws_bytes = Lb.msda_backward_workspace_bytes(BF16, p(pyr), *dims)
+    assert ws_bytes > 0
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    gv, gq = np.zeros(vb.shape, dtype=np.uint16), np.zeros(qb.shape, dtype=np.uint16)
+    assert Lb.msda_fused_backward_ws(FLAG_BF16_GV, BF16, p(vb), p(pyr), p(starts), p(pyr), p(loc), p(aw), p(ref), 2, p(gob),
+                                     *dims, p(gv), p(gq), p(ws), ws_bytes, None) == 0
+    # float64 restatement of ms_deform_attn.py:101-109
+    qd = qproj.astype(np.float64)
+    off = qd[..., :M * L * P * 2].reshape(N, Lq, M, L, P, 2)
+    lg = qd[..., M * L * P * 2:].reshape(N, Lq, M, L * P)
+    e = np.exp(lg - lg.max(-1, keepdims=True))
+    awd = (e / e.sum(-1, keepdims=True)).reshape(N, Lq, M, L, P)
+    norm = np.stack([pyr[:, 1], pyr[:, 0]], -1).astype(np.float64)
+    locd = ref.astype(np.float64)[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    np.testing.assert_allclose(loc, locd, rtol=1e-5, atol=1e-6)                      # what the forward saved for the backward
+    np.testing.assert_allclose(aw, awd, rtol=1e-4, atol=1e-6)
+    a = (value.astype(np.float64), pyr, starts, locd, awd)
+    ref_out = O.forward(*a)
+    ref_gv, ref_gl, ref_ga = O.backward(*a, grad_out.astype(np.float64))
+    tol = 2.0 ** -7
+    assert np.abs(bf16_val(out) - ref_out).max() <= tol * np.abs(ref_out).max()
+    assert np.abs(bf16_val(gv) - ref_gv).max() <= tol * np.abs(ref_gv).max()
+    g_off = ref_gl / norm[None, None, None, :, None, :]
+    g_logit = awd * (ref_ga - (awd * ref_ga).sum((-1, -2), keepdims=True))
+    ref_gq = np.concatenate([g_off.reshape(N, Lq, -1), g_logit.reshape(N, Lq, -1)], -1)
+    keep = np.broadcast_to(~kink_samples({"loc": locd, "shapes": pyr}, 1e-3)[..., None], ref_gl.shape).reshape(N, Lq, -1)
+    keep = np.concatenate([keep, np.ones((N, Lq, M * L * P), dtype=bool)], -1)
+    assert np.abs(bf16_val(gq) - ref_gq)[keep].max() <= 2.0 ** -6 * np.abs(ref_gq).max()
+
+
+def test_samples_out_of_reach_take_the_sorting_pass_within_the_same_call(lib):
+    """bfloat16 encoder call whose samples leave their cell's neighbourhood (uniform random locations): the device-side
+    "far" flag must hand grad_value to the sorting pass (bin / dest / combine kernels, gated launches) with no host decision
+    -- and the result must be the oracle's either way."""
+    M = 1
+    pyr, starts, S, ref2, value, grad_out, rng = _encoder_problem([(40, 54), (20, 27), (10, 14), (5, 7)], 1, M, seed=31)
+    loc = rng.random((1, S, M, 4, 4, 2)).astype(np.float32)                         # anywhere in the image
+    aw = rng.random((1, S, M, 4, 4))
+    aw = (aw / aw.sum((-1, -2), keepdims=True)).astype(np.float32)
+    g = dict(value=value, loc=loc, aw=aw, grad_out=grad_out, shapes=pyr, starts=starts)
+    a = (value.astype(np.float64), pyr, starts, loc.astype(np.float64), aw.astype(np.float64))
+    ref_gv, ref_gl, ref_ga = O.backward(*a, grad_out.astype(np.float64))
+    out, gv, gl, ga = lib.run("quad", "dest", BF16, g)
+    np.testing.assert_allclose(gv, ref_gv, rtol=2.0 ** -7, atol=1e-3 * float(np.abs(ref_gv).max()))
+    close32(ga, ref_ga)
+    keep = ~kink_samples(g)
+    close32(gl[keep], ref_gl[keep])

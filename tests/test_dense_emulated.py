@@ -1,0 +1,151 @@
+"""Dense helper kernels of the train step -- fused clip + AdamW (csrc/fused_adamw.hip), residual add + LayerNorm forward and
+backward (csrc/add_layernorm.hip), the backbone's add + ReLU / affine + ReLU tails (csrc/elementwise.hip) -- built for the
+CPU against the lane-level workgroup model (tools/emu/build_dense_lib.sh: the same sources hipcc compiles) and checked against
+float32 PyTorch, the checker of their GPU tests (tests/test_optim_gpu.py, test_norm_gpu.py, test_linear_gpu.py).  Kernel logic
+without a GPU; test infrastructure only -- the product has no CPU path."""
+import ctypes
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_cell_forward_emulated import CLANG  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang++ as host compiler")
+vp, ci = ctypes.c_void_p, ctypes.c_int
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("emu_dense") / "libdense_emu.so")
+    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_dense_lib.sh"), so], check=True, capture_output=True, timeout=900)
+    return ctypes.CDLL(so)
+
+
+def ptr(t):
+    return t.data_ptr()
+
+
+class _Group(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("beta1", "beta2", "one_minus_beta1", "one_minus_beta2", "eps", "decay",
+                                              "step_size", "bias_correction2_sqrt")]
+
+
+@pytest.mark.parametrize("max_norm,grad_scale", [(0.1, 1.0), (0.0, 1.0), (0.1, 0.25)])
+def test_fused_adamw_against_torch(lib, max_norm, grad_scale):
+    """two parameter groups, tensors of 1 / 37*5 / 2.4 chunks, four steps with gradients of very different size; grad_scale:
+    the data-parallel SUM route (the kernels multiply, the reference gets pre-scaled gradients)"""
+    sizes = ctypes.c_int * 4
+    s = sizes()
+    lib.adamw_abi_sizes(ctypes.byref(s, 0), ctypes.byref(s, 4), ctypes.byref(s, 8), ctypes.byref(s, 12))
+    assert (s[0], s[1], s[2]) == (56, 8, ctypes.sizeof(_Group))
+    chunk = s[3]
+    torch.manual_seed(0)
+    shapes, group_of, lrs = [(1,), (37, 5), (300, 129)], [0, 1, 0], [1e-2, 5e-3]
+    wd, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    master = [torch.randn(sh) for sh in shapes]
+    params = [m.to(torch.bfloat16) for m in master]
+    master = [p.float().clone() for p in params]
+    m1 = [torch.zeros_like(m) for m in master]
+    m2 = [torch.zeros_like(m) for m in master]
+    ref_params = [m.clone().requires_grad_(True) for m in master]
+    ref = torch.optim.AdamW([{"params": [ref_params[0], ref_params[2]]}, {"params": [ref_params[1]], "lr": lrs[1]}],
+                            lr=lrs[0], weight_decay=wd, betas=(b1, b2), eps=eps)
+    grads = [torch.zeros(sh, dtype=torch.bfloat16) for sh in shapes]
+    rows = np.array([[ptr(g), ptr(m), ptr(a), ptr(b), ptr(p), p.numel(), gi]
+                     for g, m, a, b, p, gi in zip(grads, master, m1, m2, params, group_of)], dtype=np.int64)
+    chunks = np.array([(r, c) for r, p in enumerate(params) for c in range((p.numel() + chunk - 1) // chunk)], dtype=np.int32)
+    sq = torch.zeros(1)
+    lib.adamw_grad_sqnorm_bf16.argtypes = [vp, vp, ci, vp, vp]
+    lib.adamw_step_scaled_bf16.argtypes = [vp, vp, ci, vp, ctypes.c_float, ctypes.c_float, vp, ci, vp]
+    gen = torch.Generator().manual_seed(1)
+    for step in range(1, 5):
+        for g, r in zip(grads, ref_params):
+            g.copy_((torch.randn(g.shape, generator=gen) * (10.0 if step % 2 else 0.01)).to(torch.bfloat16))
+            r.grad = g.float() * grad_scale
+        if max_norm > 0:
+            total = torch.nn.utils.clip_grad_norm_(ref_params, max_norm)
+        ref.step()
+        groups = (_Group * 2)()
+        for gi, lr in enumerate(lrs):
+            groups[gi] = _Group(b1, b2, 1.0 - b1, 1.0 - b2, eps, 1.0 - lr * wd, lr / (1.0 - b1 ** step),
+                                math.sqrt(1.0 - b2 ** step))
+        if max_norm > 0:
+            assert lib.adamw_grad_sqnorm_bf16(rows.ctypes.data, chunks.ctypes.data, len(chunks), ptr(sq), None) == 0
+            torch.testing.assert_close(sq.sqrt()[0] * grad_scale, total, rtol=1e-5, atol=0)
+        assert lib.adamw_step_scaled_bf16(rows.ctypes.data, chunks.ctypes.data, len(chunks), ptr(sq), max_norm, grad_scale,
+                                          groups, 2, None) == 0
+        for m, p, r in zip(master, params, ref_params):
+            torch.testing.assert_close(m, r.detach(), rtol=5e-6, atol=1e-6 * float(r.detach().abs().max()))
+            assert torch.equal(p, m.to(torch.bfloat16))
+    for i, r in enumerate(ref_params):
+        st = ref.state[r]
+        torch.testing.assert_close(m1[i], st["exp_avg"], rtol=5e-6, atol=1e-6 * float(st["exp_avg"].abs().max()))
+        # (the host build has no fused multiply-add: one more rounding per step in b2 * v + (1 - b2) * g * g than the device)
+        torch.testing.assert_close(m2[i], st["exp_avg_sq"], rtol=2e-5, atol=1e-6 * float(st["exp_avg_sq"].abs().max()))
+
+
+@pytest.mark.parametrize("rows,with_b", [(700, True), (129, False)])
+def test_add_layernorm_forward_and_backward_against_torch(lib, rows, with_b):
+    C, eps = 256, 1e-5
+    assert lib.add_layernorm_supported(ctypes.c_long(rows), C) == 1
+    torch.manual_seed(2)
+    a = torch.randn(rows, C).to(torch.bfloat16)
+    b = torch.randn(rows, C).to(torch.bfloat16) if with_b else None
+    gamma = (1.0 + 0.1 * torch.randn(C)).to(torch.bfloat16)
+    beta = (0.1 * torch.randn(C)).to(torch.bfloat16)
+    dy = torch.randn(rows, C).to(torch.bfloat16)
+    y = torch.empty_like(a)
+    mean, rstd = torch.empty(rows), torch.empty(rows)
+    lib.add_layernorm_forward_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_long, ci, ctypes.c_float, vp, vp, vp, vp]
+    assert lib.add_layernorm_forward_bf16(ptr(a), ptr(b) if with_b else None, ptr(gamma), ptr(beta), rows, C, eps, ptr(y),
+                                          ptr(mean), ptr(rstd), None) == 0
+    x = (a.float() + (b.float() if with_b else 0)).requires_grad_(True)
+    g32, b32 = gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x, (C,), g32, b32, eps)
+    torch.testing.assert_close(y.float(), ref.detach(), rtol=2.0 ** -7, atol=2.0 ** -7)        # one bfloat16 rounding
+    torch.testing.assert_close(mean, x.detach().mean(1), rtol=1e-5, atol=1e-6)
+    ref.backward(dy.float())
+    lib.add_layernorm_workspace_bytes.restype = ctypes.c_size_t
+    lib.add_layernorm_workspace_bytes.argtypes = [ctypes.c_long, ci]
+    wsb = lib.add_layernorm_workspace_bytes(rows, C)
+    ws = torch.zeros(max(wsb, 16), dtype=torch.uint8)
+    dx, dgamma, dbeta = torch.empty_like(a), torch.empty_like(gamma), torch.empty_like(beta)
+    lib.add_layernorm_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_long, ci, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    assert lib.add_layernorm_backward_bf16(ptr(dy), ptr(a), ptr(b) if with_b else None, ptr(gamma), ptr(mean), ptr(rstd), rows,
+                                           C, ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), wsb, None) == 0
+    tol = dict(rtol=2.0 ** -6, atol=2.0 ** -6)
+    torch.testing.assert_close(dx.float(), x.grad, rtol=2.0 ** -6, atol=2.0 ** -6 * float(x.grad.abs().max()))
+    torch.testing.assert_close(dgamma.float(), g32.grad, rtol=2.0 ** -6, atol=2.0 ** -6 * float(g32.grad.abs().max()))
+    torch.testing.assert_close(dbeta.float(), b32.grad, rtol=2.0 ** -6, atol=2.0 ** -6 * float(b32.grad.abs().max()))
+    del tol
+
+
+def test_elementwise_tails_against_torch(lib):
+    torch.manual_seed(3)
+    n, C = 8 * 1000 + 8 * 3, 64                                     # (multiples of 8 elements: the kernels' vector width)
+    a, b = torch.randn(n).to(torch.bfloat16), torch.randn(n).to(torch.bfloat16)
+    y = torch.empty_like(a)
+    lib.add_relu_bf16.argtypes = [vp, vp, vp, ctypes.c_long, vp]
+    assert lib.add_relu_bf16(ptr(a), ptr(b), ptr(y), n, None) == 0
+    assert torch.equal(y, torch.relu(a.float() + b.float()).to(torch.bfloat16))
+    rows = 200
+    x = torch.randn(rows, C).to(torch.bfloat16)
+    scale, bias = (1 + 0.2 * torch.randn(C)).to(torch.bfloat16), torch.randn(C).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    lib.affine_relu_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_long, ci, vp]
+    assert lib.affine_relu_bf16(ptr(x), ptr(scale), ptr(bias), ptr(y), rows * C, C, None) == 0
+    ref = torch.relu(x.float() * scale.float() + bias.float())
+    torch.testing.assert_close(y.float(), ref, rtol=2.0 ** -7, atol=2.0 ** -8)
+    dy = torch.randn(rows, C).to(torch.bfloat16)
+    dx = torch.empty_like(x)
+    lib.affine_relu_backward_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_long, ci, vp]
+    assert lib.affine_relu_backward_bf16(ptr(dy), ptr(y), ptr(scale), ptr(dx), rows * C, C, None) == 0
+    refdx = dy.float() * scale.float() * (y.float() > 0)
+    torch.testing.assert_close(dx.float(), refdx, rtol=2.0 ** -7, atol=2.0 ** -8)

@@ -39,9 +39,9 @@ struct Barrier {                                   // std::barrier (futex-based,
 constexpr int kMaxThreads = 1024, kLdsBytes = 160 * 1024;
 
 struct Wave {
-    Barrier quad[16], row[4], all;
+    Barrier quad[16], row[4], half[2], all;
     uint64_t slot[64][8];
-    Wave() { for (auto &b : quad) b.reset(4); for (auto &b : row) b.reset(16); all.reset(64); }
+    Wave() { for (auto &b : quad) b.reset(4); for (auto &b : row) b.reset(16); for (auto &b : half) b.reset(32); all.reset(64); }
 };
 
 struct Group {
@@ -60,11 +60,11 @@ inline int &tid_ref() { thread_local int t = 0; return t; }
 inline int lane() { return tid_ref() & 63; }
 inline Wave &wave() { return group()->waves[tid_ref() >> 6]; }
 
-enum Scope { QUAD, ROW, WAVE };
+enum Scope { QUAD, ROW, HALF, WAVE };
 inline Barrier &barrier_of(Scope s)
 {
     Wave &w = wave();
-    return s == QUAD ? w.quad[lane() >> 2] : s == ROW ? w.row[lane() >> 4] : w.all;
+    return s == QUAD ? w.quad[lane() >> 2] : s == ROW ? w.row[lane() >> 4] : s == HALF ? w.half[lane() >> 5] : w.all;
 }
 inline uint64_t *publish(Scope s, uint64_t a, uint64_t b = 0, uint64_t c = 0, uint64_t d = 0)
 {
@@ -116,13 +116,16 @@ inline unsigned long long ballot(bool p)
 }
 template <typename T> inline T shfl_xor(T v, int mask)
 {
+    // a butterfly that stays inside a quad / row / half-wave only needs those lanes (kernels run it in control flow that is
+    // uniform per half-wave: two rows of a LayerNorm per wave with different trip counts)
+    const Scope s = mask < 4 ? QUAD : mask < 16 ? ROW : mask < 32 ? HALF : WAVE;
     uint64_t u = 0;
     std::memcpy(&u, &v, sizeof(T));
-    publish(WAVE, u);
+    publish(s, u);
     const uint64_t o = wave().slot[lane() ^ mask][0];
     T r;
     std::memcpy(&r, &o, sizeof(T));
-    done(WAVE);
+    done(s);
     return r;
 }
 inline unsigned char *lds_ptr(unsigned addr)
@@ -210,6 +213,16 @@ inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
 inline unsigned long long clock64() { return 0; }
+template <typename T> inline T min(T a, T b) { return a < b ? a : b; }
+template <typename T> inline T max(T a, T b) { return a > b ? a : b; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __frcp_rn(float a) { return 1.0f / a; }
+inline long long min(long long a, long long b) { return a < b ? a : b; }
+inline long long max(long long a, long long b) { return a > b ? a : b; }
+inline unsigned long min(unsigned long a, unsigned long b) { return a < b ? a : b; }
+inline unsigned long max(unsigned long a, unsigned long b) { return a > b ? a : b; }
 inline float __expf(float x) { return expf(x); }      // (the device's fast exp: a few ulp apart; tolerances of the tests cover it)
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }

@@ -149,3 +149,22 @@ def test_elementwise_tails_against_torch(lib):
     assert lib.affine_relu_backward_bf16(ptr(dy), ptr(y), ptr(scale), ptr(dx), rows * C, C, None) == 0
     refdx = dy.float() * scale.float() * (y.float() > 0)
     torch.testing.assert_close(dx.float(), refdx, rtol=2.0 ** -7, atol=2.0 ** -8)
+
+
+def test_dab_box_refinement_against_the_reference_formula(lib):
+    """dab_refine_boxes: sigmoid(delta + inverse_sigmoid(ref)) with the reference's clamp and eps (util/misc.py:460-464,
+    dab_deformable/deformable_transformer.py:1511-1541), float32 and bfloat16 deltas, values on and beyond the clamp"""
+    torch.manual_seed(4)
+    rows, eps = 301, 1e-5
+    ref = torch.rand(rows, 4)
+    ref[0] = torch.tensor([0.0, 1.0, -0.2, 1.3])                         # clamped to [0, 1], then eps
+    for bf16 in (0, 1):
+        delta = torch.randn(rows, 4) * 2
+        d = delta.to(torch.bfloat16) if bf16 else delta
+        out = torch.empty(rows, 4)
+        lib.dab_refine_boxes.argtypes = [vp, ci, vp, vp, ctypes.c_long, ctypes.c_float, vp]
+        assert lib.dab_refine_boxes(ptr(d), bf16, ptr(ref), ptr(out), rows, eps, None) == 0
+        x = ref.clamp(0, 1)
+        inv = torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+        want = torch.sigmoid(d.float() + inv)
+        torch.testing.assert_close(out, want, rtol=2e-6, atol=1e-7)

@@ -2,14 +2,14 @@
 criterion, forward and backward under the autograd profiler.  Every aten operator that computes (views excluded) is one
 kernel launch on the GPU, so this counts -- without a GPU -- what the decoders, heads and criterion add to the launch tail
 of the train step (the fused HIP functions are replaced by their torch twins here and are not what this is about).
-usage: python tools/cpu_census.py [dec_layers]"""
+usage: python tests/scripts/cpu_census.py [dec_layers]   (lives under tests/: it runs the modules with the oracle-backed op)"""
 import collections
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))

@@ -797,7 +797,8 @@ __device__ __forceinline__ void quad_rotate4(float4 &v)
 
 // MODE (experiments, ablation build only): 0 = the product kernel, 1 = sample geometry once per quad
 // (cell_level_shared), 2 = that + the operand swap of cell_corner_dot, 3 = that + the window copies issued up front
-// + level starts as scalars in the binning
+// + level starts as scalars in the binning, 4 = mode 3 without the operand swap (every primitive then is one the product
+// kernel already runs on the hardware)
 template <int REFDIM, int MODE>
 __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
     PatchPlan pl, const bf16_t *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
             const bool own = crn == l;
             if (MODE != 0) {                     // (experiment, off by default: geometry once per quad)
                 float4 ra, rb, rw;
-                cell_level_shared<MODE >= 2>(clds, vr, g, la, lb, wa, H, W, x0w, y0w, pitch, base, lvl_byte, row_bytes, crn, rot, ra, rb, rw);
+                cell_level_shared<MODE == 2 || MODE == 3>(clds, vr, g, la, lb, wa, H, W, x0w, y0w, pitch, base, lvl_byte, row_bytes, crn, rot, ra, rb, rw);
                 if (own) { gla = ra; glb = rb; ga = rw; }
                 quad_rotate4(la); quad_rotate4(lb); quad_rotate4(wa);
                 continue;
@@ -1252,7 +1253,7 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
 #define MSDA_CELL(RD)                                                                                                 \
     do {                                                                                                              \
         if (mode == 1) MSDA_CELL_K(RD, 1); else if (mode == 2) MSDA_CELL_K(RD, 2);                                    \
-        else if (mode == 3) MSDA_CELL_K(RD, 3); else MSDA_CELL_K(RD, 0);                                              \
+        else if (mode == 3) MSDA_CELL_K(RD, 3); else if (mode == 4) MSDA_CELL_K(RD, 4); else MSDA_CELL_K(RD, 0);      \
     } while (0)
 #else
 #define MSDA_CELL(RD) MSDA_CELL_K(RD, kCellMode)

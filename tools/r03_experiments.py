@@ -18,7 +18,7 @@ from tools.msda_inputs import PYRAMID_800x1333, make_inputs  # noqa: E402
 from tools.patch_check import timed  # noqa: E402
 
 ARMS = [("default", {}), ("cell 1 shared", {"RLIPV2_CELL_SHARED": "1"}), ("cell 2 +swap", {"RLIPV2_CELL_SHARED": "2"}),
-        ("cell 3 +loads", {"RLIPV2_CELL_SHARED": "3"}),
+        ("cell 3 +loads", {"RLIPV2_CELL_SHARED": "3"}), ("cell 4 no swap", {"RLIPV2_CELL_SHARED": "4"}),
         ("patch multi1", {"RLIPV2_PATCH_MULTI": "1"}),
         ("patch reps2", {"RLIPV2_PATCH_REPS": "2"}), ("patch reps3", {"RLIPV2_PATCH_REPS": "3"}),
         ("patch reps4", {"RLIPV2_PATCH_REPS": "4"}), ("patch reps8", {"RLIPV2_PATCH_REPS": "8"}),

@@ -196,6 +196,15 @@ int msda_fused_forward(int dtype,
                        const void *qproj, const float *ref, int refdim,
                        int N, int S, int M, int D, int L, int Lq, int P,
                        void *out, float *loc_save, float *aw_save, void *stream);
+/* msda_fused_forward with an explicit kernel choice and the host copy of the level shapes: MSDA_VARIANT_AUTO is
+ * msda_fused_forward; MSDA_VARIANT_CELL (experimental, see the enum) needs loc_save / aw_save -- it is the train step's
+ * forward, whose saved locations / weights the backward pass reads -- and a bfloat16 encoder call (Lq == S). */
+int msda_fused_forward_hs(int variant, int dtype,
+                          const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                          const int64_t *spatial_shapes_host,
+                          const void *qproj, const float *ref, int refdim,
+                          int N, int S, int M, int D, int L, int Lq, int P,
+                          void *out, float *loc_save, float *aw_save, void *stream);
 int msda_fused_backward_ws(int flags, int dtype,
                            const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
                            const int64_t *spatial_shapes_host,

@@ -24,7 +24,7 @@ EXPORTS = (
     "msda_forward", "msda_backward", "msda_forward_ex", "msda_backward_ex", "msda_check_im2col_step",
     "msda_algorithmic_bytes", "msda_strerror", "msda_abi_version", "msda_variant_name", "msda_pick_variant",
     "msda_prepare_forward", "msda_prepare_backward", "msda_backward_workspace_bytes", "msda_backward_ws",
-    "msda_backward_plan_info", "msda_forward_hs",
+    "msda_backward_plan_info", "msda_forward_hs", "msda_fused_forward_hs",
     "msda_fused_supported", "msda_fused_forward", "msda_fused_backward_ws",
     # include/rlipv2_linear.h
     "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
@@ -80,6 +80,8 @@ def lib() -> ctypes.CDLL:
     L.msda_backward_workspace_bytes.restype = ctypes.c_size_t
     L.msda_forward_hs.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *dims, vp, vp]
     L.msda_forward_hs.restype = i
+    L.msda_fused_forward_hs.argtypes = [i, i, vp, vp, vp, vp, vp, vp, i, *dims, vp, vp, vp, vp]
+    L.msda_fused_forward_hs.restype = i
     L.msda_backward_plan_info.argtypes = [i, vp, *dims, vp, i]
     L.msda_backward_plan_info.restype = i
     L.msda_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, *dims, vp, vp, vp, vp, ctypes.c_size_t, vp]

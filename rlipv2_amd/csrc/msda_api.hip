@@ -242,7 +242,7 @@ int msda_forward_hs(int variant, int dtype, const void *value, const int64_t *sp
     if (L > 0 && !dest_shapes_consistent(p, spatial_shapes_host)) return MSDA_ERR_BAD_SHAPE;
     if (!cell_forward_supports(p, spatial_shapes_host)) return MSDA_ERR_BAD_VARIANT;
     (void)hipGetLastError();
-    launch_cell_forward(p, spatial_shapes_host);
+    launch_cell_forward(p, spatial_shapes_host, nullptr);
     return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
 }
 
@@ -341,6 +341,29 @@ int msda_fused_forward(int dtype, const void *value, const int64_t *spatial_shap
     f.qproj = qproj; f.ref = ref; f.refdim = refdim; f.loc_save = loc_save; f.aw_save = aw_save;
     (void)hipGetLastError();
     launch_quad_forward_fused(p, f);
+    return finish_launch();
+}
+
+int msda_fused_forward_hs(int variant, int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                          const int64_t *spatial_shapes_host, const void *qproj, const float *ref, int refdim, int N, int S,
+                          int M, int D, int L, int Lq, int P, void *out, float *loc_save, float *aw_save, void *stream)
+{
+    if (variant != MSDA_VARIANT_CELL)
+        return msda_fused_forward(dtype, value, spatial_shapes, level_start, qproj, ref, refdim, N, S, M, D, L, Lq, P, out,
+                                  loc_save, aw_save, stream);
+    if (!msda_fused_supported(dtype, nullptr, refdim, N, S, M, D, L, Lq, P) || !spatial_shapes_host) return MSDA_ERR_BAD_VARIANT;
+    if (!value || !spatial_shapes || !level_start || !qproj || !ref || !out || !loc_save || !aw_save) return MSDA_ERR_NULL_POINTER;
+    if (!(aligned16(value) && aligned16(qproj) && aligned16(ref) && aligned16(out) && aligned16(loc_save) && aligned16(aw_save)))
+        return MSDA_ERR_ALIGNMENT;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.out = out; p.stream = (hipStream_t)stream;
+    if (!dest_shapes_consistent(p, spatial_shapes_host)) return MSDA_ERR_BAD_SHAPE;
+    if (!cell_forward_supports(p, spatial_shapes_host)) return MSDA_ERR_BAD_VARIANT;
+    Fused f{};
+    f.qproj = qproj; f.ref = ref; f.refdim = refdim; f.loc_save = loc_save; f.aw_save = aw_save;
+    (void)hipGetLastError();
+    launch_cell_forward(p, spatial_shapes_host, &f);
     return finish_launch();
 }
 

@@ -88,7 +88,7 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
 bool cell_backward_supports(const Problem &p, const int64_t *shapes_host);
 // forward pass of an encoder call from LDS windows on the matrix cores (explicit variant MSDA_VARIANT_CELL; msda_patch.hip)
 bool cell_forward_supports(const Problem &p, const int64_t *shapes_host);
-void launch_cell_forward(const Problem &p, const int64_t *shapes_host);
+void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fused *f);   // f: fused geometry (saves loc / aw)
 // the plan of the cell + patch route as int32 values (include/rlipv2_msda.h: msda_backward_plan_info); 0 = route not taken
 int patch_plan_info(const Problem &p, const int64_t *shapes_host, int32_t *out, int out_len);
 void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, int *ctl, void *mask_ws);

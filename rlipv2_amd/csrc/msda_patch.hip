@@ -1201,19 +1201,28 @@ bool cell_forward_supports(const Problem &p, const int64_t *shapes_host)
     return true;
 }
 
-// out = forward pass of an encoder call, cell_forward_kernel (explicit variant MSDA_VARIANT_CELL)
-void launch_cell_forward(const Problem &p, const int64_t *shapes_host)
+// out = forward pass of an encoder call, cell_forward_kernel (explicit variant MSDA_VARIANT_CELL); f != nullptr: the module's
+// operands (projection rows + reference points), f->loc_save / f->aw_save receive the float32 locations / weights
+void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fused *f)
 {
     PatchPlan pl;
     make_patch_plan(p, shapes_host, pl);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)cell_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds);
-        attr = true;
-    }
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
-    hipLaunchKernelGGL(cell_forward_kernel, grid, block, kFwdLds, p.stream, pl, (const bf16_t *)p.value, p.starts,
-                       (const float *)p.loc, (const float *)p.aw, p.N, p.S, p.M, p.Lq, (bf16_t *)p.out);
+#define MSDA_CELL_FWD(RD, LOC, AW)                                                                                    \
+    do {                                                                                                              \
+        static bool attr = false;                                                                                     \
+        if (!attr) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void *)cell_forward_kernel<RD>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds); \
+            attr = true;                                                                                              \
+        }                                                                                                             \
+        hipLaunchKernelGGL((cell_forward_kernel<RD>), grid, block, kFwdLds, p.stream, pl, (const bf16_t *)p.value, p.starts, \
+                           (float *)(LOC), (float *)(AW), p.N, p.S, p.M, p.Lq, (bf16_t *)p.out,                       \
+                           (const bf16_t *)(f ? f->qproj : nullptr), f ? f->ref : nullptr, p.shapes);                 \
+    } while (0)
+    if (!f) MSDA_CELL_FWD(0, const_cast<void *>(p.loc), const_cast<void *>(p.aw));      // (REFDIM 0 only reads them)
+    else if (f->refdim == 2) MSDA_CELL_FWD(2, f->loc_save, f->aw_save);
+    else MSDA_CELL_FWD(4, f->loc_save, f->aw_save);
+#undef MSDA_CELL_FWD
 }
 
 bool cell_backward_supports(const Problem &p, const int64_t *shapes_host)

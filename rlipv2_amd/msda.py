@@ -259,23 +259,20 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj
     aw = torch.empty((N, Lq, M, nL, P), dtype=torch.float32, device=value.device) if save else None
     if (_FWD_CELL and save and value.dtype == torch.bfloat16 and Lq == S and nL == 4 and P == 4 and D == 32
             and host_shapes(spatial_shapes) is not None):
-        # EXPERIMENT (RLIPV2_MSDA_FWD_CELL=1; the kernel has not been validated on hardware yet): the saved float32
-        # locations / weights from the geometry kernel (bit-identical to what the fused kernel saves), the sampling from
-        # LDS windows on the matrix cores (csrc/msda_patch.hip: cell_forward_kernel)
+        # EXPERIMENT (RLIPV2_MSDA_FWD_CELL=1; the kernel has not been validated on hardware yet): geometry, the saved float32
+        # locations / weights and the sampling from LDS windows on the matrix cores in one kernel
+        # (csrc/msda_cell_forward.inc: cell_forward_kernel<refdim>)
         hs = host_shapes(spatial_shapes)
         hs_arr = (ctypes.c_int64 * len(hs))(*hs)
         with torch.cuda.device(value.device):
-            stream = torch.cuda.current_stream().cuda_stream
-            st = L.msda_prepare_forward(_DTYPES[qproj.dtype], qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
-                                        spatial_shapes.data_ptr(), N * Lq, M, nL, P, loc.data_ptr(), aw.data_ptr(), stream)
-            if not st:
-                st = L.msda_forward_hs(_lib.VARIANT_CELL, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
-                                       level_start_index.data_ptr(), hs_arr, loc.data_ptr(), aw.data_ptr(),
-                                       N, S, M, D, nL, Lq, P, out.data_ptr(), stream)
+            st = L.msda_fused_forward_hs(_lib.VARIANT_CELL, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                                         level_start_index.data_ptr(), hs_arr, qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
+                                         N, S, M, D, nL, Lq, P, out.data_ptr(), loc.data_ptr(), aw.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
         if st:
             _raise(st)
         roofline.add(roofline.tensor_bytes(value, qproj, ref, out, loc, aw))
-        last_variant["fwd"] = "geometry, cell"
+        last_variant["fwd"] = "cell+geometry"
         return out, loc, aw
     with torch.cuda.device(value.device):
         st = L.msda_fused_forward(_DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),

@@ -1,7 +1,7 @@
 """The DEVICE SOURCE of cell_forward_kernel (rlipv2_amd/csrc/msda_cell_forward.inc -- the very file hipcc compiles into the
-library) executed on the CPU against a lane-level model of a gfx950 workgroup (tools/emu/cell_forward_emu.cpp: a host thread
-per lane, LDS as a byte array, DPP / readfirstlane / transposing LDS read / 4x4x4 MFMA as wave rendezvous with the semantics
-measured on the hardware), checked against the oracle.  This pins the kernel's logic -- indexing, window staging with its
+library) executed on the CPU against the lane-level model of a gfx950 workgroup (tools/emu/: a host thread per lane, LDS as
+a byte array, DPP / readfirstlane / transposing LDS read / 4x4x4 MFMA as rendezvous with the semantics measured on the
+hardware) through the library's own C ABI (msda_forward_hs, variant "cell"), checked against the oracle.  This pins the kernel's logic -- indexing, window staging with its
 zero border, records, operand placement, the plain-load route of a level that does not fit, the store pattern -- without a
 GPU; what it cannot pin is the compiler's code generation and the hardware itself (tests/test_msda_cell_forward_gpu.py)."""
 import os
@@ -21,10 +21,14 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROC
 
 @pytest.fixture(scope="module")
 def emulator(tmp_path_factory):
-    exe = str(tmp_path_factory.mktemp("emu") / "cell_forward_emu")
-    src = os.path.join(ROOT, "tools", "emu", "cell_forward_emu.cpp")
-    subprocess.run([CLANG, "-std=c++20", "-O1", "-pthread", src, "-o", exe], check=True, capture_output=True, timeout=300)
-    return exe
+    """the MSDA library built for the workgroup model (tools/emu/build_lib.sh); the kernel is reached through its C ABI"""
+    import ctypes
+    so = str(tmp_path_factory.mktemp("emu") / "libmsda_emu.so")
+    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900)
+    L = ctypes.CDLL(so)
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    L.msda_forward_hs.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *([i] * 7), vp, vp]
+    return L
 
 
 def bf16_bits(x):
@@ -58,16 +62,15 @@ def make_problem(pyr, M, spread, seed):
     return pyr, starts, S, value.astype(np.float32), loc.astype(np.float32), aw.astype(np.float32)
 
 
-def run_emulator(exe, tmp_path, pyr, starts, S, M, value, loc, aw):
-    prob, outp = str(tmp_path / "problem.bin"), str(tmp_path / "out.bin")
-    with open(prob, "wb") as f:
-        f.write(np.asarray([1, S, M, S] + [int(v) for hw in pyr for v in hw], dtype=np.int32).tobytes())
-        f.write(bf16_bits(value).tobytes())
-        f.write(starts.astype(np.int64).tobytes())
-        f.write(loc.astype(np.float32).tobytes())
-        f.write(aw.astype(np.float32).tobytes())
-    subprocess.run([exe, prob, outp], check=True, timeout=900)
-    return bf16_val(np.fromfile(outp, dtype=np.uint16)).reshape(1, S, M * 32)
+def run_emulator(L, tmp_path, pyr, starts, S, M, value, loc, aw):
+    vb = np.ascontiguousarray(bf16_bits(value))
+    sh, st = np.ascontiguousarray(pyr, dtype=np.int64), np.ascontiguousarray(starts, dtype=np.int64)
+    loc, aw = np.ascontiguousarray(loc, dtype=np.float32), np.ascontiguousarray(aw, dtype=np.float32)
+    out = np.full((1, S, M * 32), 0x7FC0, dtype=np.uint16)                 # NaN: an unwritten query shows
+    p = lambda a: a.ctypes.data                                            # noqa: E731
+    rc = L.msda_forward_hs(6, 2, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), 1, S, M, 32, 4, S, 4, p(out), None)   # "cell", bf16
+    assert rc == 0, rc
+    return bf16_val(out).reshape(1, S, M * 32)
 
 
 @pytest.mark.parametrize("name,pyr,M,spread", [

@@ -42,6 +42,7 @@ class EmuLib:
         L.msda_backward_workspace_bytes.restype = ctypes.c_size_t
         L.msda_prepare_forward.argtypes = [i, vp, vp, i, vp, i, i, i, i, vp, vp, vp]
         L.msda_fused_forward.argtypes = [i, vp, vp, vp, vp, vp, i, *d, vp, vp, vp, vp]
+        L.msda_fused_forward_hs.argtypes = [i, i, vp, vp, vp, vp, vp, vp, i, *d, vp, vp, vp, vp]
         L.msda_fused_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, i, vp, *d, vp, vp, vp, ctypes.c_size_t, vp]
         L.msda_fused_supported.argtypes = [i, vp, i, *d]
 
@@ -195,6 +196,13 @@ def test_fused_geometry_route_of_the_train_step(lib):
     loc = np.full((N, Lq, M, L, P, 2), np.nan, dtype=np.float32)
     aw = np.full((N, Lq, M, L, P), np.nan, dtype=np.float32)
     assert Lb.msda_fused_forward(BF16, p(vb), p(pyr), p(starts), p(qb), p(ref), 2, *dims, p(out), p(loc), p(aw), None) == 0
+    # the experimental one-kernel form of the same call (cell_forward_kernel<2>: geometry + saves + LDS windows + MFMA):
+    # the saved locations / weights must be the product kernel's bit for bit (same geometry instructions)
+    out_c = np.zeros_like(out)
+    loc_c, aw_c = np.full_like(loc, np.nan), np.full_like(aw, np.nan)
+    assert Lb.msda_fused_forward_hs(VAR["cell"], BF16, p(vb), p(pyr), p(starts), p(pyr), p(qb), p(ref), 2, *dims, p(out_c),
+                                    p(loc_c), p(aw_c), None) == 0
+    assert np.array_equal(loc_c.view(np.uint32), loc.view(np.uint32)) and np.array_equal(aw_c.view(np.uint32), aw.view(np.uint32))
     ws_bytes = Lb.msda_backward_workspace_bytes(BF16, p(pyr), *dims)
     assert ws_bytes > 0
     ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
@@ -216,6 +224,7 @@ def test_fused_geometry_route_of_the_train_step(lib):
     ref_gv, ref_gl, ref_ga = O.backward(*a, grad_out.astype(np.float64))
     tol = 2.0 ** -7
     assert np.abs(bf16_val(out) - ref_out).max() <= tol * np.abs(ref_out).max()
+    assert np.abs(bf16_val(out_c) - ref_out).max() <= tol * np.abs(ref_out).max()
     assert np.abs(bf16_val(gv) - ref_gv).max() <= tol * np.abs(ref_gv).max()
     g_off = ref_gl / norm[None, None, None, :, None, :]
     g_logit = awd * (ref_ga - (awd * ref_ga).sum((-1, -2), keepdims=True))

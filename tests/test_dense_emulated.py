@@ -168,3 +168,45 @@ def test_dab_box_refinement_against_the_reference_formula(lib):
         inv = torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
         want = torch.sigmoid(d.float() + inv)
         torch.testing.assert_close(out, want, rtol=2e-6, atol=1e-7)
+
+
+def test_token_major_group_norm_against_torch(lib):
+    """GroupNorm(32, 256) of every pyramid level straight into its slice of the flattened [N, S, 256] tensor, forward and
+    backward (csrc/groupnorm_tokens.hip; reference input_proj's GroupNorm + the flatten, models/hoi.py:1936-1957,
+    dab_deformable/deformable_transformer.py:520-547) against float32 torch.nn.functional.group_norm"""
+    torch.manual_seed(5)
+    N, C, G, eps = 2, 256, 32, 1e-5
+    hw = [35, 12, 5, 2]
+    levels = len(hw)
+    assert lib.groupnorm_tokens_supported(C, G, levels) == 1
+    xs = [torch.randn(N, h, C).to(torch.bfloat16) for h in hw]
+    gammas = [(1 + 0.2 * torch.randn(C)).to(torch.bfloat16) for _ in hw]
+    betas = [(0.2 * torch.randn(C)).to(torch.bfloat16) for _ in hw]
+    S = sum(hw)
+    out = torch.empty(N, S, C, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(levels, N, G), torch.empty(levels, N, G)
+    hw_c = (ci * levels)(*hw)
+    parr = lambda ts: (vp * len(ts))(*[t.data_ptr() for t in ts])                    # noqa: E731
+    lib.groupnorm_tokens_workspace_bytes.restype = ctypes.c_size_t
+    lib.groupnorm_tokens_workspace_bytes.argtypes = [ci, vp, ci]
+    wsb = lib.groupnorm_tokens_workspace_bytes(N, hw_c, levels)
+    ws = torch.zeros(max(wsb, 16), dtype=torch.uint8)
+    lib.groupnorm_tokens_forward_bf16.argtypes = [vp, vp, ci, ci, vp, vp, ctypes.c_float, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    assert lib.groupnorm_tokens_forward_bf16(parr(xs), hw_c, levels, N, parr(gammas), parr(betas), eps, ptr(out), ptr(mean),
+                                             ptr(rstd), ptr(ws), wsb, None) == 0
+    dy = torch.randn(N, S, C).to(torch.bfloat16)
+    dxs = [torch.empty_like(x) for x in xs]
+    dgs, dbs = [torch.empty_like(g) for g in gammas], [torch.empty_like(g) for g in gammas]
+    lib.groupnorm_tokens_backward_bf16.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    assert lib.groupnorm_tokens_backward_bf16(ptr(dy), parr(xs), hw_c, levels, N, parr(gammas), ptr(mean), ptr(rstd), parr(dxs),
+                                              parr(dgs), parr(dbs), ptr(ws), wsb, None) == 0
+    start = 0
+    for l, h in enumerate(hw):
+        x = xs[l].float().requires_grad_(True)
+        g32, b32 = gammas[l].float().requires_grad_(True), betas[l].float().requires_grad_(True)
+        ref = torch.nn.functional.group_norm(x.transpose(1, 2), G, g32, b32, eps).transpose(1, 2)      # [N, C, hw] -> tokens
+        torch.testing.assert_close(out[:, start:start + h].float(), ref.detach(), rtol=2.0 ** -7, atol=2.0 ** -7)
+        ref.backward(dy[:, start:start + h].float())
+        for got, want in ((dxs[l], x.grad), (dgs[l], g32.grad), (dbs[l], b32.grad)):
+            torch.testing.assert_close(got.float(), want, rtol=2.0 ** -6, atol=2.0 ** -6 * float(want.abs().max()))
+        start += h

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
     const float *__restrict__ aw, const VT *__restrict__ grad_out, int N, int S, int M, int Lq,
     float *__restrict__ g_value, int dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    MSDA_DYNAMIC_LDS(unsigned char, lds);
     float *go = reinterpret_cast<float *>(lds + kOffGo);
     uint2 *rec = reinterpret_cast<uint2 *>(lds + kOffRec);
     int *cnt = reinterpret_cast<int *>(lds + kOffCnt);
@@ -291,8 +291,13 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
             // LDS address of this lane's channel in staged row 0; `go` sits at LDS offset 0 of a kernel without static
             // LDS, so (row offset from the record key) | go_ch is the whole address: one v_and_or_b32 per record instead
             // of and + add (the trap guards the assumption)
+#ifndef MSDA_EMU
             typedef const __attribute__((address_space(3))) float lds_cfloat;
-            const unsigned go_ch = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)go + ch_byte;
+#define K2_LDS_FLOAT(addr) (*(lds_cfloat *)(uintptr_t)(addr))
+#else
+#define K2_LDS_FLOAT(addr) (*reinterpret_cast<const float *>(emu::lds_ptr(addr)))     /* (host model, tools/emu/) */
+#endif
+            const unsigned go_ch = MSDA_LDS_BYTE_ADDR(go) + ch_byte;
             if (go_ch & 0x7f80u) __builtin_trap();
             char *gbytes = reinterpret_cast<char *>(gimg);
             // records per half-wave visit: every visit ends with a flush, so 64 instead of 32 removed ~1/5 of the row
@@ -315,12 +320,20 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
                     if (kPadInRegisters) mine.y = (e + l16 < nrec_real) ? mine.y : 0u;
                     unsigned key[16];
                     float g[16];
+// acc += (record I of the row's 16: its weight, as the DPP operand) * g -- one v_fmac_f32_dpp
+#ifndef MSDA_EMU
+#define K2_FMAC_BCAST(acc, w_bits, gval, I)                                                                          \
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #I " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w_bits), "v"(gval))
+#else
+#define K2_FMAC_BCAST(acc, w_bits, gval, I)                                                                          \
+    acc = fmaf(__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)(w_bits), 0x150 + I, 0xf, 0xf, false)), gval, acc)
+#endif
 #define K2_KEY(I) key[I] = __builtin_amdgcn_update_dpp(0u, mine.x, 0x150 + I, 0xf, 0xf, false);
                     K2_KEY(0) K2_KEY(1) K2_KEY(2) K2_KEY(3) K2_KEY(4) K2_KEY(5) K2_KEY(6) K2_KEY(7)
                     K2_KEY(8) K2_KEY(9) K2_KEY(10) K2_KEY(11) K2_KEY(12) K2_KEY(13) K2_KEY(14) K2_KEY(15)
 #undef K2_KEY
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) g[i] = *(lds_cfloat *)(uintptr_t)((key[i] & 0x7f80u) | go_ch);
+                    for (int i = 0; i < 16; ++i) g[i] = K2_LDS_FLOAT((key[i] & 0x7f80u) | go_ch);
 #ifdef K2_NOBOUNDARY       // experiment: no run detection at all (wrong results; lower bound of the walk's cost)
 #define K2_BOUNDARY(px) false
 #else
@@ -333,11 +346,10 @@ __global__ __launch_bounds__(kThreads, 8) void scatter_kernel(
                             if (!(MSDA_DBG(dbg) & 2))                                                                          \
                                 atomic_add(reinterpret_cast<float *>(gbytes + (size_t)(__umul24(cur_px, row_bytes) + ch_byte)), acc); \
                             acc = 0.f;                                                                               \
-                            asm volatile("" : "+v"(acc));       /* keep the reset inside the branch */               \
+                            MSDA_ASM_OPAQUE(acc);               /* keep the reset inside the branch */               \
                             cur_px = px;                                                                             \
                         }                                                                                            \
-                        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #I " row_mask:0xf bank_mask:0xf"      \
-                                     : "+v"(acc) : "v"(mine.y), "v"(g[I]));                                          \
+                        K2_FMAC_BCAST(acc, mine.y, g[I], I);                                                         \
                     }
                     K2_STEP(0) K2_STEP(1) K2_STEP(2) K2_STEP(3) K2_STEP(4) K2_STEP(5) K2_STEP(6) K2_STEP(7)
                     K2_STEP(8) K2_STEP(9) K2_STEP(10) K2_STEP(11) K2_STEP(12) K2_STEP(13) K2_STEP(14) K2_STEP(15)

@@ -1,5 +1,4 @@
-"""The MSDA part of the product library -- msda_api.hip and every MSDA kernel file except msda_window.hip, the SAME sources
-hipcc compiles -- built for the CPU against the lane-level workgroup model (tools/emu/build_lib.sh) and driven through its
+"""The MSDA part of the product library -- msda_api.hip and every MSDA kernel file, the SAME sources hipcc compiles -- built for the CPU against the lane-level workgroup model (tools/emu/build_lib.sh) and driven through its
 C ABI (include/rlipv2_msda.h) with host arrays: the reference-generated goldens of tests/golden/ in float64, float32 and
 bfloat16, kernel variant by kernel variant, the destination-stationary backward family (sorting pass, few-query pass, and
 for bfloat16 encoder calls cell_backward_kernel + patch_dest_kernel), the fused geometry entry points.
@@ -251,3 +250,19 @@ def test_samples_out_of_reach_take_the_sorting_pass_within_the_same_call(lib):
     close32(ga, ref_ga)
     keep = ~kink_samples(g)
     close32(gl[keep], ref_gl[keep])
+
+
+@pytest.mark.parametrize("case", ["model_dec"] + (["model_enc"] if FULL else []))
+def test_plain_b0_signature_without_host_shapes(lib, case):
+    """msda_forward / msda_backward exactly as the reference's extension is bound (no host copy of the shapes,
+    no workspace): "auto" then takes the direct-gather forward and K1 + the sorted scatter of round 1 (msda_window.hip: LDS
+    counting sort, row_newbcast DPP operands, one float atomic per finished row); with FULL also the "window" pair on the
+    encoder golden (LDS-DMA staged tile forward)."""
+    g = load_golden(case)
+    keep = ~kink_samples(g)
+    for fwd, bwd in [("auto", "auto")] + ([("window", "window")] if case == "model_enc" else []):
+        out, gv, gl, ga = lib.run(fwd, bwd, F32, g, host_shapes=False)
+        close32(out, g["out_f32"])
+        close32(gv, g["g_value_f32"])
+        close32(ga, g["g_aw_f32"])
+        close32(gl[keep], g["g_loc_f32"][keep])

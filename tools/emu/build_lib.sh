@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the MSDA part of the library (msda_api + every MSDA kernel file except msda_window.hip) for the CPU against the
+# Builds the MSDA part of the library (msda_api + every MSDA kernel file) for the CPU against the
 # lane-level workgroup model: same C ABI (include/rlipv2_msda.h), host pointers instead of device pointers, streams ignored.
 # TEST INFRASTRUCTURE ONLY: nothing in rlipv2_amd/ loads this library, and the product never falls back to it.
 #   usage: tools/emu/build_lib.sh <output.so>
@@ -11,11 +11,10 @@ CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 TMP=$(mktemp -d)
 FLAGS="-x c++ -std=c++20 -O1 -fPIC -pthread -DMSDA_EMU -I$HERE/stub -I$ROOT/include -Wno-unknown-pragmas -Wno-unused-value"
 pids=()
-for f in msda_api msda_generic msda_quad msda_dest msda_patch msda_sparse msda_prep; do
+for f in msda_api msda_generic msda_quad msda_dest msda_patch msda_sparse msda_prep msda_window; do
     $CXX $FLAGS -c $ROOT/rlipv2_amd/csrc/$f.hip -o $TMP/$f.o &
     pids+=($!)
 done
-$CXX $FLAGS -c $HERE/emu_missing.cpp -o $TMP/emu_missing.o
 for p in "${pids[@]}"; do wait $p; done
 $CXX -shared -pthread $TMP/*.o -o $OUT -Wl,--no-undefined
 rm -rf $TMP

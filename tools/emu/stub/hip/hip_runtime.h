@@ -6,7 +6,8 @@
 // MFMA (block = quad), a 16-lane row for row shifts and the transposing LDS read, the wave for everything else -- so a
 // kernel may run them in control flow that is uniform only at that granularity (e.g. "a quad is live or dead as a whole").
 // Semantics as measured on the hardware (profiles/r03_probe_mfma_tr_rates.txt):
-//   update_dpp      quad_perm 0x00-0xff; row_shr:n 0x111-0x11f; row_bcast15 0x142; row_bcast31 0x143; row_mask / bank_mask;
+//   update_dpp      quad_perm 0x00-0xff; row_shr:n 0x111-0x11f; row_newbcast:n 0x150-0x15f; row_bcast15 0x142; row_bcast31 0x143;
+//                   row_mask / bank_mask;
 //                   bound_ctrl: an invalid source gives 0 instead of `old`
 //   ds_read_b64_tr_b16   lane p of a 16-lane group ADDRESSES row p >> 2, 8-byte piece p & 3; lane i RECEIVES column i, 4 rows
 //   v_mfma_f32_4x4x4_16B_bf16    block = 4 lanes; A lane r = row r (4 k), B lane j = column j, D lane j reg i = D[i][j]
@@ -77,12 +78,13 @@ inline void done(Scope s) { barrier_of(s).wait(); }
 
 inline int update_dpp(int old, int v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
-    const Scope s = ctrl <= 0xff ? QUAD : (ctrl >= 0x111 && ctrl <= 0x11f) ? ROW : WAVE;
+    const Scope s = ctrl <= 0xff ? QUAD : ((ctrl >= 0x111 && ctrl <= 0x11f) || (ctrl >= 0x150 && ctrl <= 0x15f)) ? ROW : WAVE;
     publish(s, (uint32_t)v);
     const int l = lane(), row = l >> 4, in_row = l & 15;
     int src = -1;
     if (ctrl >= 0 && ctrl <= 0xff) src = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
     else if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; src = in_row >= n ? l - n : -1; }
+    else if (ctrl >= 0x150 && ctrl <= 0x15f) src = (l & ~15) | (ctrl - 0x150);          // row_newbcast:n
     else if (ctrl == 0x142) src = row >= 1 ? row * 16 - 1 : -1;
     else if (ctrl == 0x143) src = row >= 2 ? 31 : -1;
     else { std::fprintf(stderr, "emu: DPP control %#x not modelled\n", ctrl); std::abort(); }

@@ -125,7 +125,7 @@ def test_goldens_float64(lib, case):
     np.testing.assert_allclose(gl[keep], g["g_loc_f64"][keep], rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("case", ["testpy_d30", "testpy_d32", "model_enc"] + (["model_dec"] if FULL else []))
+@pytest.mark.parametrize("case", ["testpy_d30", "testpy_d32"] + (["model_enc", "model_dec"] if FULL else []))
 def test_goldens_float32_every_variant(lib, case):
     """model_enc: direct-gather forward, K1 + the sorting pass (bin / dest / combine kernels) for grad_value"""
     g = load_golden(case)
@@ -252,17 +252,37 @@ def test_samples_out_of_reach_take_the_sorting_pass_within_the_same_call(lib):
     close32(gl[keep], ref_gl[keep])
 
 
-@pytest.mark.parametrize("case", ["model_dec"] + (["model_enc"] if FULL else []))
-def test_plain_b0_signature_without_host_shapes(lib, case):
+def test_plain_b0_signature_without_host_shapes(lib):
     """msda_forward / msda_backward exactly as the reference's extension is bound (no host copy of the shapes,
     no workspace): "auto" then takes the direct-gather forward and K1 + the sorted scatter of round 1 (msda_window.hip: LDS
-    counting sort, row_newbcast DPP operands, one float atomic per finished row); with FULL also the "window" pair on the
-    encoder golden (LDS-DMA staged tile forward)."""
-    g = load_golden(case)
+    counting sort, row_newbcast DPP operands, one float atomic per finished row) -- a small decoder-like call against the
+    oracle; with FULL also the reference goldens, and the "window" pair (LDS-DMA staged tile forward) on the encoder one."""
+    rng = np.random.default_rng(41)
+    pyr = np.asarray([(12, 15), (6, 8), (3, 4), (2, 2)], dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
+    S, N, M, Lq = int((pyr[:, 0] * pyr[:, 1]).sum()), 2, 2, 23
+    ref = rng.uniform(-0.05, 1.05, size=(N, Lq, 2))
+    off = rng.standard_normal((N, Lq, M, 4, 4, 2)) * 2.0
+    loc = (ref[:, :, None, None, None, :] + off / np.stack([pyr[:, 1], pyr[:, 0]], -1)[None, None, None, :, None, :])
+    aw = rng.random((N, Lq, M, 4, 4))
+    g = dict(value=rng.standard_normal((N, S, M, 32)).astype(np.float32), loc=loc.astype(np.float32),
+             aw=(aw / aw.sum((-1, -2), keepdims=True)).astype(np.float32),
+             grad_out=rng.standard_normal((N, Lq, M * 32)).astype(np.float32), shapes=pyr, starts=starts)
+    a = (g["value"].astype(np.float64), pyr, starts, g["loc"].astype(np.float64), g["aw"].astype(np.float64))
+    ref_out = O.forward(*a)
+    ref_gv, ref_gl, ref_ga = O.backward(*a, g["grad_out"].astype(np.float64))
     keep = ~kink_samples(g)
-    for fwd, bwd in [("auto", "auto")] + ([("window", "window")] if case == "model_enc" else []):
-        out, gv, gl, ga = lib.run(fwd, bwd, F32, g, host_shapes=False)
-        close32(out, g["out_f32"])
-        close32(gv, g["g_value_f32"])
-        close32(ga, g["g_aw_f32"])
-        close32(gl[keep], g["g_loc_f32"][keep])
+    out, gv, gl, ga = lib.run("auto", "auto", F32, g, host_shapes=False)
+    close32(out, ref_out)
+    close32(gv, ref_gv)
+    close32(ga, ref_ga)
+    close32(gl[keep], ref_gl[keep])
+    for case in (["model_dec", "model_enc"] if FULL else []):
+        g = load_golden(case)
+        keep = ~kink_samples(g)
+        for fwd, bwd in [("auto", "auto")] + ([("window", "window")] if case == "model_enc" else []):
+            out, gv, gl, ga = lib.run(fwd, bwd, F32, g, host_shapes=False)
+            close32(out, g["out_f32"])
+            close32(gv, g["g_value_f32"])
+            close32(ga, g["g_aw_f32"])
+            close32(gl[keep], g["g_loc_f32"][keep])

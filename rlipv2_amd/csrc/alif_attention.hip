@@ -24,6 +24,11 @@
 #include "../../include/rlipv2_alif.h"
 #include "../../include/rlipv2_msda.h"
 
+// (tools/emu/ compiles this file for the CPU against a lane-level model of the workgroup and defines the macro itself)
+#ifndef MSDA_DYNAMIC_LDS
+#define MSDA_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(THREADS) void alif_forward_kernel(
     float keep_scale, int H, int Tv, int Tl, int Tvp, uint16_t *__restrict__ out_v, uint16_t *__restrict__ out_l,
     uint16_t *__restrict__ p_v, uint16_t *__restrict__ p_l)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    MSDA_DYNAMIC_LDS(unsigned char, lds);
     float *S = reinterpret_cast<float *>(lds);
     uint16_t *Pv = reinterpret_cast<uint16_t *>(lds + OFF_PV);
     uint16_t *Pl = reinterpret_cast<uint16_t *>(lds + OFF_PL);

@@ -210,3 +210,66 @@ def test_token_major_group_norm_against_torch(lib):
         for got, want in ((dxs[l], x.grad), (dgs[l], g32.grad), (dbs[l], b32.grad)):
             torch.testing.assert_close(got.float(), want, rtol=2.0 ** -6, atol=2.0 ** -6 * float(want.abs().max()))
         start += h
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_alif_attention_core_against_torch(lib, dropout):
+    """alif_attention_forward_bf16 / alif_attention_softmax_backward_bf16 (csrc/alif_attention.hip: shared logits q k^T, a
+    softmax over the text tokens for the vision side and over the vision tokens for the language side, dropout, both value
+    products on v_mfma_f32_32x32x16_bf16; reference models/fuse_helper.py:365-466) against the float32 formula"""
+    torch.manual_seed(6)
+    B, H, Tv, Tl, HD = 1, 2, 45, 11, 256
+    E = H * HD
+    assert lib.alif_attention_supported(B, H, Tv, Tl, HD) == 1
+    Tvp = lib.alif_attention_padded_tv(Tv)
+    q = (torch.randn(B, Tv, E) * 0.08).to(torch.bfloat16)
+    k = torch.randn(B, Tl, E).to(torch.bfloat16)
+    val_l = torch.randn(B, Tl, E).to(torch.bfloat16)
+    val_v = torch.randn(B, Tv, E).to(torch.bfloat16)
+    vlt = torch.zeros(B, E, 64, dtype=torch.bfloat16)
+    vlt[:, :, :Tl] = val_l.transpose(1, 2)
+    vvt = torch.zeros(B, E, Tvp, dtype=torch.bfloat16)
+    vvt[:, :, :Tv] = val_v.transpose(1, 2)
+    p_drop = 0.1
+    keep_v = (torch.rand(B, H, Tv, Tl) >= p_drop).to(torch.uint8) if dropout else None
+    keep_l = (torch.rand(B, H, Tl, Tv) >= p_drop).to(torch.uint8) if dropout else None
+    scale = 1.0 / (1.0 - p_drop) if dropout else 1.0
+    out_v, out_l = torch.zeros(B, Tv, E, dtype=torch.bfloat16), torch.zeros(B, Tl, E, dtype=torch.bfloat16)
+    probs_v = torch.zeros(B, H, Tv, Tl, dtype=torch.bfloat16)
+    probs_l = torch.zeros(B, H, Tl, Tv, dtype=torch.bfloat16)
+    lib.alif_attention_forward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, ci, ci, ci, ci, vp, vp, vp, vp, vp]
+    assert lib.alif_attention_forward_bf16(ptr(q), ptr(k), ptr(vlt), ptr(vvt), ptr(keep_v) if dropout else None,
+                                           ptr(keep_l) if dropout else None, scale, B, H, Tv, Tl, ptr(out_v), ptr(out_l),
+                                           ptr(probs_v), ptr(probs_l), None) == 0
+    heads = lambda t, T: t.float().view(B, T, H, HD).transpose(1, 2)                 # noqa: E731  [B, H, T, HD]
+    S = heads(q, Tv) @ heads(k, Tl).transpose(-1, -2)                                # [B, H, Tv, Tl]
+    Pv, Pl = torch.softmax(S, -1), torch.softmax(S.transpose(-1, -2), -1)
+    torch.testing.assert_close(probs_v.float(), Pv, rtol=2.0 ** -7, atol=2.0 ** -9)
+    torch.testing.assert_close(probs_l.float(), Pl, rtol=2.0 ** -7, atol=2.0 ** -9)
+    # the value products consume the bfloat16 probabilities the kernel keeps in LDS
+    Dv = probs_v.float() * (keep_v.float() * scale if dropout else 1.0)
+    Dl = probs_l.float() * (keep_l.float() * scale if dropout else 1.0)
+    want_v = (Dv.to(torch.bfloat16).float() @ heads(val_l, Tl)).transpose(1, 2).reshape(B, Tv, E)
+    want_l = (Dl.to(torch.bfloat16).float() @ heads(val_v, Tv)).transpose(1, 2).reshape(B, Tl, E)
+    torch.testing.assert_close(out_v.float(), want_v, rtol=2.0 ** -6, atol=2.0 ** -6 * float(want_v.abs().max()))
+    torch.testing.assert_close(out_l.float(), want_l, rtol=2.0 ** -6, atol=2.0 ** -6 * float(want_l.abs().max()))
+    # backward of the two softmaxes (+ dropouts) into the shared logits
+    d_pv = torch.randn(B, H, Tv, Tl).to(torch.bfloat16)
+    d_pl = torch.randn(B, H, Tl, Tv).to(torch.bfloat16)
+    d_logits = torch.zeros(B, H, Tv, Tl, dtype=torch.bfloat16)
+    dropped_v, dropped_l = torch.zeros_like(probs_v), torch.zeros_like(probs_l)
+    lib.alif_attention_softmax_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, ci, ci, ci, ci, vp, vp, vp, vp]
+    assert lib.alif_attention_softmax_backward_bf16(ptr(probs_v), ptr(probs_l), ptr(d_pv), ptr(d_pl),
+                                                    ptr(keep_v) if dropout else None, ptr(keep_l) if dropout else None, scale,
+                                                    B, H, Tv, Tl, ptr(d_logits), ptr(dropped_v) if dropout else None,
+                                                    ptr(dropped_l) if dropout else None, None) == 0
+    pv, pl = probs_v.float(), probs_l.float()
+    gv = d_pv.float() * (keep_v.float() * scale if dropout else 1.0)
+    gl = d_pl.float() * (keep_l.float() * scale if dropout else 1.0)
+    ds_v = pv * (gv - (pv * gv).sum(-1, keepdim=True))
+    ds_l = pl * (gl - (pl * gl).sum(-1, keepdim=True))
+    want = ds_v + ds_l.transpose(-1, -2)
+    torch.testing.assert_close(d_logits.float(), want, rtol=2.0 ** -6, atol=2.0 ** -6 * float(want.abs().max()))
+    if dropout:
+        torch.testing.assert_close(dropped_v.float(), (pv * keep_v.float() * scale), rtol=2.0 ** -7, atol=2.0 ** -9)
+        torch.testing.assert_close(dropped_l.float(), (pl * keep_l.float() * scale), rtol=2.0 ** -7, atol=2.0 ** -9)

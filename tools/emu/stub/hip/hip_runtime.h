@@ -358,3 +358,32 @@ template <typename V> inline emu_f32x4 emu_mfma16(V a, V b, emu_f32x4 c)
 // the two inline-assembly helpers of msda_patch.hip
 inline emu_s16x4 lds_tr_read(unsigned addr) { return emu_tr_read(addr, 0); }
 inline emu_s16x4 lds_tr_read32(unsigned addr) { return emu_tr_read(addr, 32); }
+
+// 32x32x16: A lane l = row l % 32, k = 8 (l / 32) + e; B lane l = column l % 32, same k; D: lane l holds column l % 32,
+// register r = row (r & 3) + 8 (r >> 2) + 4 (l / 32)   (the layout alif_attention.hip documents and a GPU has validated)
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+template <typename V> inline emu_f32x16 emu_mfma32(V a, V b, emu_f32x16 c)
+{
+    static_assert(sizeof(V) == 16, "8 bfloat16 per lane");
+    uint64_t ua[2], ub[2];
+    std::memcpy(ua, &a, 16); std::memcpy(ub, &b, 16);
+    emu::publish(emu::WAVE, ua[0], ua[1], ub[0], ub[1]);
+    const int l = emu::lane(), col = l & 31, hi = l >> 5;
+    emu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kg = 0; kg < 2; ++kg) {
+            const uint64_t *sa = emu::wave().slot[kg * 32 + row], *sb = emu::wave().slot[kg * 32 + col];
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t x = (uint32_t)((sa[e >> 2] >> (16 * (e & 3))) & 0xffff);
+                const uint32_t y = (uint32_t)((sb[2 + (e >> 2)] >> (16 * (e & 3))) & 0xffff);
+                acc += emu::bf16f(x) * emu::bf16f(y);
+            }
+        }
+        d[r] = acc;
+    }
+    emu::done(emu::WAVE);
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma32(a, b, c)

@@ -16,6 +16,8 @@
 #define MSDA_DYNAMIC_LDS_PLAIN(type, name) extern __shared__ type name[]
 #define MSDA_LDS_BYTE_ADDR(p) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(p))
 #define MSDA_ASM_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MSDA_ASM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define MSDA_ASM_WAIT_LGKM(v) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v))
 #define MSDA_ASM_FENCE() asm volatile("" ::: "memory")
 #define MSDA_ASM_OPAQUE(x) asm volatile("" : "+v"(x))
 // one LDS-DMA instruction: lane i copies 16 bytes from ITS global address to lds_base (wave-uniform) + 16 i

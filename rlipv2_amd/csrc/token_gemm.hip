@@ -31,6 +31,7 @@
 
 #include "../../include/rlipv2_linear.h"
 #include "../../include/rlipv2_msda.h"
+#include "msda_device.h"
 #include "msda_internal.h"
 
 namespace {
@@ -60,16 +61,24 @@ __device__ __forceinline__ float bf16_to_float(uint32_t bits16) { return __uint_
 template <int OFF>
 __device__ __forceinline__ s16x4 lds_tr_read(unsigned addr)
 {
+#ifndef MSDA_EMU
     s16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
+#else
+    return emu_tr_read(addr, OFF);                     // (host model, tools/emu/)
+#endif
 }
 
 template <int OFF>
 __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr)
 {
     u32x4 v;
+#ifndef MSDA_EMU
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+#else
+    std::memcpy(&v, emu::lds_ptr(addr + OFF), 16);
+#endif
     return v;
 }
 
@@ -92,9 +101,13 @@ __device__ __forceinline__ void read_step(StepFragments &s, unsigned a0, unsigne
 
 __device__ __forceinline__ void wait_step(StepFragments &s)
 {
+#ifndef MSDA_EMU
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(s.r[0]), "+v"(s.r[1]), "+v"(s.r[2]), "+v"(s.r[3]), "+v"(s.r[4]), "+v"(s.r[5]), "+v"(s.r[6]),
                    "+v"(s.r[7]));
+#else
+    (void)s;
+#endif
 }
 
 __device__ __forceinline__ void mfma_step(const StepFragments &s, f32x16 (&acc)[2][2])
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
     const uint16_t *__restrict__ dy, const uint16_t *__restrict__ x, int M, int K, int steps_total,
     int steps_per_chunk, int chunks, int bias_parts, float *__restrict__ partial, float *__restrict__ bias_partial)
 {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    MSDA_DYNAMIC_LDS_ALIGNED(char, smem, 1024);
     const int tiles_k = K / BN, tiles = (M / BM) * tiles_k;
     const int total = chunks * tiles;
     // physical workgroup b runs on XCD b % 8: give every XCD a contiguous range of logical ids so that
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
         const int c = wave_piece + 4 * f + 2 * (g & 1) + ((p & 3) >> 1);
         return (lane >> 5) * 2 * GROUP_BYTES + r * 256 + ((c ^ (4 * r)) * 16) + (p & 1) * 8;
     };
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned lds0 = MSDA_LDS_BYTE_ADDR(smem);
     const unsigned a0 = lds0 + frag_addr(wm * 8, 0), a1 = lds0 + frag_addr(wm * 8, 1);
     const unsigned b0 = lds0 + frag_addr(wn * 8, 0), b1 = lds0 + frag_addr(wn * 8, 1);
     const unsigned bias_addr = lds0 + wave * GROUP_BYTES + lane * 16;
@@ -179,10 +192,10 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
         const uint16_t *a = a_src + (size_t)st * a_step;
         const uint16_t *b = b_src + (size_t)st * b_step;
         char *dst = smem + stage * STAGE_BYTES + wave * GROUP_BYTES;
-        __builtin_amdgcn_global_load_lds((global_void *)a, (lds_void *)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((global_void *)(a + a_half), (lds_void *)(dst + 4 * GROUP_BYTES), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((global_void *)b, (lds_void *)(dst + TILE_BYTES), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((global_void *)(b + b_half), (lds_void *)(dst + TILE_BYTES + 4 * GROUP_BYTES), 16, 0, 0);
+        MSDA_GLOBAL_LOAD_LDS16(a, dst);
+        MSDA_GLOBAL_LOAD_LDS16(a + a_half, dst + 4 * GROUP_BYTES);
+        MSDA_GLOBAL_LOAD_LDS16(b, dst + TILE_BYTES);
+        MSDA_GLOBAL_LOAD_LDS16(b + b_half, dst + TILE_BYTES + 4 * GROUP_BYTES);
     };
     auto compute = [&](auto stage_c) {
         constexpr int SB = decltype(stage_c)::value * STAGE_BYTES;
@@ -218,12 +231,12 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
         };
         if (bias_h0) {
             u32x4 v = lds_read_b128<SB>(bias_addr);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+            MSDA_ASM_WAIT_LGKM(v);
             bias_add(v);
         }
         if (bias_h1) {
             u32x4 v = lds_read_b128<SB + 4 * GROUP_BYTES>(bias_addr);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
+            MSDA_ASM_WAIT_LGKM(v);
             bias_add(v);
         }
     };
@@ -232,10 +245,10 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
     // step i+2 goes.
     auto body = [&](int i, auto stage_c) {
         constexpr int stage = decltype(stage_c)::value;
-        if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (dbg & 1) MSDA_ASM_WAIT_VM(); else
+        MSDA_ASM_WAIT_VMCNT(4);
         __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        MSDA_ASM_FENCE();
         if (!(dbg & 1)) issue(i + 2, (stage + 2) % STAGES);
         compute(stage_c);
     };
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(THREADS, WAVES_PER_SIMD) void wgrad_kernel(
         body(i, std::integral_constant<int, 2>{});
         if (++i >= nsteps) break;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two surplus DMAs still target our LDS
+    MSDA_ASM_WAIT_VM();                                   // the two surplus DMAs still target our LDS
     __builtin_amdgcn_s_barrier();
 
     // partial[chunk][m][k]: accumulator register q of lane l is row 8*(q/4) + 4*(l/32) + q%4, column l%32

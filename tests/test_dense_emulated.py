@@ -273,3 +273,29 @@ def test_alif_attention_core_against_torch(lib, dropout):
     if dropout:
         torch.testing.assert_close(dropped_v.float(), (pv * keep_v.float() * scale), rtol=2.0 ** -7, atol=2.0 ** -9)
         torch.testing.assert_close(dropped_l.float(), (pl * keep_l.float() * scale), rtol=2.0 ** -7, atol=2.0 ** -9)
+
+
+@pytest.mark.parametrize("T,M,K,f32", [(100, 128, 128, False), (256, 256, 128, True), (1203, 128, 256, False)])
+def test_mfma_weight_gradient_against_torch(lib, T, M, K, f32):
+    """linear_wgrad_bf16 (csrc/token_gemm.hip: dW = dY^T X and db = column sums of dY on v_mfma_f32_32x32x16_bf16, LDS-DMA
+    staged tiles read through transposing LDS reads, chunk partials + a reduce pass that also takes the T % 32 tail rows; one
+    chunk and no tail: the direct-store instantiation) against float32 matmul -- 100 rows (3 steps + 4 tail rows), 256 rows
+    (direct), 1 203 rows (several chunks + 19 tail rows)"""
+    torch.manual_seed(7)
+    dy = torch.randn(T, M).to(torch.bfloat16)
+    x = torch.randn(T, K).to(torch.bfloat16)
+    lib.linear_wgrad_supported.argtypes = [ci, ci, ci]
+    assert lib.linear_wgrad_supported(T, M, K) == 1
+    lib.linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    lib.linear_wgrad_workspace_bytes.argtypes = [ci, ci, ci]
+    wsb = lib.linear_wgrad_workspace_bytes(T, M, K)
+    ws = torch.zeros(wsb + 64, dtype=torch.uint8)
+    odt = torch.float32 if f32 else torch.bfloat16
+    dw, db = torch.full((M, K), float("nan"), dtype=odt), torch.full((M,), float("nan"), dtype=odt)
+    lib.linear_wgrad_bf16.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp, ctypes.c_size_t, vp]
+    assert lib.linear_wgrad_bf16(ptr(dy), ptr(x), T, M, K, ptr(dw), ptr(db), 1 if f32 else 0, ptr(ws), wsb, None) == 0
+    want_w = dy.float().t() @ x.float()
+    want_b = dy.float().sum(0)
+    tol = 1e-5 if f32 else 2.0 ** -7
+    torch.testing.assert_close(dw.float(), want_w, rtol=tol, atol=tol * float(want_w.abs().max()))
+    torch.testing.assert_close(db.float(), want_b, rtol=tol, atol=tol * float(want_b.abs().max()))

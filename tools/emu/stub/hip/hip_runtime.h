@@ -170,6 +170,9 @@ template <typename F> inline void launch(unsigned grid, unsigned block, F body)
     std::memcpy(emu::lds_ptr(MSDA_LDS_BYTE_ADDR(lds_base) + 16u * (unsigned)emu::lane()), (src), 16)
 #define MSDA_LDS_BYTE_ADDR(p) ((unsigned)((const unsigned char *)(p) - emu::group()->lds))
 #define MSDA_ASM_WAIT_VM() do { } while (0)
+#define MSDA_ASM_WAIT_VMCNT(n) do { } while (0)
+#define MSDA_ASM_WAIT_LGKM(v) do { } while (0)
+#define __builtin_amdgcn_s_barrier() emu::group()->bar.wait()
 #define MSDA_ASM_FENCE() do { } while (0)
 #define MSDA_WAVE_LDS_SYNC() emu::barrier_of(emu::WAVE).wait()
 

@@ -45,14 +45,16 @@
 
 #include "../../include/rlipv2_linear.h"
 #include "../../include/rlipv2_msda.h"
+#include "msda_device.h"
+#ifdef MSDA_EMU
+#include <cstring>
+#endif
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void global_void;
 
 constexpr int XK = 256;                     // reduction width (fixed: the encoder's d_model)
 constexpr int XBM = 256;                    // tokens per workgroup (4 waves x 64)
@@ -83,7 +85,11 @@ template <int OFF>
 __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr)
 {
     u32x4 v;
+#ifndef MSDA_EMU
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+#else
+    std::memcpy(&v, emu::lds_ptr(addr + OFF), 16);     // (host model, tools/emu/)
+#endif
     return v;
 }
 
@@ -91,13 +97,21 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 __device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v)
 {
+#ifndef MSDA_EMU
     asm volatile("ds_write_b64 %0, %1" : : "v"(addr), "v"(v) : "memory");
+#else
+    std::memcpy(emu::lds_ptr(addr), &v, 8);
+#endif
 }
 
 __device__ __forceinline__ u32x2 lds_read_b64(unsigned addr)
 {
     u32x2 v;
+#ifndef MSDA_EMU
     asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr));
+#else
+    std::memcpy(&v, emu::lds_ptr(addr), 8);
+#endif
     return v;
 }
 
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
                                                              const uint16_t *__restrict__ mask, int T, int N,
                                                              int steps_per_split, uint16_t *__restrict__ c)
 {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    MSDA_DYNAMIC_LDS_ALIGNED(char, smem, 1024);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform values stay in scalar registers
     const int l32 = lane & 31, hi = lane >> 5;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
         for (int j = 0; j < 8; ++j) {
             const int n = j * 8 + drow;
             const uint16_t *src = tile + (size_t)n * XK + ((dpc ^ (n & 31)) * 8);
-            __builtin_amdgcn_global_load_lds((global_void *)src, (lds_void *)(dst + j * 4096), 16, 0, 0);
+            MSDA_GLOBAL_LOAD_LDS16(src, dst + j * 4096);
         }
     };
     if (step0 < step1) issue(step0);
@@ -176,11 +190,11 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) asm volatile("" : "+v"(af[mt][s]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int s = 0; s < 16; ++s) MSDA_ASM_OPAQUE(af[mt][s]);
+    MSDA_ASM_WAIT_VM();
 
     // fragment addresses: row n = nt * 32 + l32 of the tile, k-step s -> logical piece 2 s + hi
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    const unsigned lds0 = MSDA_LDS_BYTE_ADDR(smem);
     const unsigned frag_row = lds0 + (unsigned)l32 * 512u;
     const unsigned stage_lds = lds0 + BTILE + wave * CSTAGE;
     const unsigned bias_lds = lds0 + BTILE + XWAVES * CSTAGE;
@@ -191,7 +205,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
     auto step_body = [&](int i) {
         constexpr int BUF = 0;
         __builtin_amdgcn_s_barrier();          // tile i is in LDS, for every wave
-        asm volatile("" ::: "memory");
+        MSDA_ASM_FENCE();
         XTS(0);
 
         // The 64-column tile is taken as two 32-column halves, one after the other: a half needs 2 accumulators
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
         // without registers and the spill reloads (vector-memory operations) waited for the output stores.
         const int ncol = i * XBN;
         unsigned swz = (unsigned)l32;              // opaque copy of the lane id: keeps the 16 swizzled addresses
-        asm volatile("" : "+v"(swz));              // from being hoisted out of the column loop (16 registers)
+        MSDA_ASM_OPAQUE(swz);                      // from being hoisted out of the column loop (16 registers)
         // staging tile of this wave: [64 tokens][128 bytes], 16-byte piece c of row r stored at piece c ^ ((r >> 1) & 7)
         // (the same map for the mask that arrives by DMA and for the results that replace it)
         const unsigned s3 = ((unsigned)(l32 >> 1) & 7u) << 4;
@@ -218,8 +232,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
                 const int r = 8 * j + r0;
                 const unsigned row = (unsigned)min(t0 + r, T - 1);
                 const unsigned src = (row * (unsigned)N + (unsigned)(ncol + ((q8 ^ ((r >> 1) & 7)) << 3))) * 2u;
-                __builtin_amdgcn_global_load_lds((global_void *)(mbytes + src),
-                                                 (lds_void *)(smem + BTILE + wave * CSTAGE + j * 1024), 16, 0, 0);
+                MSDA_GLOBAL_LOAD_LDS16(mbytes + src, smem + BTILE + wave * CSTAGE + j * 1024);
             }
         }
 #pragma unroll
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
                 // reads issued after read(s) and still allowed in flight: min(PF - 1, 15 - s)
                 constexpr int dummy = 0; (void)dummy;
                 const int allow = (15 - s < PF - 1) ? 15 - s : PF - 1;
+#ifndef MSDA_EMU
                 switch (allow) {
                 case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[s % PF])); break;
                 case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f[s % PF])); break;
@@ -255,6 +269,9 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
                 case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f[s % PF])); break;
                 default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(f[s % PF])); break;
                 }
+#else
+                (void)allow;
+#endif
                 union { u32x4 u; bf16x8 v; } w;
                 w.u = f[s % PF];
                 if (XDBG & 1) { acc[0][s] += __uint_as_float(w.u[0]); acc[1][s] += __uint_as_float(w.u[1]); continue; }
@@ -269,21 +286,28 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
             XTS(1 + 2 * nt);
             u32x2 mraw[2][4];
             if (MASK) {
-                if (nt == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the mask tile has landed
+                if (nt == 0) {
+                    MSDA_ASM_WAIT_VM();      // the mask tile has landed
+                    MSDA_WAVE_LDS_SYNC();    // (every lane's slice of it, for the lanes that read it below)
+                }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) mraw[mt][g] = lds_read_b64(wbase + mt * 32 * 128 + (s3 ^ ((4 * nt + g) << 4)));
+#ifndef MSDA_EMU
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(mraw[0][0]), "+v"(mraw[0][1]), "+v"(mraw[0][2]), "+v"(mraw[0][3]), "+v"(mraw[1][0]),
                                "+v"(mraw[1][1]), "+v"(mraw[1][2]), "+v"(mraw[1][3]));
+#endif
             }
             u32x2 braw[4];
             if (BIAS) {
                 const unsigned baddr = bias_lds + (unsigned)((i - step0) * XBN + nt * 32 + 4 * hi) * 2u;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) braw[g] = lds_read_b64(baddr + 8 * g * 2);
+#ifndef MSDA_EMU
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(braw[0]), "+v"(braw[1]), "+v"(braw[2]), "+v"(braw[3]));
+#endif
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -314,7 +338,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
         // every wave is done with tile i -> the next tile may overwrite it; its latency hides behind the rest of
         // the epilogue and, beyond that, behind the sibling workgroup
         __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        MSDA_ASM_FENCE();
         XTS(5);
         if (!(XDBG & 16) && i + 1 < step1) issue(i + 1);
         // read back whole rows: lane -> row (lane >> 3) + 8 jj, 16-byte slot lane & 7 (LDS runs a wave's
@@ -328,7 +352,9 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
                 const unsigned r = (unsigned)(r0 + 8 * (4 * half + j));
                 rv[j] = lds_read_b128<0>(stage_lds + r * 128u + (((unsigned)q8 ^ ((r >> 1) & 7u)) << 4));
             }
+#ifndef MSDA_EMU
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]));
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int jj = 4 * half + j, r = r0 + 8 * jj;
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void expand_kernel(const uint16_t *__r
             }
         }
         XTS(8);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile i+1 has landed (and this step's stores have left)
+        MSDA_ASM_WAIT_VM();      // tile i+1 has landed (and this step's stores have left)
         XTS(9);
     };
 

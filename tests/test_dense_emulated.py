@@ -299,3 +299,38 @@ def test_mfma_weight_gradient_against_torch(lib, T, M, K, f32):
     tol = 1e-5 if f32 else 2.0 ** -7
     torch.testing.assert_close(dw.float(), want_w, rtol=tol, atol=tol * float(want_w.abs().max()))
     torch.testing.assert_close(db.float(), want_b, rtol=tol, atol=tol * float(want_b.abs().max()))
+
+
+@pytest.mark.parametrize("T,N,mask,bias,relu", [(300, 128, False, True, True), (77, 192, True, False, False),
+                                                (256, 64, False, False, False), (513, 128, True, True, False)])
+def test_mfma_expand_gemm_against_torch(lib, T, N, mask, bias, relu):
+    """linear_expand_bf16 (csrc/expand_gemm.hip: C[T, N] = A[T, 256] B[N, 256]^T on v_mfma_f32_32x32x16_bf16 with the A slice
+    resident in registers, LDS-DMA'd swizzled B tiles, a per-wave swizzled staging tile that the mask rows reach by DMA and the
+    results replace; epilogue = + bias, ReLU, keep-where-mask-positive) against float32 matmul: ragged last row block, one to
+    three column steps, every epilogue combination the encoder FFN uses"""
+    torch.manual_seed(11)
+    a = torch.randn(T, 256).to(torch.bfloat16)
+    b = (torch.randn(N, 256) / 16).to(torch.bfloat16)
+    bv = torch.randn(N).to(torch.bfloat16) if bias else None
+    mk = torch.randn(T, N).to(torch.bfloat16) if mask else None
+    if mask:
+        mk[::7, ::5] = 0.0           # zeros and negative zeros are "not positive"
+        mk[1::7, 1::5] = -0.0
+    c = torch.full((T, N), float("nan"), dtype=torch.bfloat16)
+    lib.linear_expand_supported.argtypes = [ci, ci, ci]
+    assert lib.linear_expand_supported(T, N, 256) == 1 and lib.linear_expand_supported(T, N, 128) == 0
+    lib.linear_expand_bf16.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]
+    rc = lib.linear_expand_bf16(ptr(a), ptr(b), ptr(bv) if bias else None, ptr(mk) if mask else None, T, N, 256,
+                                1 if relu else 0, ptr(c), None)
+    assert rc == 0
+    want = a.float() @ b.float().t()
+    if bias:
+        want = want + bv.float()
+    if relu:
+        want = want.relu()
+    want = want.to(torch.bfloat16).float()
+    if mask:
+        want = torch.where(mk.float() > 0, want, torch.zeros_like(want))
+    torch.testing.assert_close(c.float(), want, rtol=2.0 ** -7, atol=2.0 ** -8)
+    if mask:
+        assert bool((c[mk.float() <= 0] == 0).all())

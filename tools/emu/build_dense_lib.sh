@@ -1,6 +1,6 @@
 #!/bin/bash
 # The dense helper kernels without inline assembly (fused AdamW, add + LayerNorm, the backbone's elementwise tails, token-major
-# GroupNorm, decoder glue, the ALIF attention core, the MFMA weight-gradient kernel) built for the CPU against the lane-level workgroup model -- same C ABIs, host pointers.
+# GroupNorm, decoder glue, the ALIF attention core, the MFMA weight-gradient and expand-GEMM kernels) built for the CPU against the lane-level workgroup model -- same C ABIs, host pointers.
 # TEST INFRASTRUCTURE ONLY (tests/test_dense_emulated.py).   usage: tools/emu/build_dense_lib.sh <output.so>
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -10,7 +10,7 @@ CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 TMP=$(mktemp -d)
 FLAGS="-x c++ -std=c++20 -O1 -fPIC -pthread -DMSDA_EMU -I$HERE/stub -I$ROOT/include -Wno-unknown-pragmas -Wno-unused-value"
 pids=()
-for f in fused_adamw add_layernorm elementwise groupnorm_tokens decoder_glue alif_attention token_gemm; do
+for f in fused_adamw add_layernorm elementwise groupnorm_tokens decoder_glue alif_attention token_gemm expand_gemm; do
     $CXX $FLAGS -c $ROOT/rlipv2_amd/csrc/$f.hip -o $TMP/$f.o &
     pids+=($!)
 done

@@ -53,7 +53,7 @@ struct Group {
     alignas(16) unsigned char guard_hi[16 << 20];
     Barrier bar;
     Wave waves[kMaxThreads / 64];
-    int block_idx = 0, block_dim = 0, grid_dim = 0;
+    int block_idx = 0, block_idx_y = 0, block_dim = 0, grid_dim = 0, grid_dim_y = 1;
 };
 
 inline Group *&group() { static Group *g = new Group; return g; }
@@ -138,13 +138,15 @@ inline unsigned char *lds_ptr(unsigned addr)
 inline float bf16f(uint32_t bits16) { const uint32_t u = bits16 << 16; float f; std::memcpy(&f, &u, 4); return f; }
 
 // launch: every block in turn, block_dim host threads each
-template <typename F> inline void launch(unsigned grid, unsigned block, F body)
+template <typename F> inline void launch(unsigned grid, unsigned grid_y, unsigned block, F body)
 {
     Group *g = group();
     if (block > (unsigned)kMaxThreads) { std::fprintf(stderr, "emu: block of %u threads\n", block); std::abort(); }
+    for (unsigned by = 0; by < grid_y; ++by)
     for (unsigned b = 0; b < grid; ++b) {
         std::memset(g->lds, 0xa5, sizeof(g->lds));                 // LDS starts as garbage
-        g->block_idx = (int)b; g->block_dim = (int)block; g->grid_dim = (int)grid;
+        g->block_idx = (int)b; g->block_idx_y = (int)by; g->block_dim = (int)block; g->grid_dim = (int)grid;
+        g->grid_dim_y = (int)grid_y;
         g->bar.reset((int)block);
         std::vector<std::thread> th;
         th.reserve(block);
@@ -178,9 +180,9 @@ template <typename F> inline void launch(unsigned grid, unsigned block, F body)
 
 struct emu_idx { int x, y, z; };
 #define threadIdx (emu_idx{emu::tid_ref(), 0, 0})
-#define blockIdx (emu_idx{emu::group()->block_idx, 0, 0})
+#define blockIdx (emu_idx{emu::group()->block_idx, emu::group()->block_idx_y, 0})
 #define blockDim (emu_idx{emu::group()->block_dim, 1, 1})
-#define gridDim (emu_idx{emu::group()->grid_dim, 1, 1})
+#define gridDim (emu_idx{emu::group()->grid_dim, emu::group()->grid_dim_y, 1})
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 typedef void *hipStream_t;
 typedef int hipError_t;
@@ -193,7 +195,7 @@ inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::m
 template <typename T> inline hipError_t hipMemcpyToSymbol(T &sym, const void *src, size_t n) { std::memcpy(&sym, src, n); return 0; }
 template <typename T> inline hipError_t hipMemcpyFromSymbol(void *dst, const T &sym, size_t n) { std::memcpy(dst, &sym, n); return 0; }
 #define hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, ...)                                              \
-    emu::launch(dim3(grid).x, dim3(block).x, [&] { kernel(__VA_ARGS__); })
+    emu::launch(dim3(grid).x, dim3(grid).y, dim3(block).x, [&] { kernel(__VA_ARGS__); })
 
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };

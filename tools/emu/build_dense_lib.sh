@@ -9,11 +9,14 @@ OUT=${1:-/tmp/libdense_emu.so}
 CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 TMP=$(mktemp -d)
 FLAGS="-x c++ -std=c++20 -O1 -fPIC -pthread -DMSDA_EMU -I$HERE/stub -I$ROOT/include -Wno-unknown-pragmas -Wno-unused-value"
+# EMU_SANITIZE=1: AddressSanitizer + UndefinedBehaviorSanitizer build (global-memory accesses of the kernels against the
+# host allocator's red zones; run python with LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so))
+if [ "${EMU_SANITIZE:-0}" = "1" ]; then FLAGS="$FLAGS -g -fno-omit-frame-pointer -fsanitize=address,undefined -shared-libasan"; SAN="-fsanitize=address,undefined -shared-libasan"; fi
 pids=()
 for f in fused_adamw add_layernorm elementwise groupnorm_tokens decoder_glue alif_attention token_gemm expand_gemm; do
     $CXX $FLAGS -c $ROOT/rlipv2_amd/csrc/$f.hip -o $TMP/$f.o &
     pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-$CXX -shared -pthread $TMP/*.o -o $OUT -Wl,--no-undefined
+$CXX -shared -pthread $SAN $TMP/*.o -o $OUT -Wl,--no-undefined
 rm -rf $TMP

@@ -9,6 +9,9 @@ cd $GRAFT_REPO_ROOT
 tail -5 $OUT/pytest_gpu.txt
 ( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; timeout 900 python tools/r03_experiments.py > $OUT/experiments.txt 2>&1 )
 cat $OUT/experiments.txt
+# where the cycles of cell_backward_kernel go, product kernel vs arm 3 (cycle stamps of thread 0, summed over the workgroups)
+( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; for m in 0 3; do echo "== cell timeline, RLIPV2_CELL_SHARED=$m"; RLIPV2_CELL_SHARED=$m timeout 300 python tools/cell_timeline.py init; done > $OUT/cell_timeline.txt 2>&1 )
+cat $OUT/cell_timeline.txt
 ( RLIPV2_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_msda_cell_forward_gpu.py -q -m gpu > $OUT/pytest_cell_forward.txt 2>&1; timeout 300 python tools/cell_forward_check.py >> $OUT/pytest_cell_forward.txt 2>&1 )
 tail -25 $OUT/pytest_cell_forward.txt
 timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt

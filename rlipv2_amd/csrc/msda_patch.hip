@@ -514,8 +514,11 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
                 float tx[4], ty[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    tx[c] = fmaxf(0.f, 1.f - fabsf(dx - (float)c));
-                    ty[c] = a * fmaxf(0.f, 1.f - fabsf(dy - (float)c));
+                    // (experimental instantiation: the median with 0 and 1 compiles to the subtraction's `clamp` modifier, one
+                    //  instruction less per tent, same bits -- 1 - |d| never exceeds 1, NaN -> 0 either way)
+                    const float ux = 1.f - fabsf(dx - (float)c), uy = 1.f - fabsf(dy - (float)c);
+                    tx[c] = MULTI ? __builtin_amdgcn_fmed3f(ux, 0.f, 1.f) : fmaxf(0.f, ux);
+                    ty[c] = a * (MULTI ? __builtin_amdgcn_fmed3f(uy, 0.f, 1.f) : fmaxf(0.f, uy));
                 }
                 if (border) {                              // pixels of the patch beyond the level's edge receive nothing
 #pragma unroll

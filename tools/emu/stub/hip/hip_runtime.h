@@ -210,6 +210,12 @@ inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z,
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return {x, y}; }
 inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return {x, y, z, w}; }
 
+// v_med3_f32: the median; with a NaN among the inputs the minimum of the others (what the clamp modifier it compiles to gives)
+inline float __builtin_amdgcn_fmed3f(float a, float b, float c)
+{
+    if (a != a || b != b || c != c) return std::fmin(std::fmin(a, b), c);
+    return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c));
+}
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }

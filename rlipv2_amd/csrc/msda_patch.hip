@@ -1042,17 +1042,9 @@ namespace {
 #endif
 
 // ---- cell_forward_kernel: source in msda_cell_forward.inc (shared with the host-side lane-level model) ----------------
-#ifndef MSDA_EMU
-__device__ __forceinline__ s16x4 lds_tr_read32(unsigned addr)    // lds_tr_read 32 bytes further (second channel half)
-{
-    s16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:32" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-#endif
 #define MSDA_DEVFN __device__ __forceinline__
 #define MSDA_KERNEL_BOUNDS(T, W) __global__ __launch_bounds__(T, W)
-#define MSDA_LDS_DYNAMIC(name) MSDA_DYNAMIC_LDS(unsigned char, name)
+#define MSDA_LDS_DYNAMIC(name) MSDA_DYNAMIC_LDS_ALIGNED(unsigned char, name, 256)
 #define MSDA_LDS_STATIC(type, name, dims) __shared__ type name dims
 #define MSDA_TID threadIdx.x
 #define MSDA_BID blockIdx.x
@@ -1063,13 +1055,13 @@ __device__ __forceinline__ s16x4 lds_tr_read32(unsigned addr)    // lds_tr_read 
 #define MSDA_LDS_ADDR(p) MSDA_LDS_BYTE_ADDR(p)
 #define MSDA_WAVE_FENCE() do { __builtin_amdgcn_wave_barrier(); MSDA_ASM_FENCE(); } while (0)
 #ifndef MSDA_EMU
-#define MSDA_TR_READ_PAIR(b0, b1, addr)                                                                              \
+#define MSDA_TR_READ_PAIR(b0, b1, addr0, addr1)                                                                      \
     do {                                                                                                              \
-        b0 = lds_tr_read(addr); b1 = lds_tr_read32(addr);                                                            \
+        b0 = lds_tr_read(addr0); b1 = lds_tr_read(addr1);                                                            \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1) : : "memory");                                      \
     } while (0)
 #else
-#define MSDA_TR_READ_PAIR(b0, b1, addr) do { b0 = lds_tr_read(addr); b1 = lds_tr_read32(addr); } while (0)
+#define MSDA_TR_READ_PAIR(b0, b1, addr0, addr1) do { b0 = lds_tr_read(addr0); b1 = lds_tr_read(addr1); } while (0)
 #endif
 #define MSDA_MFMA444(a, b, c) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0)
 #include "msda_cell_forward.inc"

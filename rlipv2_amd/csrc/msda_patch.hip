@@ -369,8 +369,14 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
     const int nq = n * Lq;
     // transpose-read addresses: lane (p = lane & 15, kg = lane >> 4) supplies row 8 kg + 4 j + (p >> 2), piece p & 3
     const int p16 = lane & 15, kg = lane >> 4;
-    const unsigned a_rd = lds0 + kOffA + (8 * kg + (p16 >> 2)) * 32 + (p16 & 3) * 8;         // + matrix * 1024 + j * 128
-    const unsigned g_rd = lds0 + kOffG + (8 * kg + (p16 >> 2)) * 64 + (p16 & 3) * 8;         // + tile * 32 + j * 256
+    // (experimental instantiation: the odd 8-row blocks are staged with their two 4-row halves (A^T) / their two 32-byte
+    //  channel halves (grad_out) exchanged, so that the two lane groups of a 32-lane half -- rows 8 kg .. and 8 (kg + 1) ..,
+    //  256 / 512 bytes apart -- read from different banks; addresses only, the instruction stream is the same)
+    const int rsw = MULTI ? (kg & 1) : 0;
+    const int a_j = rsw ? -128 : 128, g_t = rsw ? -32 : 32;
+    const unsigned a_rd = lds0 + kOffA + (8 * kg + (p16 >> 2) + 4 * rsw) * 32 + (p16 & 3) * 8;     // + matrix * 1024 + j * a_j
+    const unsigned g_rd = lds0 + kOffG + (8 * kg + (p16 >> 2)) * 64 + (p16 & 3) * 8 + rsw * 32;    // + tile * g_t + j * 256
+    const int wsw = MULTI ? ((kk >> 3) & 1) : 0;
     // This wave's mask words of a patch: slots part, part + parts, ... of the patch's neighbourhood, 12 words each, taken 64
     // at a time (lane i holds word wbase + i; the next 64 are already travelling).  Word order = (slot, word) order, so a
     // wave-wide prefix sum of the popcounts puts the candidates in a fixed order.
@@ -537,12 +543,12 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
 #pragma unroll
             for (int i = 0; i < 8; ++i) split_pair(e[2 * i], e[2 * i + 1], hi[i], lo[i]);
             // A^T matrices: [half][hi | lo][32 groups][16 pixels] bfloat16, row kk of the lane's half
-            uint4 *arow = reinterpret_cast<uint4 *>(wl + kOffA + half * 2048 + kk * 32);
+            uint4 *arow = reinterpret_cast<uint4 *>(wl + kOffA + half * 2048 + (kk ^ (wsw << 2)) * 32);
             arow[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
             arow[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
             arow[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);            // + 1024 bytes
             arow[65] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-            uint4 *grow = reinterpret_cast<uint4 *>(wl + kOffG + kk * 64 + half * 32);
+            uint4 *grow = reinterpret_cast<uint4 *>(wl + kOffG + kk * 64 + (half ^ wsw) * 32);
             grow[0] = g0;
             grow[1] = g1;
             MSDA_WAVE_LDS_SYNC();
@@ -550,11 +556,11 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
             union Frag { bf16x8 v; s16x4 h[2]; };
             Frag gt0, gt1, at0, at1, at2, at3;
             gt0.h[0] = lds_tr_read(g_rd); gt0.h[1] = lds_tr_read(g_rd + 256);
-            gt1.h[0] = lds_tr_read(g_rd + 32); gt1.h[1] = lds_tr_read(g_rd + 32 + 256);
-            at0.h[0] = lds_tr_read(a_rd); at0.h[1] = lds_tr_read(a_rd + 128);
-            at1.h[0] = lds_tr_read(a_rd + 1024); at1.h[1] = lds_tr_read(a_rd + 1024 + 128);
-            at2.h[0] = lds_tr_read(a_rd + 2048); at2.h[1] = lds_tr_read(a_rd + 2048 + 128);
-            at3.h[0] = lds_tr_read(a_rd + 3072); at3.h[1] = lds_tr_read(a_rd + 3072 + 128);
+            gt1.h[0] = lds_tr_read(g_rd + g_t); gt1.h[1] = lds_tr_read(g_rd + g_t + 256);
+            at0.h[0] = lds_tr_read(a_rd); at0.h[1] = lds_tr_read(a_rd + a_j);
+            at1.h[0] = lds_tr_read(a_rd + 1024); at1.h[1] = lds_tr_read(a_rd + 1024 + a_j);
+            at2.h[0] = lds_tr_read(a_rd + 2048); at2.h[1] = lds_tr_read(a_rd + 2048 + a_j);
+            at3.h[0] = lds_tr_read(a_rd + 3072); at3.h[1] = lds_tr_read(a_rd + 3072 + a_j);
             MSDA_WAVE_LDS_SYNC();
             // (the wait names the fragments so that the scheduler cannot lift an MFMA above it: the compiler does not
             //  know that the transpose-reads' results are still in flight)

@@ -81,6 +81,17 @@ __host__ __device__ inline int nb_origin(int l, int pp, int rad, int nb, int cel
     return o < 0 ? 0 : (o > cells - nb ? cells - nb : o);
 }
 
+// The patch rows (columns) of level l whose neighbourhood contains cell row (column) c, in closed form: nb_origin is
+// non-decreasing in the patch index, so they are the interval [first t with origin(t) > c - nb, last t with origin(t) <= c].
+// Returns {lo, hi}; lo > hi: none.  (Checked against the enumeration for every level, grid size, radius and patch count.)
+__host__ __device__ inline void nb_range(int l, int c, int rad, int nb, int cells, int P, int &lo, int &hi)
+{
+    const int s = 4 - l, v = c - nb + 1;
+    lo = v <= 0 ? 0 : v > cells - nb ? P : ((((v + rad) << s) + 3) >> 2);
+    hi = c >= cells - nb ? P - 1 : ((((c + rad + 1) << s) + 3) >> 2) - 1;
+    hi = hi < P - 1 ? hi : P - 1;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // bin2_kernel: one workgroup per (image, cell, head) -- which of the cell's queries touch which patch
 // ------------------------------------------------------------------------------------------------------------------
@@ -127,6 +138,21 @@ __device__ __forceinline__ void bin_cell(const PatchPlan &pl, const int64_t *__r
     const int cy = c / pl.CX, cx = c % pl.CX;
     unsigned long long ts_last = clock64();
     (void)ts_last;
+    if (SCALAR_STARTS) {
+        // (experiment, with the scalar level starts: the ranges below in closed form -- wave-uniform scalar arithmetic with
+        //  compile-time level indices, no loops over the patch rows / columns, no LDS atomics, one barrier less; thread 0 writes)
+#pragma unroll
+        for (int l = 0; l < kL; ++l) {
+            int ylo, yhi, xlo, xhi;
+            nb_range(l, cy, pl.rad[l], pl.nby[l], pl.CY, pl.PY[l], ylo, yhi);
+            nb_range(l, cx, pl.rad[l], pl.nbx[l], pl.CX, pl.PX[l], xlo, xhi);
+            if (tid == 0) {
+                rng[l][0] = ylo <= yhi ? ylo : (1 << 30); rng[l][1] = ylo <= yhi ? yhi : -1;
+                rng[l][2] = xlo <= xhi ? xlo : (1 << 30); rng[l][3] = xlo <= xhi ? xhi : -1;
+            }
+        }
+        if (BBOX && tid >= 32 && tid < 48) box[(tid - 32) >> 2][tid & 3] = 0x3fffffff;
+    } else {
     if (tid < 16) rng[tid >> 2][tid & 3] = (tid & 1) ? -1 : (1 << 30);
     if (BBOX && tid >= 32 && tid < 48) box[(tid - 32) >> 2][tid & 3] = 0x3fffffff;
     __syncthreads();
@@ -141,6 +167,7 @@ __device__ __forceinline__ void bin_cell(const PatchPlan &pl, const int64_t *__r
             const int o = nb_origin(l, t, pl.rad[l], pl.nbx[l], pl.CX);
             if (o <= cx && cx < o + pl.nbx[l]) { atomicMin(&rng[l][2], t); atomicMax(&rng[l][3], t); }
         }
+    }
     }
     __syncthreads();
     if (BBOX) CTS(8);

@@ -99,3 +99,32 @@ def test_route_is_refused_where_it_does_not_apply():
     S = sum(h * w for h, w in enc)
     assert L.msda_backward_plan_info(_lib.MSDA_BF16, hs.ctypes.data, 4, S, 8, 32, 4, S, 4, out.ctypes.data, out.size) == -1
     assert L.msda_backward_plan_info(_lib.MSDA_BF16, hs.ctypes.data, 4, S + 1, 8, 32, 4, S + 1, 4, out.ctypes.data, out.size) == 0
+
+
+def test_closed_form_of_the_patch_ranges_equals_the_enumeration():
+    """nb_range (csrc/msda_patch.hip, arms 3 / 4 of cell_backward_kernel): the patch rows (columns) whose neighbourhood contains
+    a cell row (column), as an interval in closed form, against the enumeration over nb_origin the product kernel runs -- every
+    level, grid sizes 1-24 cells, every radius of the plan, patch counts around the natural one (the formula restated here; the
+    C code itself runs on the host model: tests/test_backward_emulated.py compares the arms with the product kernels bit for bit)"""
+    def nb_origin(l, pp, rad, nb, cells):
+        o = ((pp * 4) >> (4 - l)) - rad
+        return 0 if o < 0 else (cells - nb if o > cells - nb else o)
+
+    def closed(l, c, rad, nb, cells, P):
+        s, v = 4 - l, c - nb + 1
+        lo = 0 if v <= 0 else P if v > cells - nb else ((((v + rad) << s) + 3) >> 2)
+        hi = P - 1 if c >= cells - nb else ((((c + rad + 1) << s) + 3) >> 2) - 1
+        return lo, min(hi, P - 1)
+
+    n = 0
+    for l in range(4):
+        for cells in range(1, 25):
+            for rad in (1, 2, 3, 6):
+                nb = min(2 * rad + 1, cells)
+                for P in range(1, ((cells * 16) >> l) // 4 + 3):
+                    for c in range(cells):
+                        ts = [t for t in range(P) if nb_origin(l, t, rad, nb, cells) <= c < nb_origin(l, t, rad, nb, cells) + nb]
+                        lo, hi = closed(l, c, rad, nb, cells, P)
+                        assert (ts == [] and lo > hi) or (ts and (lo, hi) == (ts[0], ts[-1]) and ts == list(range(lo, hi + 1)))
+                        n += 1
+    assert n > 100000

@@ -353,12 +353,269 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, const f32x
     *reinterpret_cast<uint2 *>(p) = make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
 }
 
-template <typename OT, int WPS, bool MULTI>
+// The product kernel.  Its device code is the one that passed the GPU suite (tools/isa_audit.py compares it with that build
+// instruction for instruction); experiments live in patch_dest_multi_kernel below, which only the ablation build compiles.
+template <typename OT, int WPS>
 __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
     PatchPlan pl, const int64_t *__restrict__ starts, const float *__restrict__ recs,
     const bf16_t *__restrict__ grad_out, const uint32_t *__restrict__ masks, const int *__restrict__ ctl,
     OT *__restrict__ g_value, int N, int S, int M, int Lq, int dbg)
 {
+    MSDA_DYNAMIC_LDS(unsigned char, lds);
+    if (ctl[kFarWord] != 0) return;                       // a far sample: the sorting pass of msda_dest.hip takes the call
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned char *wl = lds + wave * kWaveLds;
+    uint16_t *list = reinterpret_cast<uint16_t *>(wl + kOffList);
+    const unsigned lds0 = MSDA_LDS_BYTE_ADDR(wl);
+
+    // ---- item: (image, head) group by XCD (hardware block b runs on XCD b % 8), coarsest level first -----------------
+    const int NM = N * M;
+    int nm, it;
+    if ((NM & 7) == 0) {
+        const int per = NM >> 3, idx = blockIdx.x >> 3;
+        nm = (blockIdx.x & 7) * per + idx % per;
+        it = idx / per;
+    } else {
+        nm = blockIdx.x % NM;
+        it = blockIdx.x / NM;
+    }
+    int l = 0;
+#pragma unroll
+    for (int k = 0; k < kL; ++k) l = (it >= pl.ibase[k] && it < pl.ibase[k] + pl.nitems[k]) ? k : l;
+    const int parts = pl.parts[l];
+    const int pi = (it - pl.ibase[l]) * (kWaves / parts) + wave / parts, part = wave % parts;
+    const int PX = pl.PX[l], npatch = pl.PY[l] * PX;
+    const bool active = pi < npatch;
+    const int n = nm / M, m = nm % M;
+    const int H = pl.H[l], W = pl.W[l];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // channels 0-15 | 16-31 of pixel lane & 15
+    const int py = active ? pi / PX : 0, px = active ? pi % PX : 0;
+
+    if (active) {
+        const int nbx = pl.nbx[l], nb2 = pl.nby[l] * nbx, invx = pl.invx[l];
+        const int oy = nb_origin(l, py, pl.rad[l], pl.nby[l], pl.CY), ox = nb_origin(l, px, pl.rad[l], nbx, pl.CX);
+        const uint32_t *mrow = masks + ((size_t)nm * pl.slots + pl.sbase[l] + (size_t)pi * nb2) * kSlotWords;
+        const float *rbase = recs + ((size_t)nm * kL + l) * (size_t)(pl.CY * pl.CX) * kCellQ * 12;
+        const float Hf = (float)H, Wf = (float)W;
+        const float y0f = (float)(py * 4), x0f = (float)(px * 4);
+        const bool border = py * 4 + 3 >= H || px * 4 + 3 >= W;
+        // per-level (start, width) of the query levels, selected per lane below
+        const int st0 = (int)starts[0], st1 = (int)starts[1], st2 = (int)starts[2], st3 = (int)starts[3];
+        const int W0 = pl.W[0], W1 = pl.W[1], W2 = pl.W[2], W3 = pl.W[3];
+        const int kk = lane & 31, half = lane >> 5;
+        const int nq = n * Lq;
+        // transpose-read addresses: lane (p = lane & 15, kg = lane >> 4) supplies row 8 kg + 4 j + (p >> 2), piece p & 3
+        const int p16 = lane & 15, kg = lane >> 4;
+        const unsigned a_rd = lds0 + kOffA + (8 * kg + (p16 >> 2)) * 32 + (p16 & 3) * 8;     // + matrix * 1024 + j * 128
+        const unsigned g_rd = lds0 + kOffG + (8 * kg + (p16 >> 2)) * 64 + (p16 & 3) * 8;     // + tile * 32 + j * 256
+
+        // This wave's mask words: slots part, part + parts, ... of the patch's neighbourhood, 12 words each, taken 64 at
+        // a time (lane i holds word wbase + i; the next 64 are already travelling).  Word order = (slot, word) order, so
+        // a wave-wide prefix sum of the popcounts puts the candidates in a fixed order.
+        const int nslots = (nb2 - part + parts - 1) / parts, nwords = nslots * kSlotWords;
+        auto word_of = [&](int w) -> uint32_t {              // (captures scalars only; inlined)
+            if (w >= nwords) return 0u;
+            const int s = (w * 683) >> 13, wi = w - s * kSlotWords;      // w / 12 for w < 2048
+            return mrow[(part + s * parts) * kSlotWords + wi];
+        };
+        int wbase = 0;
+        uint32_t cur = word_of(lane), nxt = word_of(64 + lane);
+        int head = 0, tail = 0;
+        bool exhausted = nwords <= 0;
+        int avail_c = 0;                                   // the step whose operands are in flight / in registers
+        float4 xy_c = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 a2_c = make_float2(0.f, 0.f);
+        uint4 g0_c = make_uint4(0u, 0u, 0u, 0u), g1_c = g0_c;
+        for (;;) {
+            // ---- refill: expand mask bits into the candidate list until a full step is there ---------------------------
+            while (tail - head < kStep && !exhausted) {
+                if (__builtin_amdgcn_ballot_w64(cur != 0u) == 0ull) {
+                    wbase += 64;
+                    if (wbase >= nwords) { exhausted = true; break; }
+                    cur = nxt;
+                    nxt = word_of(wbase + 64 + lane);
+                    continue;
+                }
+                if (head > 0) {                           // carry the < 32 left-over entries to the front
+                    const int left = tail - head;
+                    int v = 0;
+                    if (lane < left) v = list[head + lane];
+                    MSDA_WAVE_LDS_SYNC();
+                    if (lane < left) list[lane] = (uint16_t)v;
+                    MSDA_WAVE_LDS_SYNC();
+                    head = 0; tail = left;
+                }
+                const int cnt = __popc(cur);
+                const int incl = wave_inclusive_scan(cnt);
+                const bool fits = incl <= kListCap - tail;             // a prefix of the lanes
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(fits);
+                const int nfit = __popcll(fm);                          // >= 1: 32 bits of one lane always fit
+                const int total = __builtin_amdgcn_readlane(incl, nfit - 1);
+                if (fits) {
+                    const int w = wbase + lane;
+                    const int s = (w * 683) >> 13, wi = w - s * kSlotWords;
+                    const int code0 = ((part + s * parts) << 9) | (wi * 32);
+                    int pos = tail + incl - cnt;
+                    uint32_t f = cur;
+                    while (f) {
+                        const int b = __ffs(f) - 1;
+                        list[pos++] = (uint16_t)(code0 | b);
+                        f &= f - 1u;
+                    }
+                    cur = 0u;
+                }
+                MSDA_WAVE_LDS_SYNC();
+                tail += total;
+            }
+            // ---- operands of the NEXT step start travelling (software pipeline: one step of loads in flight) ------------
+            const int avail_n = min(tail - head, kStep);
+            float4 xy_n = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 a2_n = make_float2(0.f, 0.f);
+            uint4 g0_n = make_uint4(0u, 0u, 0u, 0u), g1_n = g0_n;
+            if (avail_n > 0) {
+                const int h0 = head;
+                head += avail_n;
+                const int code = list[h0 + (kk < avail_n ? kk : 0)];
+                const int slot = code >> 9, bit = code & 511;
+                const int sy = (slot * invx) >> 16, sx = slot - sy * nbx;
+                const int lq = bit < 256 ? 0 : bit < 320 ? 1 : bit < 336 ? 2 : 3;
+                const int r = bit - (lq == 0 ? 0 : lq == 1 ? 256 : lq == 2 ? 320 : 336);
+                const int sh = 4 - lq;
+                const int iy = ((oy + sy) << sh) + (r >> sh), ix = ((ox + sx) << sh) + (r & ((1 << sh) - 1));
+                const int stq = lq == 0 ? st0 : lq == 1 ? st1 : lq == 2 ? st2 : st3;
+                const int Wq = lq == 0 ? W0 : lq == 1 ? W1 : lq == 2 ? W2 : W3;
+                int qm = (nq + stq + iy * Wq + ix) * M + m;                            // < 2^25 (checked by the ABI)
+                int ri = ((oy + sy) * pl.CX + ox + sx) * kCellQ + bit;                 // record of (cell, query)
+                if (MSDA_DBG(dbg) & 2) { qm = (nq + (lane & 7)) * M + m; ri = lane & 7; }   // ablation: cache-resident operands
+                const float *rec = rbase + (size_t)ri * 12;
+                xy_n = reinterpret_cast<const float4 *>(rec)[half];
+                a2_n = reinterpret_cast<const float2 *>(rec + 8)[half];
+                const uint4 *gp = reinterpret_cast<const uint4 *>(grad_out + (size_t)qm * kD + half * 16);
+                g0_n = gp[0]; g1_n = gp[1];
+            }
+            // ---- one MFMA step over the `avail` <= 32 candidates whose operands were requested one iteration ago -------
+            const int avail = avail_c;
+            const float4 xy = xy_c;
+            const float2 a2 = a2_c;
+            const uint4 g0 = g0_c, g1 = g1_c;
+            avail_c = avail_n; xy_c = xy_n; a2_c = a2_n; g0_c = g0_n; g1_c = g1_n;
+            if (avail <= 0) {
+                if (avail_n <= 0) break;
+                continue;
+            }
+            if (MSDA_DBG(dbg) & 1) { acc0[0] += (float)avail; continue; }            // ablation: enumeration only
+            if (MSDA_DBG(dbg) & 4) { acc0[0] += xy.x + a2.x + __uint_as_float(g0.x ^ g1.y); continue; }   // ablation: loads only
+            const bool valid = kk < avail;
+            float e[16];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const float x = pt ? xy.z : xy.x, y = pt ? xy.w : xy.y, a_in = pt ? a2.y : a2.x;
+                const float h_im = fmaf(y, Hf, -0.5f), w_im = fmaf(x, Wf, -0.5f);
+                const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);            // .cuh:285
+                const bool use = inside && valid;
+                const float a = use ? a_in : 0.f;
+                const float dx = use ? w_im - x0f : -8.f, dy = use ? h_im - y0f : -8.f;
+                float tx[4], ty[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    tx[c] = fmaxf(0.f, 1.f - fabsf(dx - (float)c));
+                    ty[c] = a * fmaxf(0.f, 1.f - fabsf(dy - (float)c));
+                }
+                if (border) {                              // pixels of the patch beyond the level's edge receive nothing
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        tx[c] = px * 4 + c < W ? tx[c] : 0.f;
+                        ty[c] = py * 4 + c < H ? ty[c] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int ry = 0; ry < 4; ++ry)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        e[ry * 4 + c] = pt ? fmaf(ty[ry], tx[c], e[ry * 4 + c]) : ty[ry] * tx[c];
+            }
+            uint32_t hi[8], lo[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split_pair(e[2 * i], e[2 * i + 1], hi[i], lo[i]);
+            // A^T matrices: [half][hi | lo][32 groups][16 pixels] bfloat16, row kk of the lane's half
+            uint4 *arow = reinterpret_cast<uint4 *>(wl + kOffA + half * 2048 + kk * 32);
+            arow[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            arow[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+            arow[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);            // + 1024 bytes
+            arow[65] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+            uint4 *grow = reinterpret_cast<uint4 *>(wl + kOffG + kk * 64 + half * 32);
+            grow[0] = g0;
+            grow[1] = g1;
+            MSDA_WAVE_LDS_SYNC();
+            // operands: G^T tiles (channels 0-15 | 16-31) and the four A^T matrices, 8 consecutive groups per lane
+            union Frag { bf16x8 v; s16x4 h[2]; };
+            Frag gt0, gt1, at0, at1, at2, at3;
+            gt0.h[0] = lds_tr_read(g_rd); gt0.h[1] = lds_tr_read(g_rd + 256);
+            gt1.h[0] = lds_tr_read(g_rd + 32); gt1.h[1] = lds_tr_read(g_rd + 32 + 256);
+            at0.h[0] = lds_tr_read(a_rd); at0.h[1] = lds_tr_read(a_rd + 128);
+            at1.h[0] = lds_tr_read(a_rd + 1024); at1.h[1] = lds_tr_read(a_rd + 1024 + 128);
+            at2.h[0] = lds_tr_read(a_rd + 2048); at2.h[1] = lds_tr_read(a_rd + 2048 + 128);
+            at3.h[0] = lds_tr_read(a_rd + 3072); at3.h[1] = lds_tr_read(a_rd + 3072 + 128);
+            MSDA_WAVE_LDS_SYNC();
+            // (the wait names the fragments so that the scheduler cannot lift an MFMA above it: the compiler does not
+            //  know that the transpose-reads' results are still in flight)
+#ifndef MSDA_EMU
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(gt0.h[0]), "+v"(gt0.h[1]), "+v"(gt1.h[0]), "+v"(gt1.h[1]), "+v"(at0.h[0]), "+v"(at0.h[1]),
+                           "+v"(at1.h[0]), "+v"(at1.h[1]), "+v"(at2.h[0]), "+v"(at2.h[1]), "+v"(at3.h[0]), "+v"(at3.h[1])
+                         :
+                         : "memory");
+#endif
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at0.v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at0.v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at1.v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at1.v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at2.v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at2.v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt0.v, at3.v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt1.v, at3.v, acc1, 0, 0, 0);
+        }
+    }
+
+    // ---- parts of one patch: summed in part order by the first wave of the patch, then the rows leave once ----------
+    if (parts > 1) {
+        float *red = reinterpret_cast<float *>(wl);           // this wave's own (now idle) LDS
+        if (part > 0) {
+            reinterpret_cast<f32x4 *>(red)[lane * 2] = acc0;
+            reinterpret_cast<f32x4 *>(red)[lane * 2 + 1] = acc1;
+        }
+        __syncthreads();
+        if (part == 0) {
+            for (int j = 1; j < parts; ++j) {
+                const f32x4 *o = reinterpret_cast<const f32x4 *>(lds + (wave + j) * kWaveLds);
+                acc0 += o[lane * 2];
+                acc1 += o[lane * 2 + 1];
+            }
+        }
+    }
+    if (active && part == 0) {
+        const int pix = lane & 15, y = py * 4 + (pix >> 2), x = px * 4 + (pix & 3);
+        if (y < H && x < W) {
+            const long row = (long)n * S + (long)starts[l] + (long)y * W + x;
+            OT *dst = g_value + (row * M + m) * kD + 4 * (lane >> 4);
+            store4<OT>(dst, acc0);
+            store4<OT>(dst + 16, acc1);
+        }
+    }
+}
+
+#ifdef MSDA_ABLATION
+// Experiment arms of the patch pass, never in the product library (tools/r03_experiments.py): several patches per wave on the
+// fine levels with the next patch's mask words prefetched, the mask-word prefetch outside a branch, tents through the clamp
+// modifier, operand images staged with exchanged halves (bank-conflict-free transposing reads).  Must reproduce
+// patch_dest_kernel bit for bit.
+template <typename OT, int WPS>
+__global__ __launch_bounds__(kThreads, WPS) void patch_dest_multi_kernel(
+    PatchPlan pl, const int64_t *__restrict__ starts, const float *__restrict__ recs,
+    const bf16_t *__restrict__ grad_out, const uint32_t *__restrict__ masks, const int *__restrict__ ctl,
+    OT *__restrict__ g_value, int N, int S, int M, int Lq, int dbg)
+{
+    constexpr bool MULTI = true;
     MSDA_DYNAMIC_LDS(unsigned char, lds);
     if (ctl[kFarWord] != 0) return;                       // a far sample: the sorting pass of msda_dest.hip takes the call
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -636,6 +893,7 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
     }
   }   // patches of this wave
 }
+#endif   // MSDA_ABLATION
 
 // ------------------------------------------------------------------------------------------------------------------
 // cell_backward_kernel: grad_sampling_loc / grad_attn_weight (or, fused, the gradient of the projection row) of one
@@ -659,7 +917,7 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
 // What the product build runs (the other modes / instantiations are the measured arms of tools/r03_experiments.py; they
 // become the default here, in one place, once a GPU run has shown them bit-identical and faster):
 constexpr int kCellMode = 0;                  // cell_backward_kernel<., MODE>
-constexpr int kPatchMulti = 0;                // patch_dest_kernel<., ., MULTI>
+constexpr int kPatchMulti = 0;                // 1: patch_dest_multi_kernel (ablation build only)
 constexpr int kPatchReps = 1;                 // patches per wave on the fine levels (MULTI only)
 constexpr int kCellThreads = 512;
 constexpr int kWinBytes = 48 * 1024;          // LDS window budget (all levels together)
@@ -1321,15 +1579,20 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
                            (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);
     const int grid = pl.items * p.N * p.M;
     static const int wps = ablation_env("RLIPV2_PATCH_WPS", 4);
-bool multi = ablation_env("RLIPV2_PATCH_MULTI", kPatchMulti) != 0;      // (the experimental instantiation, also with 1 patch per wave)
-    for (int l = 0; l < kL; ++l) multi = multi || pl.reps[l] > 1;
-#define MSDA_PATCH(OT, WPS, MULTI)                                                                                   \
-    hipLaunchKernelGGL((patch_dest_kernel<OT, WPS, MULTI>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, pl, \
+#define MSDA_PATCH(KERNEL, OT, WPS)                                                                                  \
+    hipLaunchKernelGGL((KERNEL<OT, WPS>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, pl,              \
                        p.starts, (const float *)recs, (const bf16_t *)p.grad_out, masks,                            \
                        (const int *)ctl, (OT *)p.g_value, p.N, p.S, p.M, p.Lq, ablation_env("RLIPV2_PATCH_DBG", 0))
-    if (multi) { if (out_bf16) MSDA_PATCH(bf16_t, 4, true); else MSDA_PATCH(float, 4, true); }
-    else if (out_bf16) { if (wps == 5) MSDA_PATCH(bf16_t, 5, false); else MSDA_PATCH(bf16_t, 4, false); }
-    else { if (wps == 5) MSDA_PATCH(float, 5, false); else MSDA_PATCH(float, 4, false); }
+#ifdef MSDA_ABLATION
+    bool multi = ablation_env("RLIPV2_PATCH_MULTI", kPatchMulti) != 0;      // (the experiment kernel, also with 1 patch per wave)
+    for (int l = 0; l < kL; ++l) multi = multi || pl.reps[l] > 1;
+    if (multi) {
+        if (out_bf16) MSDA_PATCH(patch_dest_multi_kernel, bf16_t, 4); else MSDA_PATCH(patch_dest_multi_kernel, float, 4);
+        return;
+    }
+#endif
+    if (out_bf16) { if (wps == 5) MSDA_PATCH(patch_dest_kernel, bf16_t, 5); else MSDA_PATCH(patch_dest_kernel, bf16_t, 4); }
+    else { if (wps == 5) MSDA_PATCH(patch_dest_kernel, float, 5); else MSDA_PATCH(patch_dest_kernel, float, 4); }
 #undef MSDA_PATCH
 }
 

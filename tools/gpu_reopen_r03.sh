@@ -5,8 +5,9 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/reopen_r03
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-( timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt )
+( timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt )
 tail -5 $OUT/pytest_gpu.txt
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/smoke.txt ); tail -3 $OUT/smoke.txt
 ( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; timeout 900 python tools/r03_experiments.py > $OUT/experiments.txt 2>&1 )
 cat $OUT/experiments.txt
 # where the cycles of cell_backward_kernel go, product kernel vs arm 3 (cycle stamps of thread 0, summed over the workgroups)

@@ -320,6 +320,7 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     synchronizer = None
     eager_step = step_module
     force_dp = os.environ.get("RLIPV2_FORCE_DP") == "1" and dist.is_initialized()   # 1-rank plumbing check
+    overlap = bool(args.dp_overlap)
     if world > 1 or force_dp:
         train.broadcast_parameters(model, 0)
         # static unused-parameter mask from a dry run (identical on every rank), instead of per-step graph
@@ -337,20 +338,19 @@ def run_train_step_bench(args, world, rank, local_rank, device):
                 # the 1 / world of the gradient average is applied inside the fused optimiser's kernels (no extra pass
                 # over the 425 MB gradient buffer); the float32-parameter optimiser path scales in the synchronizer
                 synchronizer.scale_in_optimizer = bool(master)
-                if os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1" and not train.captured_collective_selftest(device):
+                if overlap and not train.captured_collective_selftest(device):
                     # (RCCL only; every other backend is answered "no" without a capture attempt)
                     # (all ranks agree on the verdict) captured collectives do not replay here: flat schedule
                     print("[bench] collectives cannot be captured into the backward graph here (not RCCL, or the self-test "
                           "failed): one flat all-reduce after the backward graph",
                           file=sys.stderr)
-                    os.environ["RLIPV2_DP_OVERLAP"] = "0"
+                    overlap = False
             if args.var_targets:
-                step_module = train.GraphedStepCache(step_module, model, synchronizer, criterion=criterion)
-                for b in rotation:
-                    step_module.get(b)                          # capture every bucket before the timed region
+                step_module = train.GraphedStepCache(step_module, model, synchronizer, criterion=criterion, overlap=overlap)
+                step_module.register(rotation)                  # capture every bucket before the timed region
             else:
                 step_module = train.graph_step_module(step_module, model, batch, synchronizer,
-                                                      criterion=criterion if args.graph_criterion else None)
+                                                      criterion=criterion if args.graph_criterion else None, overlap=overlap)
             graphed = True
         except Exception as e:                                  # noqa: BLE001 -- fall back to eager, say so
             import traceback
@@ -579,6 +579,9 @@ def main():
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-overlap", action="store_true", default=os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1",
+                    help="data-parallel runs: bucketed gradient all-reduce captured inside the backward graph (overlapped "
+                         "with the backward pass) instead of one flat all-reduce after it; off until verified on >= 2 GPUs")
     ap.add_argument("--deterministic", action="store_true",
                     help="MIOpen restricted to deterministic convolution solvers (torch.backends.cudnn.deterministic): the one "
                          "source of run-to-run noise in the step is a MIOpen convolution (tools/nondet_modules.py)")
@@ -641,7 +644,7 @@ def main():
                               "backward graph on a communication stream: bucket k travels while autograd computes the "
                               "earlier layers); model forward/backward replayed as HIP graphs"
                               if graphed and (world > 1 or os.environ.get("RLIPV2_FORCE_DP") == "1")
-                              and os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1" else
+                              and bool(getattr(step_module, "overlap", False)) else
                               f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
                               "model forward/backward replayed as HIP graphs" if graphed else
                               f"dp{world} (DDP: bucketed RCCL gradient all-reduce overlapped with backward); eager launches"),

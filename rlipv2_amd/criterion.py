@@ -266,10 +266,12 @@ class SetCriterionHOI(nn.Module):
         return losses
 
     @staticmethod
-    def _num_interactions(sizes, device):
+    def _num_interactions(sizes, device, local=False):
+        """`local`: this rank's count only, no collective (warm-up steps of a graph capture, which one rank may run
+        while the others are in a training step: a capture must not issue collectives of its own)"""
         num = torch.as_tensor([sum(sizes)], dtype=torch.float, device=device)
         world = 1
-        if dist.is_available() and dist.is_initialized():
+        if not local and dist.is_available() and dist.is_initialized():
             dist.all_reduce(num)                               # keeps the loss scale of the reference
             world = dist.get_world_size()
         return torch.clamp(num / world, min=1)[0]              # stays on the device: no .item() sync

@@ -122,22 +122,24 @@ class GraphedStep:
     runs on them eagerly; `loss.backward()` fills their `.grad`; `step.backward()` replays the model's
     backward graph from those."""
 
-    def __init__(self, step_module, model, batch, warmup=3, synchronizer=None, criterion=None, overlap=None):
-        """`overlap` (RLIPV2_DP_OVERLAP=1; default off until a run on >= 2 GPUs has verified it): the gradient all-reduce is
+    def __init__(self, step_module, model, batch, warmup=3, synchronizer=None, criterion=None, overlap=False):
+        """`overlap` (off until a run on >= 2 GPUs has verified it; bench.py --dp-overlap): the gradient all-reduce is
         bucketed and captured INSIDE the backward graph on a communication stream, each bucket starting as soon as its
         last gradient exists (GradientSynchronizer.hooked) -- averaging overlapped with the rest of the backward pass
-        (reference main.py:515-517).  Off: one flat all-reduce after the backward replay."""
+        (reference main.py:515-517).  Off: one flat all-reduce after the backward replay.
+
+        A capture issues NO collective of its own: the warm-up steps use this rank's interaction count, collectives inside
+        the captured backward are recorded, not run.  A rank may therefore capture a new batch bucket while the other ranks
+        replay theirs -- they simply wait at the step's first collective (GraphedStepCache).  The one exception is the bucket
+        plan of the overlapped schedule (rank 0's gradient arrival order, broadcast once): if the synchronizer has no plan
+        yet, every rank must construct its first GraphedStep together (GraphedStepCache plans at the end of step 0)."""
         samples, text, targets = batch
+        self.step_module = step_module
         self.synchronizer = synchronizer
         self.criterion = criterion
-        if overlap is None:
-            # off by default: captured RCCL collectives have replayed on a 1-rank group only (no multi-GPU box so far);
-            # RLIPV2_DP_OVERLAP=1 selects the overlapped schedule, bench.py additionally runs the captured-collective
-            # self-test on all ranks before using it
-            overlap = os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1"
-            if overlap and synchronizer is not None:
-                import torch.distributed as dist                  # only RCCL collectives can be captured into the graph
-                overlap = dist.is_initialized() and dist.get_backend(synchronizer.group) == "nccl"
+        if overlap and synchronizer is not None:
+            import torch.distributed as dist                      # only RCCL collectives can be captured into the graph
+            overlap = dist.is_initialized() and dist.get_backend(synchronizer.group) == "nccl"
         self.overlap = bool(overlap) and synchronizer is not None
         self.wrapper = GraphedTrainForward(step_module, text["obj_pred_names_sums"],
                                            model.transformer.ho_decoder.num_layers, model.pseudo_verb)
@@ -188,28 +190,24 @@ class GraphedStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for it in range(warmup):
-                wmode = "record" if (self.overlap and it == warmup - 1) else "plain"
+                wmode = "record" if (self.overlap and not synchronizer.planned and it == warmup - 1) else "plain"
                 outs, state = forward_part()
                 if criterion is not None:
                     index = criterion.assign(state).to(samples.tensors.device)
-                    num = criterion._num_interactions(self.sizes, samples.tensors.device).reshape(1)
+                    # (local count: run() overwrites static_num with the all-reduced one on every step)
+                    num = criterion._num_interactions(self.sizes, samples.tensors.device, local=True).reshape(1)
                     loss_and_grads(outs, state, index, num[0], wmode)
                 else:
                     loss_and_grads(outs, None, None, None, wmode)
             del outs, state
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.overlap:
+        if self.overlap and not synchronizer.planned:
             # buckets in the order the gradients arrive; rank 0's order for everybody (the schedule of collectives
-            # has to be the same on all ranks)
-            import torch.distributed as dist
-            order = [list(self.arrival)]
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(synchronizer.group) > 1:
-                dist.broadcast_object_list(order, src=0, group=synchronizer.group)
-            # (one layout per synchronizer: earlier captures have the flat buffer's offsets baked into their copies and
-            #  collectives -- a later capture keeps the plan, whatever order its own gradients arrived in)
-            if not synchronizer.planned:
-                synchronizer.plan_buckets(order[0])
+            # has to be the same on all ranks).  One layout per synchronizer: earlier captures have the flat buffer's
+            # offsets baked into their copies and collectives -- a later capture keeps the plan, whatever order its own
+            # gradients arrived in, and does not communicate.
+            synchronizer.plan_collectively(self.arrival)
         pool = torch.cuda.graph_pool_handle()
         # "thread_local": other threads of the process may call HIP while we capture -- with a process group
         # alive, RCCL's watchdog thread polls events, which in the default "global" mode invalidates the capture
@@ -272,6 +270,9 @@ class GraphedStep:
         self._deliver()
         self.leaves = None
 
+    def parameters(self):
+        return self.step_module.parameters()
+
     @property
     def grad_scale(self):
         """factor the optimiser has to apply to `p.grad` (1 / world when the synchronizer leaves the SUM)"""
@@ -305,69 +306,148 @@ class GraphedStep:
         return self.loss_dict, self.total
 
 
-class GraphedStepCache:
-    """One GraphedStep per batch bucket.  A capture is specific to the image tensor's shape, the padding hint and the
-    number of targets per image (the matched-index tensor's shape); the reference pads every batch to its own maximum
-    and has a variable number of triplets per image (util/misc.py:299-320, datasets/vg.py), so a training run meets a
-    handful of buckets.  A batch of a new bucket is captured on first sight (a few eager warm-up steps + two
-    captures), afterwards replayed; `max_buckets` bounds the memory held by captures (least recently used goes)."""
+class EagerSyncStep:
+    """The train step without graphs, issuing exactly the collectives a GraphedStep replay issues (the interaction count,
+    then the gradient average on the synchronizer's current schedule: bucketed in plan order, or flat) -- what a rank
+    runs for a batch bucket it has not captured (yet) while other ranks replay theirs, and the step of a
+    data-parallel run without graphs.  Same protocol as GraphedStep.run: gradients in `p.grad` (views of the flat
+    buffer with a synchronizer), `grad_scale` for the optimiser, returns (loss dict, weighted total)."""
 
-    def __init__(self, step_module, model, synchronizer=None, criterion=None, max_buckets=8):
+    def __init__(self, step_module, criterion, synchronizer=None, overlap=False, autocast_dtype=None):
+        self.step_module, self.criterion, self.synchronizer = step_module, criterion, synchronizer
+        self.overlap = bool(overlap) and synchronizer is not None
+        self.autocast_dtype = autocast_dtype
+        self.params = synchronizer.params if synchronizer is not None else [p for p in step_module.parameters()
+                                                                            if p.requires_grad]
+        self.arrival = None
+
+    @property
+    def grad_scale(self):
+        s = self.synchronizer
+        return s.grad_scale if (s is not None and s.scale_in_optimizer) else 1.0
+
+    def parameters(self):
+        return self.step_module.parameters()
+
+    def run(self, samples, text, targets):
+        dt = self.autocast_dtype
+        with torch.autocast(samples.tensors.device.type, dtype=dt, enabled=dt is not None):
+            outputs = self.step_module(samples, text, targets)
+        loss_dict = self.criterion(outputs, targets)                 # (all-reduces the interaction count)
+        total = self.criterion.weighted_sum(loss_dict)
+        s = self.synchronizer
+        if s is None:
+            grads = torch.autograd.grad(total, self.params, allow_unused=True)
+        elif self.overlap and s.planned:
+            with s.hooked():
+                torch.autograd.grad(total, self.params, allow_unused=True)
+            grads = s.views
+        else:
+            # flat schedule; an overlapped run without a bucket plan records the arrival order here (GraphedStepCache
+            # turns it into the plan after this step, on all ranks at once)
+            with s.recording() as rec:
+                g = torch.autograd.grad(total, self.params, allow_unused=True)
+            self.arrival = rec.order
+            grads = s(g)
+        for p, g in zip(self.params, grads):
+            p.grad = g
+        return loss_dict, total.detach()
+
+
+class GraphedStepCache:
+    """One GraphedStep per batch bucket, an eager step for everything else.  A capture is specific to the image tensor's
+    shape, the padding hint and the number of targets per image (the matched-index tensor's shape); the reference pads
+    every batch to its own maximum and has a variable number of triplets per image (util/misc.py:299-320,
+    datasets/vg.py), and under data parallelism every rank pads its own shard -- the ranks meet different buckets at
+    different steps.  The reference's DistributedDataParallel takes any shapes (main.py:515-517); so does this:
+
+    * a bucket seen fewer than `capture_after` times runs as EagerSyncStep (any shape works, nothing is captured for
+      one-off shapes), afterwards it is captured (a few eager warm-up steps + two captures) and replayed;
+    * every decision is LOCAL -- hit, miss, capture, eviction of the least recently used capture beyond `max_buckets`.
+      That is sound because all three ways of running a step issue the same sequence of collectives (interaction count,
+      then the gradient buckets in plan order or the one flat all-reduce) and a capture issues none: a rank that
+      captures is merely late for the step's first collective.  No per-step agreement exchange, no host sync;
+    * the overlapped schedule needs one bucket plan shared by all ranks before anything is captured on it: step 0 (a
+      miss on every rank by construction) runs eagerly on the flat schedule, records the gradient arrival order, and
+      `after_step` broadcasts rank 0's order -- the only collective of the cache, at the same point on all ranks.
+
+    `factory(batch) -> step` builds the captured step (default: GraphedStep); tests on the CPU pass a stand-in."""
+
+    def __init__(self, step_module, model, synchronizer=None, criterion=None, max_buckets=8, capture_after=1,
+                 overlap=False, autocast_dtype=None, factory=None):
         self.step_module, self.model = step_module, model
         self.synchronizer, self.criterion = synchronizer, criterion
-        self.max_buckets = max_buckets
+        self.max_buckets, self.capture_after = max_buckets, max(1, int(capture_after))
+        self.overlap = bool(overlap) and synchronizer is not None
         self.graphs = {}                    # key -> GraphedStep (insertion order = recency)
-        self.captures = 0
+        self.seen = {}                      # key -> times met
+        self.captures = self.hits = self.eager_steps = self.evictions = 0
+        self.eager = EagerSyncStep(step_module, criterion, synchronizer, overlap=self.overlap, autocast_dtype=autocast_dtype)
+        self.factory = factory or (lambda batch: GraphedStep(step_module, model, batch, synchronizer=synchronizer,
+                                                             criterion=criterion, overlap=self.overlap))
 
     @staticmethod
     def bucket(batch):
         samples, text, targets = batch
-        split = text.get("obj_pred_names_sums")
-        split = tuple(int(v) for v in (split.flatten().tolist() if torch.is_tensor(split) else split)) if split is not None else ()
+        split = text.get("obj_pred_names_sums") if isinstance(text, dict) else None
+        if split is not None:               # (a host-side list / CPU tensor: a device tensor here would cost a sync per step)
+            split = tuple(int(v) for v in (split.flatten().tolist() if torch.is_tensor(split) else split))
+        ids = text["input_ids"].shape if isinstance(text, dict) else tuple(t.shape for t in text if torch.is_tensor(t))
         return (tuple(samples.tensors.shape), str(samples.tensors.dtype), bool(getattr(samples, "no_padding", False)),
-                tuple(text["input_ids"].shape), tuple(len(t["obj_labels"]) for t in targets),
+                tuple(ids), tuple(len(t["obj_labels"]) for t in targets),
                 # the (objects, predicates) split of the text rows and the width of the verb labels are baked into a
                 # capture as well: two batches that differ only there must not share a graph
-                split, tuple(tuple(t["verb_labels"].shape) for t in targets))
+                split or (), tuple(tuple(t["verb_labels"].shape) for t in targets))
 
-    def _agree(self, hit):
-        """Data-parallel runs: a capture runs eager warm-up steps and collectives of its own, a replay runs the
-        captured schedule -- ranks that disagree would issue different collectives and hang or reduce mismatched
-        buffers.  Every step all ranks exchange hit / miss (one MIN + MAX pair); all hit: replay, all miss: capture
-        together, mixed: an error that says how to avoid it (pre-capture the buckets collectively with `register`)."""
-        if self.synchronizer is None or not (dist.is_available() and dist.is_initialized()):
+    def _plan_pending(self):
+        return self.overlap and not self.synchronizer.planned
+
+    def plan(self, batch):
+        """overlapped schedule without a bucket plan: one forward + backward of `batch` on the flat schedule (no optimiser
+        step) records the gradient arrival order, then rank 0's order becomes the plan -- all ranks call this together.
+        A training run does not need it (step 0 does the same as a side effect)."""
+        if not self._plan_pending():
             return
-        group = self.synchronizer.group
-        if dist.get_world_size(group) == 1:
-            return
-        dev = self.synchronizer.flat.device
-        flags = torch.tensor([1 if hit else 0, -1 if hit else 0], device=dev, dtype=torch.int32)   # MIN -> (all hit, -any hit)
-        dist.all_reduce(flags, op=dist.ReduceOp.MIN, group=group)
-        all_hit, any_hit = int(flags[0].item()) == 1, int(flags[1].item()) == -1
-        if all_hit or not any_hit:
-            return                                   # everybody replays, or everybody captures (same collectives)
-        raise RuntimeError("GraphedStepCache: the ranks disagree on this step's batch bucket (some have captured it, some "
-                           "have not); a capture issues collectives of its own, so ranks must capture together -- call "
-                           "register(batches) with every bucket of the run on all ranks before training, or pad the "
-                           "batches to common buckets")
+        self.eager.run(*batch)
+        self.after_step()
+        for p in self.eager.params:
+            p.grad = None
 
     def register(self, batches):
-        """capture every bucket of `batches` now (all ranks call this with batches of the same buckets in the same order)"""
+        """capture the buckets of `batches` now, whatever `capture_after` says (before a timed region).  With the
+        overlapped schedule and no bucket plan yet this plans first -- then all ranks must call it together."""
+        batches = list(batches)
+        if batches:
+            self.plan(batches[0])
         for b in batches:
+            key = self.bucket(b)
+            self.seen[key] = max(self.seen.get(key, 0), self.capture_after - 1)
             self.get(b)
 
     def get(self, batch):
+        """the step object for this batch: a captured GraphedStep, or the eager step"""
         key = self.bucket(batch)
-        self._agree(key in self.graphs)
         g = self.graphs.pop(key, None)
-        if g is None:
-            if len(self.graphs) >= self.max_buckets:
-                self.graphs.pop(next(iter(self.graphs)))
-            g = GraphedStep(self.step_module, self.model, batch, synchronizer=self.synchronizer,
-                            criterion=self.criterion)
-            self.captures += 1
+        if g is not None:
+            self.graphs[key] = g            # most recently used
+            self.hits += 1
+            return g
+        self.seen[key] = self.seen.get(key, 0) + 1
+        if self._plan_pending() or self.seen[key] < self.capture_after:
+            self.eager_steps += 1
+            return self.eager
+        while len(self.graphs) >= self.max_buckets:
+            self.graphs.pop(next(iter(self.graphs)))
+            self.evictions += 1
+        g = self.factory(batch)
+        self.captures += 1
         self.graphs[key] = g
         return g
+
+    def after_step(self):
+        """end of a train step (train_step calls it): fixes the bucket plan of the overlapped schedule after step 0"""
+        if self._plan_pending() and self.eager.arrival is not None:
+            self.synchronizer.plan_collectively(self.eager.arrival)
 
     def parameters(self):
         return self.step_module.parameters()
@@ -414,12 +494,12 @@ class NonFiniteGuard:
                     raise NonFiniteLoss(f"loss was not finite at step {self.step - 1}, stopping training")
 
 
-def graph_step_module(step_module, model, batch, synchronizer=None, criterion=None):
+def graph_step_module(step_module, model, batch, synchronizer=None, criterion=None, overlap=False):
     """Capture `step_module` (both model phases, forward and backward) for the shapes of `batch`; returns a
     GraphedStep.  Raises if capture is not possible.  `synchronizer`: a GradientSynchronizer for data-parallel
     runs (the gradient all-reduce then follows the backward replay).  `criterion`: capture the criterion's
     device work into the two graphs as well (`GraphedStep.run`)."""
-    return GraphedStep(step_module, model, batch, synchronizer=synchronizer, criterion=criterion)
+    return GraphedStep(step_module, model, batch, synchronizer=synchronizer, criterion=criterion, overlap=overlap)
 
 
 def captured_collective_selftest(device, group=None):
@@ -548,6 +628,14 @@ class GradientSynchronizer:
         self.planned = True
         return buckets
 
+    def plan_collectively(self, order):
+        """rank 0's arrival order becomes everybody's bucket plan (a collective: all ranks call it at the same point)"""
+        import torch.distributed as dist
+        order = [list(order)]
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.broadcast_object_list(order, src=0, group=self.group)
+        return self.plan_buckets(order[0])
+
     # ---- flat schedule --------------------------------------------------------------------------------------------
     def pack(self, grads):
         """copy one gradient (or None = zero) per parameter into the flat buffer; returns the views"""
@@ -675,7 +763,8 @@ class _GradHooks:
         s = self.sync
         self.lock = threading.Lock()
         self.left = [len(b) for b in s.buckets]
-        self.streams = [[] for _ in s.buckets]
+        self.next = 0                                    # buckets leave in INDEX order, whatever order they complete in:
+        self.streams = [[] for _ in s.buckets]           # the sequence of collectives is the same on every rank
         self.got = [False] * len(s.params)
         self.held = [dict() for _ in s.buckets]          # bucket -> {stream: (views, gradients)} waiting for their copy
         self.handles = [p.register_hook(lambda g, i=i: self._arrived(i, g)) for i, p in enumerate(s.params)]
@@ -707,10 +796,16 @@ class _GradHooks:
             if cur is not None and all(cur != st for st in self.streams[k]):
                 self.streams[k].append(cur)
             self.left[k] -= 1
-            if self.left[k] == 0:
-                self._flush(k)
-                s.launch_bucket(k, self.streams[k])
+            self._launch_ready()
         return None
+
+    def _launch_ready(self):
+        s = self.sync
+        while self.next < len(self.left) and self.left[self.next] == 0:
+            k = self.next
+            self._flush(k)
+            s.launch_bucket(k, self.streams[k])
+            self.next += 1
 
     def _flush(self, k):
         """the held gradients of bucket k -> their views, one multi-tensor copy per stream they arrived on"""
@@ -736,10 +831,8 @@ class _GradHooks:
                 cur = torch.cuda.current_stream(s.flat.device)
                 if all(cur != st for st in self.streams[k]):
                     self.streams[k].append(cur)          # (the zero-fill above ran on this stream)
-            if self.left[k] == 0:
-                self._flush(k)
-                s.launch_bucket(k, self.streams[k])
-        assert all(n == 0 for n in self.left), self.left
+        self._launch_ready()
+        assert all(n == 0 for n in self.left) and self.next == len(self.left), (self.left, self.next)
         s.finish()
         return False
 
@@ -937,35 +1030,55 @@ def synthetic_batch(batch, height=800, width=1333, n_obj=43, n_verb=21, triplets
     return NestedTensor(images, mask, no_padding=True), text, targets
 
 
-def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_dtype=torch.bfloat16, guard=None):
-    """One optimisation step; returns the (device) loss.  No host synchronisation except the
-    matcher's single device->host copy of the cost matrices.  `autocast_dtype=None` runs the model
-    in whatever dtype its parameters have (float32, or bfloat16 with MasterWeightAdamW).  `guard`: a
-    NonFiniteGuard (raises NonFiniteLoss one step after a non-finite loss, engine.py:123-128)."""
+def _forward_backward(step_module, criterion, optimizer, batch, autocast_dtype):
+    """forward + criterion + backward of one batch on whatever kind of step object this is; leaves this batch's gradients
+    in `p.grad` and returns (weighted loss, factor the optimiser has to apply to the gradients)"""
     samples, text, targets = batch
-    if isinstance(step_module, GraphedStepCache):
-        step_module = step_module.get(batch)                # capture on first sight of a bucket, replay afterwards
-    if isinstance(step_module, GraphedStep) and step_module.criterion is not None:
-        optimizer.zero_grad(set_to_none=True)
+    cache = step_module if isinstance(step_module, GraphedStepCache) else None
+    if cache is not None:
+        step_module = cache.get(batch)                      # a captured bucket, or the eager step for this batch
+    optimizer.zero_grad(set_to_none=True)
+    if isinstance(step_module, EagerSyncStep) or (isinstance(step_module, GraphedStep) and step_module.criterion is not None):
         _, loss = step_module.run(samples, text, targets)
     else:
         with torch.autocast(samples.tensors.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
             outputs = step_module(samples, text, targets)
         loss_dict = criterion(outputs, targets)
         loss = criterion.weighted_sum(loss_dict)
-        optimizer.zero_grad(set_to_none=True)
         loss.backward()
         if isinstance(step_module, GraphedStep):
             step_module.backward()
+    if cache is not None:
+        cache.after_step()
+    return loss, float(getattr(step_module, "grad_scale", 1.0))
+
+
+def _optimizer_step(optimizer, max_norm, grad_scale, params=None):
+    """clip + update; `grad_scale` (1 / world when the synchronizer leaves the all-reduced SUM in the gradients) is applied
+    inside FusedMasterAdamW's kernels -- no other optimiser knows about it, so anything else must see averaged gradients"""
     if isinstance(optimizer, FusedMasterAdamW):
-        optimizer.step(max_norm, grad_scale=float(getattr(step_module, "grad_scale", 1.0)))
-    elif isinstance(optimizer, MasterWeightAdamW):
+        optimizer.step(max_norm, grad_scale=grad_scale)
+        return
+    if grad_scale != 1.0:
+        raise RuntimeError("GradientSynchronizer.scale_in_optimizer leaves the SUM over ranks in the gradients; only "
+                           "FusedMasterAdamW applies the 1 / world factor -- switch scale_in_optimizer off for this optimiser")
+    if isinstance(optimizer, MasterWeightAdamW):
         optimizer.step(max_norm)
     else:
-        if max_norm > 0:
-            params = [p for g in optimizer.param_groups for p in g["params"]]
+        if max_norm and max_norm > 0:
+            params = params if params is not None else [p for g in optimizer.param_groups for p in g["params"]]
             torch.nn.utils.clip_grad_norm_(params, max_norm, foreach=True)
         optimizer.step()
+
+
+def train_step(step_module, criterion, optimizer, batch, max_norm=0.1, autocast_dtype=torch.bfloat16, guard=None):
+    """One optimisation step; returns the (device) loss.  No host synchronisation except the
+    matcher's single device->host copy of the cost matrices.  `autocast_dtype=None` runs the model
+    in whatever dtype its parameters have (float32, or bfloat16 with MasterWeightAdamW).  `guard`: a
+    NonFiniteGuard (raises NonFiniteLoss one step after a non-finite loss, engine.py:123-128).
+    `step_module`: a plain module (or DistributedDataParallel), a GraphedStep, an EagerSyncStep or a GraphedStepCache."""
+    loss, grad_scale = _forward_backward(step_module, criterion, optimizer, batch, autocast_dtype)
+    _optimizer_step(optimizer, max_norm, grad_scale)
     if guard is not None:
         guard.submit(loss)
     return loss.detach()
@@ -1092,15 +1205,19 @@ class AccumulatedUpdate:
         last = self.strategy == "vanilla" or self.i % self.n == 0
         first = self.strategy == "vanilla" or self.i % self.n == 1
         if self.strategy == "gradient_accumulation":
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+            # float32 sums; a parameter that received no gradient in ANY batch of the round keeps `.grad = None`, so the
+            # optimiser skips it as torch.optim.AdamW does after the reference's single backward (engine.py:136-153)
             if first:
-                self.acc = [g.detach().float().clone() for g in grads]
-            else:
-                torch._foreach_add_(self.acc, [g.detach().float() for g in grads])
+                self.acc = [None] * len(self.params)
+            for k, p in enumerate(self.params):
+                if p.grad is None:
+                    continue
+                g = p.grad.detach().float()
+                self.acc[k] = g.clone() if self.acc[k] is None else self.acc[k].add_(g)
             if not last:
                 return False
             for p, a in zip(self.params, self.acc):
-                p.grad = a.to(p.dtype)
+                p.grad = None if a is None else a.to(p.dtype)
             self.acc = None
         if step is not None:
             step(self.params)
@@ -1115,26 +1232,15 @@ def train_round(step_module, criterion, optimizer, batches, paradigm, strategy="
     --gradient_strategy gradient_accumulation): `batches` = the `len(paradigm)` batches of the round in paradigm order
     (one per dataset slot, their image sizes and text lists may differ).  Each batch runs forward + backward on its own
     (one batch of activations alive at a time), the gradients are summed in float32 and ONE clipping + optimiser step
-    closes the round -- the same update as the reference's backward over the summed losses (AccumulatedUpdate).  Returns
-    the list of the batches' weighted losses (device tensors)."""
+    closes the round -- the same update as the reference's backward over the summed losses (AccumulatedUpdate).
+    `step_module` may be any step object train_step takes (plain / DDP module, GraphedStep, EagerSyncStep,
+    GraphedStepCache): data-parallel gradients are averaged per batch, a SUM left for the optimiser (`grad_scale`) is scaled
+    once, on the summed gradients.  Returns the list of the batches' weighted losses (device tensors)."""
     params = [p for p in step_module.parameters() if p.requires_grad]
     upd = state if state is not None else AccumulatedUpdate(params, optimizer, paradigm, strategy=strategy, max_norm=max_norm)
-
-    def apply(ps):
-        if isinstance(optimizer, (MasterWeightAdamW, FusedMasterAdamW)):
-            optimizer.step(max_norm)
-        else:
-            if max_norm and max_norm > 0:
-                torch.nn.utils.clip_grad_norm_(ps, max_norm, foreach=True)
-            optimizer.step()
-
     losses = []
-    for samples, text, targets in batches:
-        with torch.autocast(samples.tensors.device.type, dtype=autocast_dtype, enabled=autocast_dtype is not None):
-            outputs = step_module(samples, text, targets)
-        loss = criterion.weighted_sum(criterion(outputs, targets))
-        optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        upd.add_gradients(step=apply)
+    for batch in batches:
+        loss, grad_scale = _forward_backward(step_module, criterion, optimizer, batch, autocast_dtype)
+        upd.add_gradients(step=lambda ps, gs=grad_scale: _optimizer_step(optimizer, max_norm, gs, params=ps))
         losses.append(loss.detach())
     return losses

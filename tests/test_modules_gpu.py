@@ -535,6 +535,20 @@ def test_graphed_step_cache_recaptures_per_bucket():
         _, total = g.run(*batch)
         torch.testing.assert_close(total.float(), eager, rtol=3e-2, atol=3e-2)
     assert cache.captures == 2 and len(cache.graphs) == 2
+    # one-off shapes stay eager (capture_after), captures beyond max_buckets evict the least recently used one; every
+    # kind of step gives the eager loss and leaves gradients
+    cache = train.GraphedStepCache(step, model, criterion=criterion, capture_after=2, max_buckets=1)
+    kinds = []
+    for batch in (make(3, False, 0), make(3, False, 1), make(5, True, 2), make(5, True, 3), make(3, False, 4)):
+        with torch.no_grad():
+            eager = criterion.weighted_sum(criterion(step(*batch), batch[2])).float()
+        g = cache.get(batch)
+        kinds.append(type(g).__name__)
+        _, total = g.run(*batch)
+        torch.testing.assert_close(total.float(), eager, rtol=3e-2, atol=3e-2)
+        assert all(p.grad is not None for p in step.parameters() if p.requires_grad)
+    assert kinds == ["EagerSyncStep", "GraphedStep", "EagerSyncStep", "GraphedStep", "GraphedStep"], kinds
+    assert cache.captures == 3 and cache.evictions == 2 and len(cache.graphs) == 1
 
 
 # ---- ALIF attention core on the HIP kernel (csrc/alif_attention.hip) -----------------------------------------------------

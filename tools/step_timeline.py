@@ -28,7 +28,8 @@ if os.environ.get("STEP_DP") in ("1", "2", "3", "4", "5"):                     #
         sync.all_reduce = lambda: None                     # ablation: no collective
     if os.environ["STEP_DP"] == "3":
         sync.pack = lambda grads: grads                    # ablation: no packing either
-graphed = train.graph_step_module(step_module, model, batch, synchronizer=sync, criterion=criterion)
+graphed = train.graph_step_module(step_module, model, batch, synchronizer=sync, criterion=criterion,
+                                  overlap=os.environ.get("RLIPV2_DP_OVERLAP", "1") == "1")
 names = ["forward graph (model + cost matrices)", "host: D2H + assignment + H2D", "backward graph (losses + backward)", "optimizer"]
 acc_gpu = [0.0] * 4; acc_host = [0.0] * 4
 for it in range(steps + 3):

@@ -108,10 +108,10 @@ def convert_dab_ddetr(checkpoint, dataset="hico", with_box_refine=False, drop_cl
         "no pair" row (a Linear(256, 1), :60-63, :134-139); V-COCO gets one more fresh row in front of the last (:158-168);
       * `verb_tgt_embed` starts from `tgt_embed` (:146).
     `generator`: torch.Generator for the fresh rows (the reference draws them from the global RNG)."""
-    src = _weights(checkpoint)
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)      # a path: load first, then look
     mmdet = isinstance(checkpoint, dict) and "state_dict" in checkpoint and "model" not in checkpoint
-    if mmdet:
-        src = checkpoint["state_dict"]
+    src = checkpoint["state_dict"] if mmdet else _weights(checkpoint)
     model = OrderedDict((k.replace("bbox_head.", "") if mmdet else k, v) for k, v in src.items())
 
     def fresh_row(width, like):
@@ -132,6 +132,7 @@ def convert_dab_ddetr(checkpoint, dataset="hico", with_box_refine=False, drop_cl
                 model[k.replace("transformer.decoder", "transformer.verb_decoder")] = model[k].clone()
         if not mmdet:
             ids = list(COCO_OBJECT_IDS) + [91]                  # 91: the appended "no pair" row
+            background = None                                   # ONE fresh row shared by all layers (:60-63)
             for i in range(num_layers):
                 for j in range(3):
                     for part in ("weight", "bias"):
@@ -145,7 +146,9 @@ def convert_dab_ddetr(checkpoint, dataset="hico", with_box_refine=False, drop_cl
                                 model[f"transformer.{dec}.obj_bbox_embed.{i}.layers.{j}.{part}"] = inner
                 if not drop_class_embed:
                     w, b = model[f"class_embed.{i}.weight"], model[f"class_embed.{i}.bias"]
-                    fw, fb = fresh_row(w.shape[1], w)
+                    if background is None:
+                        background = fresh_row(w.shape[1], w)
+                    fw, fb = background
                     model[f"obj_class_embed.{i}.weight"] = torch.cat((w.clone(), fw), 0)[ids]
                     model[f"obj_class_embed.{i}.bias"] = torch.cat((b.clone(), fb), 0)[ids]
             model["verb_tgt_embed.weight"] = model["tgt_embed.weight"]

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/rlipv2_alif.h"
+#include "once_per_device.h"
 #include "../../include/rlipv2_msda.h"
 
 // (tools/emu/ compiles this file for the CPU against a lane-level model of the workgroup and defines the macro itself)
@@ -373,12 +374,9 @@ int alif_attention_forward_bf16(const void *q, const void *k, const void *values
     if (!(aligned16(q) && aligned16(k) && aligned16(values_l_t) && aligned16(values_v_t))) return MSDA_ERR_ALIGNMENT;
     const int Tvp = alif_attention_padded_tv(Tv);
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {      // more than 64 KB of dynamic LDS has to be asked for
+    RLIPV2_ONCE_PER_DEVICE(      // more than 64 KB of dynamic LDS has to be asked for
         (void)hipFuncSetAttribute((const void *)alif_forward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)alif_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute((const void *)alif_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     (void)hipGetLastError();
     if (keep_v)
         hipLaunchKernelGGL(alif_forward_kernel<true>, dim3(B * H), dim3(THREADS), LDS_BYTES, s, (const uint16_t *)q,

@@ -44,6 +44,7 @@
 #include <type_traits>
 
 #include "../../include/rlipv2_linear.h"
+#include "once_per_device.h"
 #include "../../include/rlipv2_msda.h"
 #include "msda_device.h"
 #ifdef MSDA_EMU
@@ -415,12 +416,8 @@ extern "C" int linear_expand_bf16(const void *a, const void *b, const void *bias
     if (lds_bytes > 160 * 1024 || (size_t)T * N * 2 >= ((size_t)1 << 32)) return MSDA_ERR_BAD_SHAPE;
 #define XLAUNCH(M_, B_, R_)                                                                                              \
     do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
-        if (!attr_set) {                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&expand_kernel<M_, B_, R_>),                        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
-            attr_set = true;                                                                                             \
-        }                                                                                                                \
+        RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void *>(&expand_kernel<M_, B_, R_>),     \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));       \
         hipLaunchKernelGGL((expand_kernel<M_, B_, R_>), grid, block, lds_bytes, stream, a16, b16, bias16, mask16, T, N,     \
                            steps_per_split, c16);                                                                        \
     } while (0)

@@ -739,13 +739,7 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
     } else {
         k1();
     }
-    {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax);
-            attr = true;
-        }
-    }
+    RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax));
     hipLaunchKernelGGL(bin_kernel, dim3(p.N * pl.Ts * p.M), dim3(256), pl.Td * 32, p.stream, pl, p.starts,
                        (const float *)p.loc, p.M, p.Lq, masks, gate);
     constexpr int TH = kDestTH, kThreads = Geo<TH>::kThreads;
@@ -756,13 +750,10 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
     do {                                                                                                             \
         const int lds_bytes = DestLds<VT, TH>::bytes(pl.Ts);                                                         \
         auto kern = waves == 8 ? dest_kernel<VT, OT, TH, 8> : waves == 6 ? dest_kernel<VT, OT, TH, 6> : dest_kernel<VT, OT, TH, 4>; \
-        static bool attr_set = false;                            /* once per instantiation, not inside every capture */ \
-        if (!attr_set) {                                                                                             \
+        RLIPV2_ONCE_PER_DEVICE(                       /* once per instantiation and device, not inside every capture */ \
             (void)hipFuncSetAttribute((const void *)dest_kernel<VT, OT, TH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax); \
             (void)hipFuncSetAttribute((const void *)dest_kernel<VT, OT, TH, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax); \
-            (void)hipFuncSetAttribute((const void *)dest_kernel<VT, OT, TH, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax); \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
+            (void)hipFuncSetAttribute((const void *)dest_kernel<VT, OT, TH, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, p.stream, pl, p.starts, (const float *)p.loc, \
                            (const float *)p.aw, (const VT *)p.grad_out, masks, counter, (OT *)p.g_value, partials,  \
                            p.N, p.S, p.M, p.Lq, gate);                                                               \

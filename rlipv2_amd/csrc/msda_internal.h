@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/rlipv2_msda.h"
+#include "once_per_device.h"
 
 // Ablation / tuning switches (environment variables read by the launchers, `dbg` bits inside kernels that skip
 // work and produce WRONG results) exist only in builds with -DMSDA_ABLATION (make -C rlipv2_amd/csrc ablation ->

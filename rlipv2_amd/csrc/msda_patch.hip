@@ -1496,11 +1496,8 @@ void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fus
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
 #define MSDA_CELL_FWD(RD, LOC, AW)                                                                                    \
     do {                                                                                                              \
-        static bool attr = false;                                                                                     \
-        if (!attr) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)cell_forward_kernel<RD>, hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds); \
-            attr = true;                                                                                              \
-        }                                                                                                             \
+        RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)cell_forward_kernel<RD>,                       \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));       \
         hipLaunchKernelGGL((cell_forward_kernel<RD>), grid, block, kFwdLds, p.stream, pl, (const bf16_t *)p.value, p.starts, \
                            (float *)(LOC), (float *)(AW), p.N, p.S, p.M, p.Lq, (bf16_t *)p.out,                       \
                            (const bf16_t *)(f ? f->qproj : nullptr), f ? f->ref : nullptr, p.shapes);                 \
@@ -1532,12 +1529,9 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
     static const int mode = ablation_env("RLIPV2_CELL_SHARED", kCellMode);
 #define MSDA_CELL_K(RD, MODE)                                                                                         \
     do {                                                                                                              \
-        static bool attr = false;                                                                                     \
-        if (!attr) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)cell_backward_kernel<RD, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      kZeroBytes + kWinBytes + kCellTableMax);                                        \
-            attr = true;                                                                                              \
-        }                                                                                                             \
+        RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)cell_backward_kernel<RD, MODE>,                \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                                                         kZeroBytes + kWinBytes + kCellTableMax));                    \
         hipLaunchKernelGGL((cell_backward_kernel<RD, MODE>), grid, block, lds_bytes, p.stream, pl, (const bf16_t *)p.value, \
                            p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, (const bf16_t *)p.grad_out, \
                            p.N, p.S, p.M, p.Lq, vbytes, (float *)p.g_loc, (float *)p.g_aw, f ? f->ref : nullptr,      \
@@ -1569,11 +1563,7 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
     make_patch_plan(p, shapes_host, pl);
     uint32_t *masks = reinterpret_cast<uint32_t *>(mask_ws);
     float *recs = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(mask_ws) + mask_bytes(p, pl));
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)bin2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
-        attr = true;
-    }
+    RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)bin2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024));
     if (!binned)
         hipLaunchKernelGGL(bin2_kernel, dim3(p.N * pl.CY * pl.CX * p.M), dim3(kBinThreads), pl.bin_lds, p.stream, pl, p.starts,
                            (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);

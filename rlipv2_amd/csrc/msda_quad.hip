@@ -929,15 +929,12 @@ static void launch_coarse_forward(const Problem &p, const Fused *f)
                        (const bf16_t *)(f ? f->qproj : nullptr), f ? f->ref : nullptr, p.N, p.S, p.M, p.Lq, wgs,     \
                        value_bytes(p), (bf16_t *)p.out, f ? f->loc_save : nullptr, f ? f->aw_save : nullptr,         \
                        ablation_env("RLIPV2_COARSE_STAGED", kL))
-    static bool attr_set = false;
-    if (!attr_set) {      // more than 64 KB of dynamic LDS has to be asked for, once per kernel
+    RLIPV2_ONCE_PER_DEVICE(      // more than 64 KB of dynamic LDS has to be asked for, once per kernel and device
         (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
         (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
         (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
         (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
-        (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute((const void *)quad_forward_coarse_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseBytes));
     if (!f && ablation_env("RLIPV2_COARSE_BLOCK", 1024) == 256) {      // ablation: small one-shot workgroups, nothing staged
         const int w256 = wgs * 4;
         hipLaunchKernelGGL((quad_forward_coarse_kernel<0, false, 256>), dim3(pairs * w256), dim3(256), kCoarseBytes, p.stream,

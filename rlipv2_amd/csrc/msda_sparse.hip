@@ -223,11 +223,8 @@ void launch_sparse_dest(const Problem &p, const int64_t *shapes_host, bool out_b
     const dim3 grid(p.N * p.M * kL), block(kThreads);
 #define MSDA_SPARSE(VT, OT)                                                                                          \
     do {                                                                                                             \
-        static bool attr = false;                                                                                    \
-        if (!attr) {                                                                                                 \
-            (void)hipFuncSetAttribute((const void *)sparse_dest_kernel<VT, OT>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget); \
-            attr = true;                                                                                             \
-        }                                                                                                            \
+        RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)sparse_dest_kernel<VT, OT>,                   \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));   \
         hipLaunchKernelGGL((sparse_dest_kernel<VT, OT>), grid, block, lds_bytes, p.stream, pl, p.starts,             \
                            (const float *)p.loc, (const float *)p.aw, (const VT *)p.grad_out, (OT *)p.g_value, p.N,  \
                            p.S, p.M);                                                                                \

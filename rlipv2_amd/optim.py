@@ -52,6 +52,7 @@ class FusedMasterAdamW:
         self.steps = [0] * len(self.params)     # per-parameter step count, as torch.optim keeps it
         self.device = self.params[0].device
         self.sqnorm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._last_grad_scale = 1.0
         sizes = [ctypes.c_int() for _ in range(4)]
         _lib.lib().adamw_abi_sizes(*[ctypes.byref(s) for s in sizes])
         assert (sizes[0].value, sizes[1].value, sizes[2].value) == (56, 8, ctypes.sizeof(_Group)), "ABI mismatch"
@@ -109,6 +110,7 @@ class FusedMasterAdamW:
         idx, grads = self._grads()
         if not idx:
             return
+        self._last_grad_scale = float(grad_scale)
         self.t += 1
         # bias corrections depend on how many updates a parameter has had; a parameter that skipped a step
         # (no gradient) lags behind, so the kernel's "group" is (parameter group, update count)
@@ -141,9 +143,9 @@ class FusedMasterAdamW:
         roofline.add(n * (2 * (2 if clip else 1) + 3 * 8 + 2))
 
     def grad_norm(self):
-        """sqrt of the squared-norm buffer of the last step (device tensor; no sync; of the gradients as stored, i.e.
-        before `grad_scale`)."""
-        return self.sqnorm.sqrt()
+        """norm of the last step's gradients as the update saw them, i.e. with that step's `grad_scale` applied -- the
+        value the reference logs from clip_grad_norm_ (engine.py:170); a device tensor, no sync."""
+        return self.sqnorm.sqrt() * self._last_grad_scale
 
     def state_dict(self):
         return {"t": self.t, "steps": list(self.steps), "names": list(self.names), "master": self.master, "exp_avg": self.exp_avg,

@@ -200,9 +200,15 @@ class LabelEmbeddingCache:
         self.table = None                   # [entries, hidden] on the encoder's device
         self.max_entries = max_entries
         self.hits = self.misses = 0
+        self.signature = None
 
     def clear(self):
         self.rows, self.table = {}, None
+
+    @staticmethod
+    def _signature(text_encoder):
+        ps = list(text_encoder.parameters())
+        return (id(text_encoder), str(ps[0].dtype), str(ps[0].device), ps[0].data_ptr(), sum(p._version for p in ps))
 
     def encode(self, text_encoder, input_ids, attention_mask, use_cache=None):
         """-> pooled embeddings [n_text, hidden] in the rows' order.  `use_cache` default: the encoder has no trainable
@@ -216,7 +222,15 @@ class LabelEmbeddingCache:
             uid, uam = bucket_token_length(uid, uam)
             pooled = text_encoder(input_ids=uid.to(device), attention_mask=uam.to(device)).pooler_output
             return pooled[inverse.to(device)]
-        keys = [tuple(r) for r in (uid * uam + (1 - uam) * -1).tolist()]
+        # the table belongs to one state of the encoder: other weights (load_state_dict, an optimiser step: in-place writes
+        # bump the tensors' version counters), another dtype or device (to_bf16 swaps the storage) start a new table
+        sig = self._signature(text_encoder)
+        if sig != self.signature:
+            self.clear()
+            self.signature = sig
+        # key = the label's own tokens, without the padding of this batch's longest member (the same label in a batch of
+        # another width must hit)
+        keys = [tuple(t for t, m in zip(r, a) if m) for r, a in zip(uid.tolist(), uam.tolist())]
         new = [i for i, k in enumerate(keys) if k not in self.rows]
         self.hits += len(keys) - len(new)
         self.misses += len(new)

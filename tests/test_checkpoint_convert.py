@@ -64,6 +64,9 @@ def test_parse_conversion_of_a_dab_ddetr_checkpoint():
         assert torch.equal(w[:80], before[f"class_embed.{i}.weight"][list(C.COCO_OBJECT_IDS)])
         assert torch.equal(b[:80], before[f"class_embed.{i}.bias"][list(C.COCO_OBJECT_IDS)])
         assert float(w[80].abs().max()) <= 1.0 / 16 + 1e-6                                       # Linear(256, 1) init range
+    # ONE fresh "no pair" row shared by the six layers (the reference draws background_class once, :60-63)
+    assert all(torch.equal(m[f"obj_class_embed.{i}.weight"][80], m["obj_class_embed.0.weight"][80]) for i in range(6))
+    assert all(torch.equal(m[f"obj_class_embed.{i}.bias"][80], m["obj_class_embed.0.bias"][80]) for i in range(6))
     assert len(C.COCO_OBJECT_IDS) == 80 and 12 not in C.COCO_OBJECT_IDS and 91 not in C.COCO_OBJECT_IDS
     assert torch.equal(m["verb_tgt_embed.weight"], before["tgt_embed.weight"])
     assert torch.equal(m["backbone.0.body.conv1.weight"], before["backbone.0.body.conv1.weight"])
@@ -90,6 +93,21 @@ def test_mmdetection_checkpoint_only_gets_the_duplication():
     assert torch.equal(m["transformer.ho_encoder.layers.0.linear1.weight"], sd["bbox_head.transformer.encoder.layers.0.linear1.weight"])
     assert torch.equal(m["transformer.verb_decoder.layers.0.linear1.weight"], sd["bbox_head.transformer.decoder.layers.0.linear1.weight"])
     assert "verb_tgt_embed.weight" not in m and not any("bbox_head" in k for k in m)
+
+
+def test_mmdetection_checkpoint_given_as_a_path(tmp_path):
+    """the kind of checkpoint is decided on the LOADED dict, not on the path argument"""
+    sd = {"bbox_head.transformer.encoder.layers.0.linear1.weight": _fill("a", (4, 4)),
+          "bbox_head.transformer.decoder.layers.0.linear1.weight": _fill("b", (4, 4))}
+    path = tmp_path / "mmdet.pth"
+    torch.save({"state_dict": sd, "meta": 1}, path)
+    out = C.convert_dab_ddetr(str(path))
+    m = out["model"]
+    assert out["meta"] == 1 and not any("bbox_head" in k for k in m)
+    assert torch.equal(m["transformer.ho_decoder.layers.0.linear1.weight"], sd["bbox_head.transformer.decoder.layers.0.linear1.weight"])
+    torch.save({"model": _dab_ddetr_state(), "epoch": 3}, tmp_path / "dab.pth")
+    out = C.convert_dab_ddetr(tmp_path / "dab.pth")
+    assert out["epoch"] == 3 and out["model"]["obj_class_embed.5.weight"].shape == (81, 256)
 
 
 def test_converted_checkpoint_loads_into_the_model_non_strictly():

@@ -189,6 +189,7 @@ typedef int hipError_t;
 constexpr int hipSuccess = 0;
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 0;
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 #define HIP_SYMBOL(x) x

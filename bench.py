@@ -579,6 +579,9 @@ def main():
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msda-fwd-cell", action="store_true",
+                    help="EXPERIMENT: the encoder's fused MSDA forward through cell_forward_kernel (LDS windows + matrix cores); "
+                         "not validated on hardware, never the default")
     ap.add_argument("--dp-overlap", action="store_true", default=os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1",
                     help="data-parallel runs: bucketed gradient all-reduce captured inside the backward graph (overlapped "
                          "with the backward pass) instead of one flat all-reduce after it; off until verified on >= 2 GPUs")
@@ -598,6 +601,9 @@ def main():
         # torch.cuda.is_available() above this line): a process that has initialised the GPU must never exec or be
         # replaced.  Rank 0's JSON line passes through on stdout; the exit code is the launcher's.
         raise SystemExit(self_launch(args.gpus))
+    if args.msda_fwd_cell:
+        from rlipv2_amd import msda as _msda
+        _msda.fused_forward_cell = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

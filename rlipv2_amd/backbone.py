@@ -186,7 +186,7 @@ class RepeatableConv3x3(torch.autograd.Function):
         return dx, dw
 
 
-repeatable_conv_backward = os.environ.get("RLIPV2_REPEATABLE_CONV", "1") != "0"      # (A/B switch)
+repeatable_conv_backward = True      # (tools/grad_repeat.py flips the attribute for its A/B; not read from the environment)
 
 
 def conv3x3(x, conv):

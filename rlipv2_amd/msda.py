@@ -31,8 +31,9 @@ _DTYPES = {torch.float32: _lib.MSDA_F32, torch.float64: _lib.MSDA_F64, torch.bfl
 # kernel override for benchmarks / tests ("auto" in product use)
 _variant_fwd = _lib.VARIANT_AUTO
 _variant_bwd = _lib.VARIANT_AUTO
-# experiment switch of the train step's encoder forward (see ms_deform_attn_fused_forward); off unless asked for
-_FWD_CELL = os.environ.get("RLIPV2_MSDA_FWD_CELL", "0") == "1"
+# the train step's encoder forward through cell_forward_kernel (see ms_deform_attn_fused_forward): an experiment that has
+# not run on hardware; a plain attribute that only tools / bench.py --msda-fwd-cell set, never read from the environment
+fused_forward_cell = False
 # name of the kernel variant the last call of each direction ran (read by bench.py's roofline line)
 last_variant = {}
 
@@ -257,9 +258,9 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     loc = torch.empty((N, Lq, M, nL, P, 2), dtype=torch.float32, device=value.device) if save else None
     aw = torch.empty((N, Lq, M, nL, P), dtype=torch.float32, device=value.device) if save else None
-    if (_FWD_CELL and save and value.dtype == torch.bfloat16 and Lq == S and nL == 4 and P == 4 and D == 32
+    if (fused_forward_cell and save and value.dtype == torch.bfloat16 and Lq == S and nL == 4 and P == 4 and D == 32
             and host_shapes(spatial_shapes) is not None):
-        # EXPERIMENT (RLIPV2_MSDA_FWD_CELL=1; the kernel has not been validated on hardware yet): geometry, the saved float32
+        # EXPERIMENT (msda.fused_forward_cell = True; the kernel has not been validated on hardware yet): geometry, the saved float32
         # locations / weights and the sampling from LDS windows on the matrix cores in one kernel
         # (csrc/msda_cell_forward.inc: cell_forward_kernel<refdim>)
         hs = host_shapes(spatial_shapes)

@@ -18,6 +18,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_cell_forward_emulated import CLANG  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang++ as host compiler")
+# Kernels whose device code is instruction-identical to a build that passed the GPU suite (tools/isa_audit.py,
+# profiles/r04_isa_audit_vs_round2_gputest.txt) gain nothing from the host model: their cases run only when asked for.  The
+# fused optimiser (its `grad_scale` argument has not run on hardware) and the weight-gradient kernel (under work) always run.
+unchanged_since_gpu_run = pytest.mark.skipif(os.environ.get("RLIPV2_TEST_EMU_FULL", "0") != "1",
+                                             reason="device code unchanged since a green GPU run; RLIPV2_TEST_EMU_FULL=1 runs it")
 vp, ci = ctypes.c_void_p, ctypes.c_int
 
 
@@ -91,6 +96,7 @@ def test_fused_adamw_against_torch(lib, max_norm, grad_scale):
         torch.testing.assert_close(m2[i], st["exp_avg_sq"], rtol=2e-5, atol=1e-6 * float(st["exp_avg_sq"].abs().max()))
 
 
+@unchanged_since_gpu_run
 @pytest.mark.parametrize("rows,with_b", [(700, True), (129, False)])
 def test_add_layernorm_forward_and_backward_against_torch(lib, rows, with_b):
     C, eps = 256, 1e-5
@@ -127,6 +133,7 @@ def test_add_layernorm_forward_and_backward_against_torch(lib, rows, with_b):
     del tol
 
 
+@unchanged_since_gpu_run
 def test_elementwise_tails_against_torch(lib):
     torch.manual_seed(3)
     n, C = 8 * 1000 + 8 * 3, 64                                     # (multiples of 8 elements: the kernels' vector width)
@@ -151,6 +158,7 @@ def test_elementwise_tails_against_torch(lib):
     torch.testing.assert_close(dx.float(), refdx, rtol=2.0 ** -7, atol=2.0 ** -8)
 
 
+@unchanged_since_gpu_run
 def test_dab_box_refinement_against_the_reference_formula(lib):
     """dab_refine_boxes: sigmoid(delta + inverse_sigmoid(ref)) with the reference's clamp and eps (util/misc.py:460-464,
     dab_deformable/deformable_transformer.py:1511-1541), float32 and bfloat16 deltas, values on and beyond the clamp"""
@@ -170,6 +178,7 @@ def test_dab_box_refinement_against_the_reference_formula(lib):
         torch.testing.assert_close(out, want, rtol=2e-6, atol=1e-7)
 
 
+@unchanged_since_gpu_run
 def test_token_major_group_norm_against_torch(lib):
     """GroupNorm(32, 256) of every pyramid level straight into its slice of the flattened [N, S, 256] tensor, forward and
     backward (csrc/groupnorm_tokens.hip; reference input_proj's GroupNorm + the flatten, models/hoi.py:1936-1957,
@@ -212,6 +221,7 @@ def test_token_major_group_norm_against_torch(lib):
         start += h
 
 
+@unchanged_since_gpu_run
 @pytest.mark.parametrize("dropout", [False, True])
 def test_alif_attention_core_against_torch(lib, dropout):
     """alif_attention_forward_bf16 / alif_attention_softmax_backward_bf16 (csrc/alif_attention.hip: shared logits q k^T, a
@@ -301,6 +311,7 @@ def test_mfma_weight_gradient_against_torch(lib, T, M, K, f32):
     torch.testing.assert_close(db.float(), want_b, rtol=tol, atol=tol * float(want_b.abs().max()))
 
 
+@unchanged_since_gpu_run
 @pytest.mark.parametrize("T,N,mask,bias,relu", [(300, 128, False, True, True), (77, 192, True, False, False),
                                                 (256, 64, False, False, False), (513, 128, True, True, False)])
 def test_mfma_expand_gemm_against_torch(lib, T, N, mask, bias, relu):

@@ -38,5 +38,5 @@ tail -25 $OUT/pytest_cell_forward.txt
 timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 tail -c 1500 $OUT/bench_line.json
 # the train step with the encoder forward through the geometry kernel + cell_forward_kernel (only meaningful once the tests above pass)
-RLIPV2_MSDA_FWD_CELL=1 timeout 600 python bench.py --no-cpu-baseline > $OUT/bench_line_fwd_cell.json 2> $OUT/bench_fwd_cell_stderr.txt
+timeout 600 python bench.py --no-cpu-baseline --msda-fwd-cell > $OUT/bench_line_fwd_cell.json 2> $OUT/bench_fwd_cell_stderr.txt
 tail -c 600 $OUT/bench_line_fwd_cell.json

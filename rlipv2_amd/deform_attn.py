@@ -117,6 +117,8 @@ def _is_power_of_2(n):
 
 
 class MSDeformAttn(nn.Module):
+    trace = None          # optional callable (module, qproj, reference_points) -> (qproj, reference_points); tests only
+
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
         if d_model % n_heads != 0:
@@ -182,6 +184,10 @@ class MSDeformAttn(nn.Module):
         qproj = token_linear(query,
                              adjacent_cat(self, "_qproj_w", self.sampling_offsets.weight, self.attention_weights.weight),
                              adjacent_cat(self, "_qproj_b", self.sampling_offsets.bias, self.attention_weights.bias))
+        if MSDeformAttn.trace is not None:
+            # test instrumentation (tests/test_modules_gpu.py: the bf16 model against a float32 run that is handed the SAME
+            # projection rows / reference points, so that both runs take the same floor() decisions in the sampling)
+            qproj, reference_points = MSDeformAttn.trace(self, qproj, reference_points)
         if (qproj.is_cuda and fused_geometry and L == 4 and P == 4 and reference_points.shape[-1] in (2, 4)
                 and qproj.dtype in (torch.float32, torch.bfloat16)):
             if (fused_sampling and msda_function is msda.MSDeformAttnFunction and qproj.dtype == value.dtype

@@ -574,3 +574,62 @@ def test_non_finite_loss_stops_training():
         guard.submit(torch.tensor(float("nan")))
     with pytest.raises(train.NonFiniteLoss):
         train.NonFiniteGuard().submit(torch.tensor(float("inf")))
+
+
+def test_bf16_gradient_bar_with_pinned_sampling_on_cpu_arithmetic():
+    """The method of the GPU test test_full_parseda_bf16_against_the_f32_reference_golden, run here with PyTorch's CPU
+    bfloat16 arithmetic (every intermediate rounded -- coarser than the product's kernels, which keep float32 inside): a
+    bfloat16 run of the small model records the projection rows / reference points of every MSDeformAttn call, a float32 run
+    on the bf16-rounded weights and inputs is handed them (straight-through), gradients of the golden's loss are compared.
+    Pins the hook (`MSDeformAttn.trace`), and that the 0.95 cosine bar of the GPU test is attainable by honest bf16 arithmetic."""
+    g = load("parseda")
+    MS = deform_attn.MSDeformAttn
+
+    def run(model, bb, gg, trace):
+        MS.trace = trace
+        try:
+            _, out, feats, _ = run_small_parseda(model, bb, gg)
+            loss = 0
+            for k in KEYS:
+                loss = loss + (out[k].float() * g["g_" + k]).sum() + (out["aux_outputs"][0][k].float() * g["g_" + k]).sum() * 0.5
+            loss.backward()
+        finally:
+            MS.trace = None
+        grads = {f"g_feat{i}": t.grad.float() for i, (t, _) in enumerate(feats)}
+        params = dict(model.named_parameters(remove_duplicate=False))
+        for key in g:
+            if key.startswith("gparam_") and g[key].numel():
+                name = key[len("gparam_"):].replace("__", ".")
+                grads[name] = params[name].grad.float()
+        return grads
+
+    recorded = []
+
+    def record(module, qproj, ref):
+        recorded.append((qproj.detach().clone(), ref.detach().clone()))
+        return qproj, ref
+
+    model, bb = build_small_parseda()
+    model = model.to(torch.bfloat16)
+    gb = {k: (v.to(torch.bfloat16) if v.dtype == torch.float32 else v) for k, v in g.items()}
+    gb["img_mask"] = g["img_mask"]
+    got = run(model, bb, gb, record)
+    ref_model, ref_bb = build_small_parseda()
+    with torch.no_grad():
+        for p in ref_model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    g32 = {k: (v.to(torch.bfloat16).float() if v.dtype == torch.float32 else v) for k, v in g.items()}
+    g32["img_mask"] = g["img_mask"]
+    replay = iter(recorded)
+
+    def force(module, qproj, ref):
+        q_rec, r_rec = next(replay)
+        assert q_rec.shape == qproj.shape
+        return qproj + (q_rec.float() - qproj).detach(), r_rec.float()
+
+    ref = run(ref_model, ref_bb, g32, force)
+    assert next(replay, None) is None and len(recorded) == 8          # 4 encoder + 2 x 2 decoder layers
+    for name in got:
+        a, b = got[name].double().flatten(), ref[name].double().flatten()
+        c = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+        assert c >= 0.95, (name, c)

@@ -62,6 +62,40 @@ def refine_boxes(delta, ref, eps=1e-5):
         return out
 
 
+class BoxHeadFunction(torch.autograd.Function):
+    """boxes = sigmoid(delta + inverse_sigmoid(ref)) of a prediction head (reference hoi.py:2122-2138) for a reference that
+    carries no gradient (the refined, detached anchors of decoder layers >= 1): forward = the one launch of `refine_boxes`
+    (bit-identical to the op sequence: inverse_sigmoid's 6 launches + cast + add + sigmoid), backward = sigmoid's own backward
+    + the cast back to the head's dtype."""
+
+    @staticmethod
+    def forward(ctx, delta, ref):
+        y = refine_boxes(delta, ref)
+        ctx.save_for_backward(y)
+        ctx.delta_dtype = delta.dtype
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return torch.ops.aten.sigmoid_backward(g, y).to(ctx.delta_dtype), None
+
+
+def box_head(delta, ref):
+    """sigmoid(delta + inverse_sigmoid(ref)), differentiable in `delta` (and in `ref` when it requires grad: the
+    learnable anchors of layer 0 keep the op sequence)."""
+    if (not ref.requires_grad and ref.shape[-1] == 4 and delta.shape == ref.shape and delta.is_cuda and _glue_ok(ref)
+            and delta.dtype in (torch.bfloat16, torch.float32)):
+        return BoxHeadFunction.apply(delta, ref)
+    inv = inverse_sigmoid(ref)
+    delta = delta.to(inv.dtype)              # no mixed-dtype elementwise ops (see below)
+    if ref.shape[-1] == 4:
+        return (delta + inv).sigmoid()
+    assert ref.shape[-1] == 2
+    return torch.cat([delta[..., :2] + inv, delta[..., 2:]], dim=-1).sigmoid()
+
+
 def reference_embed(sub_ref, obj_ref, valid_ratios, parse, out_dtype):
     """(ref_in [N, nq, L, 4] float32, sine features of its level 0 [N, nq, 512] in `out_dtype`) from the anchor boxes:
     one launch of csrc/decoder_glue.hip (the boxes are detached, nothing here carries a gradient)."""
@@ -154,6 +188,10 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
         self.return_intermediate = return_intermediate
         self.sub_bbox_embed = None          # set by the model (aliases of its box heads)
         self.obj_bbox_embed = None
+        # set by a model whose prediction heads apply the SAME bbox_embed[lid] to the same layer outputs (RLIP_ParSeDA,
+        # hoi.py:2122-2138 against deformable_transformer.py:1511-1541): the head MLPs then run once, with autograd, and
+        # the refinement uses their detached result -- `hs.deltas[lid] = (sub, obj)` goes to the heads
+        self.keep_box_deltas = False
         self.class_embed = None
         self.use_dab = use_dab
         self.d_model = d_model
@@ -182,7 +220,7 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
 
         # (explicit .float() before mixing with the float32 box chain: PyTorch-ROCm's mixed-dtype elementwise
         #  kernel costs ~40 us even on a [4, 150, 4] tensor, against ~2 us for a cast + a same-dtype op)
-        inter, inter_sub, inter_obj = [], [], []
+        inter, inter_sub, inter_obj, deltas = [], [], [], []
         glue = (self.use_dab and not self.no_sine_embed and _glue_ok(sub_ref, obj_ref, src_valid_ratios)
                 and output.dtype in (torch.bfloat16, torch.float32) and src_valid_ratios.shape[1] <= 8)
         for lid, layer in enumerate(self.layers):
@@ -211,14 +249,23 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
             #  torch's ModuleTracker -- FlopCounterMode, i.e. bench.py's step-roofline probe -- with "Expected gradient
             #  function to be set"; that is what removed `step_roofline` from round 2's bench line)
             out_d = output.detach()
-            if self.sub_bbox_embed is not None:
-                with torch.no_grad():
-                    delta = self.sub_bbox_embed[lid](out_d[:, :n_pair] if self.ParSe else out_d)
-                sub_ref = refine_boxes(delta, sub_ref)
-            if self.obj_bbox_embed is not None:
-                with torch.no_grad():
-                    delta = self.obj_bbox_embed[lid](out_d[:, n_pair:] if self.ParSe else out_d)
-                obj_ref = refine_boxes(delta, obj_ref)
+            share = (self.keep_box_deltas and self.ParSe and self.return_intermediate and torch.is_grad_enabled()
+                     and self.sub_bbox_embed is not None and self.obj_bbox_embed is not None)
+            if share:
+                d_sub = self.sub_bbox_embed[lid](output[:, :n_pair])
+                d_obj = self.obj_bbox_embed[lid](output[:, n_pair:])
+                deltas.append((d_sub, d_obj))
+                sub_ref = refine_boxes(d_sub.detach(), sub_ref)
+                obj_ref = refine_boxes(d_obj.detach(), obj_ref)
+            else:
+                if self.sub_bbox_embed is not None:
+                    with torch.no_grad():
+                        delta = self.sub_bbox_embed[lid](out_d[:, :n_pair] if self.ParSe else out_d)
+                    sub_ref = refine_boxes(delta, sub_ref)
+                if self.obj_bbox_embed is not None:
+                    with torch.no_grad():
+                        delta = self.obj_bbox_embed[lid](out_d[:, n_pair:] if self.ParSe else out_d)
+                    obj_ref = refine_boxes(delta, obj_ref)
             if self.return_intermediate:
                 inter.append(output)
                 inter_sub.append(sub_ref)
@@ -230,5 +277,7 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
             # consumers that walk the layers take the per-layer tensors themselves: hs[l] would put a select (and its
             # zero-fill + copy + accumulate backward) between every head and the layer that feeds it
             hs.layers = tuple(inter)
+            if len(deltas) == len(inter):
+                hs.deltas = tuple(deltas)
             return hs, refs
         return output, reference_points

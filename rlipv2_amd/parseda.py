@@ -31,7 +31,7 @@ from .msda import attach_host_shapes
 from .alif import RLIPv2_VLFuse, RobertaLayer
 from .blocks import (MLP, FeatureResizer, MultiBranchFusion, NestedTensor, inverse_sigmoid,
                      nested_tensor_from_tensor_list)
-from .decoder import DABDeformableTransformerDecoderHOI, DeformableTransformerDecoderLayer
+from .decoder import DABDeformableTransformerDecoderHOI, DeformableTransformerDecoderLayer, box_head
 from .deform_attn import MSDeformAttn
 from .linear import add_row_vector
 from .encoder import DeformableTransformerEncoderLayer, RLIPv2_DeformableTransformerEncoder, _clones
@@ -315,6 +315,7 @@ class RLIP_ParSeDA(nn.Module):
             transformer.verb_decoder.sub_bbox_embed = self.sub_bbox_embed[n_pred:]
             transformer.ho_decoder.obj_bbox_embed = self.obj_bbox_embed[:n_pred]
             transformer.verb_decoder.obj_bbox_embed = self.obj_bbox_embed[n_pred:]
+            transformer.ho_decoder.keep_box_deltas = True      # the heads below reuse the refinement's MLP outputs
         else:
             nn.init.constant_(sub.layers[-1].bias.data[2:], -2.0)
             nn.init.constant_(obj.layers[-1].bias.data[2:], -2.0)
@@ -451,11 +452,23 @@ class RLIP_ParSeDA(nn.Module):
 
         sub_cls, obj_cls, verb_cls, sub_box, obj_box = [], [], [], [], []
         hs_h, hs_o = [None] * len(ho_layers), [None] * len(ho_layers)
+        deltas = getattr(hs_ho, "deltas", None)
+        dec = self.transformer.ho_decoder
+        if deltas is not None and not (len(deltas) == len(ho_layers) and all(
+                dec.sub_bbox_embed[k] is self.sub_bbox_embed[k] and dec.obj_bbox_embed[k] is self.obj_bbox_embed[k]
+                for k in range(len(ho_layers)))):
+            deltas = None                                   # (not the heads' own modules: compute them here)
         for lvl in range(len(ho_layers)):
             hs_h[lvl], hs_o[lvl] = ho_layers[lvl].split(half, dim=1)
             ref_s, ref_o = init_reference if lvl == 0 else inter_references[lvl - 1]
-            sub_box.append(_add_reference(self.sub_bbox_embed[lvl](hs_h[lvl]), ref_s).sigmoid())
-            obj_box.append(_add_reference(self.obj_bbox_embed[lvl](hs_o[lvl]), ref_o).sigmoid())
+            # the decoder has already applied these heads to these layer outputs for its box refinement (same modules,
+            # same inputs): their results arrive with the layers, the MLPs run once per step
+            if deltas is not None:
+                d_sub, d_obj = deltas[lvl]
+            else:
+                d_sub, d_obj = self.sub_bbox_embed[lvl](hs_h[lvl]), self.obj_bbox_embed[lvl](hs_o[lvl])
+            sub_box.append(box_head(d_sub, ref_s))
+            obj_box.append(box_head(d_obj, ref_o))
             text = F.normalize(text_dec[lvl].transpose(0, 1).float(), p=2, dim=-1)       # float32 norm
             proj = self.projection_text((text / 2.0).to(self.projection_text.weight.dtype))
             assert n_obj + n_verb == proj.shape[1]

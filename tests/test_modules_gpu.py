@@ -782,6 +782,21 @@ def test_decoder_glue_kernels_match_the_op_sequence(parse, dtype):
     want_box = (delta.float() + inverse_sigmoid(obj)).sigmoid()
     assert (got - want_box).abs().max() <= 1e-6
     assert got.dtype == torch.float32 and not got.requires_grad
+    # the prediction heads' form of the same arithmetic (decoder.box_head): one launch forward, sigmoid's backward
+    d1 = delta.clone().requires_grad_(True)
+    d2 = delta.clone().requires_grad_(True)
+    y1 = decoder.box_head(d1, obj)
+    y2 = (d2.float() + inverse_sigmoid(obj)).sigmoid()
+    assert type(y1.grad_fn).__name__ == "BoxHeadFunctionBackward"
+    assert (y1 - y2).abs().max() <= 1e-6
+    w = torch.randn(N, n, 4, generator=g).cuda()
+    (y1 * w).sum().backward()
+    (y2 * w).sum().backward()
+    assert d1.grad.dtype == dtype and (d1.grad.float() - d2.grad.float()).abs().max() <= (2.0 ** -7 if dtype == torch.bfloat16 else 1e-6)
+    # a reference that carries a gradient (the learnable anchors of layer 0) keeps the differentiable op sequence
+    r = obj.clone().clamp(0.05, 0.95).requires_grad_(True)
+    decoder.box_head(delta, r).sum().backward()
+    assert r.grad is not None and torch.isfinite(r.grad).all()
 
 
 @pytest.mark.gpu

@@ -53,12 +53,18 @@ def generalized_box_iou(a, b):
 def paired_giou(a, b):
     """GIoU of xyxy boxes a[i] with b[i] ([N,4] x [N,4] -> [N]): the diagonal of generalized_box_iou"""
     # (explicit products: prod()'s backward inspects the data for zeros on the host -- a sync, and not
-    #  graph-capturable)
-    wh = (torch.min(a[:, 2:], b[:, 2:]) - torch.max(a[:, :2], b[:, :2])).clamp(min=0)
-    inter = wh[:, 0] * wh[:, 1]
-    union = _area(a) + _area(b) - inter
-    wh = (torch.max(a[:, 2:], b[:, 2:]) - torch.min(a[:, :2], b[:, :2])).clamp(min=0)
-    hull = wh[:, 0] * wh[:, 1]
+    #  graph-capturable.  Coordinates through ONE unbind per box set: every `x[:, k]` / `x[:, :2]` on a tensor that
+    #  requires grad is a node whose backward is a zero-fill + a copy + an accumulation -- ~30 launch-bound kernels per
+    #  call for the predicted boxes; unbind's backward is one stack.  Same operations per element, same order.)
+    ax0, ay0, ax1, ay1 = a.unbind(-1)
+    bx0, by0, bx1, by1 = b.unbind(-1)
+    iw = (torch.min(ax1, bx1) - torch.max(ax0, bx0)).clamp(min=0)
+    ih = (torch.min(ay1, by1) - torch.max(ay0, by0)).clamp(min=0)
+    inter = iw * ih
+    union = (ax1 - ax0) * (ay1 - ay0) + (bx1 - bx0) * (by1 - by0) - inter
+    hw = (torch.max(ax1, bx1) - torch.min(ax0, bx0)).clamp(min=0)
+    hh = (torch.max(ay1, by1) - torch.min(ay0, by0)).clamp(min=0)
+    hull = hw * hh
     return inter / union - (hull - union) / hull
 
 

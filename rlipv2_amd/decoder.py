@@ -252,9 +252,12 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
             share = (self.keep_box_deltas and self.ParSe and self.return_intermediate and torch.is_grad_enabled()
                      and self.sub_bbox_embed is not None and self.obj_bbox_embed is not None)
             if share:
-                d_sub = self.sub_bbox_embed[lid](output[:, :n_pair])
-                d_obj = self.obj_bbox_embed[lid](output[:, n_pair:])
-                deltas.append((d_sub, d_obj))
+                # (one split node per layer output, shared with the heads: two slices here and another split there would
+                #  be three nodes whose gradients autograd has to zero-fill, copy and add up)
+                out_h, out_o = output.split(n_pair, dim=1)
+                d_sub = self.sub_bbox_embed[lid](out_h)
+                d_obj = self.obj_bbox_embed[lid](out_o)
+                deltas.append((d_sub, d_obj, out_h, out_o))
                 sub_ref = refine_boxes(d_sub.detach(), sub_ref)
                 obj_ref = refine_boxes(d_obj.detach(), obj_ref)
             else:

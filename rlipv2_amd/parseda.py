@@ -459,12 +459,15 @@ class RLIP_ParSeDA(nn.Module):
                 for k in range(len(ho_layers)))):
             deltas = None                                   # (not the heads' own modules: compute them here)
         for lvl in range(len(ho_layers)):
-            hs_h[lvl], hs_o[lvl] = ho_layers[lvl].split(half, dim=1)
+            if deltas is not None:
+                hs_h[lvl], hs_o[lvl] = deltas[lvl][2], deltas[lvl][3]
+            else:
+                hs_h[lvl], hs_o[lvl] = ho_layers[lvl].split(half, dim=1)
             ref_s, ref_o = init_reference if lvl == 0 else inter_references[lvl - 1]
             # the decoder has already applied these heads to these layer outputs for its box refinement (same modules,
             # same inputs): their results arrive with the layers, the MLPs run once per step
             if deltas is not None:
-                d_sub, d_obj = deltas[lvl]
+                d_sub, d_obj = deltas[lvl][:2]
             else:
                 d_sub, d_obj = self.sub_bbox_embed[lvl](hs_h[lvl]), self.obj_bbox_embed[lvl](hs_o[lvl])
             sub_box.append(box_head(d_sub, ref_s))

@@ -228,7 +228,10 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
 
         hs_ho, inter_refs = self.ho_decoder(tgt, init_reference, img_memory, spatial_shapes, level_start_index,
                                             valid_ratios, query_pos=None, src_padding_mask=masks)
-        last_sub, last_obj = getattr(hs_ho, "layers", hs_ho)[-1].split(nq // 2, dim=1)
+        if getattr(hs_ho, "deltas", None) is not None:          # (the decoder's own split of its last layer output)
+            last_sub, last_obj = hs_ho.deltas[-1][2], hs_ho.deltas[-1][3]
+        else:
+            last_sub, last_obj = getattr(hs_ho, "layers", hs_ho)[-1].split(nq // 2, dim=1)
         kind = self.verb_query_tgt_type
         if kind == "vanilla":
             verb_in = verb_tgt[:, :nq // 2] + verb_tgt[:, nq // 2:]

@@ -17,6 +17,9 @@ from .linear import fused_ffn, token_linear
 from .norm import add_layer_norm
 
 
+inplace_tail = True       # (tests flip it to compare with the concatenating form)
+
+
 def _clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
 
@@ -77,6 +80,61 @@ def encoder_reference_points(spatial_shapes_list, valid_ratios, device):
     return ref[:, :, None] * valid_ratios[:, None]
 
 
+class _TailGradient:
+    """what _TakeTail and _PutTail share in the backward pass: the full-size gradient buffer"""
+    full = None
+
+
+class _TakeTail(torch.autograd.Function):
+    """tail = x[:, start:].clone() -- the last pyramid level, handed to the fusion (reference
+    deformable_transformer.py:844-846 clones it too).  Its gradient is NOT returned as a zero-padded full-size tensor for
+    autograd to add to _PutTail's: it is copied into the tail of the gradient buffer _PutTail has already handed over for
+    the same `x` (see there)."""
+
+    @staticmethod
+    def forward(ctx, x, start, shared):
+        ctx.start, ctx.shared = start, shared
+        return x[:, start:].clone()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_tail):
+        full = ctx.shared.full
+        ctx.shared.full = None
+        if full is None:                 # _PutTail's output took no gradient: the plain zero-padded form
+            out = g_tail.new_zeros((g_tail.shape[0], ctx.start + g_tail.shape[1]) + tuple(g_tail.shape[2:]))
+            out[:, ctx.start:] = g_tail
+            return out, None, None
+        full[:, ctx.start:].copy_(g_tail)
+        return None, None, None
+
+
+class _PutTail(torch.autograd.Function):
+    """x[:, start:] = fused tail, in place (Q4: the reference writes the fused last-level slice back into the full tensor,
+    deformable_transformer.py:855-859).  `torch.cat([x[:, :start], tail], 1)` is the same values through a 90 MB copy, and its
+    backward through autograd is two zero-filled full-size gradients (one per slice) plus their sum: ~310 MB of traffic per
+    fusion for a 0.5 MB slice.  Here the forward copies the slice; the backward hands the incoming full-size gradient on AS
+    the gradient of `x` and lets _TakeTail overwrite its tail with the fusion's input gradient: `x` is consumed by exactly
+    these two nodes (the encoder below), so nothing reads the buffer between the two."""
+
+    @staticmethod
+    def forward(ctx, x, tail, start, shared):
+        ctx.start, ctx.shared = start, shared
+        x[:, start:] = tail
+        ctx.mark_dirty(x)
+        return x
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        g_tail = g[:, ctx.start:].clone()
+        # (the buffer must be this node's own: a gradient that is an expanded / shared view is materialised first)
+        if not g.is_contiguous() or g._base is not None:
+            g = g.contiguous().clone() if g._base is not None else g.contiguous()
+        ctx.shared.full = g
+        return g, g_tail, None, None
+
+
 class RLIPv2_DeformableTransformerEncoder(nn.Module):
     """Every `fusion_interval`-th layer is preceded by an ALIF fusion (on the last pyramid level
     only when `fusion_last_vis`) and a language layer on the fused text states."""
@@ -110,12 +168,22 @@ class RLIPv2_DeformableTransformerEncoder(nn.Module):
         for idx, layer in enumerate(self.layers):
             if idx % self.fusion_interval == 0:
                 k = idx // self.fusion_interval
-                part = output[:, last_start:] if self.fusion_last_vis else output
+                # (in place only into a tensor this loop produced -- the previous layer's LayerNorm output, which no
+                #  backward has saved; layer 0's input belongs to the caller and keeps the out-of-place form)
+                in_place = self.fusion_last_vis and idx > 0 and inplace_tail and torch.is_grad_enabled() and output.requires_grad
+                if in_place:
+                    shared = _TailGradient()
+                    part = _TakeTail.apply(output, last_start, shared)
+                else:
+                    part = output[:, last_start:] if self.fusion_last_vis else output
                 fused = self.VLFuse_layers[k]({"visual": {"src": part, "padding_mask": vis_mask, "pos": vis_pos},
                                                "lang": {"hidden": hidden, "masks": lang_mask}})
                 part, hidden = fused["visual"]["src"], fused["lang"]["hidden"]
                 # Q4: the fused last-level slice replaces that slice of the full sequence
-                output = torch.cat([output[:, :last_start], part], 1) if self.fusion_last_vis else part
+                if in_place:
+                    output = _PutTail.apply(output, part, last_start, shared)
+                else:
+                    output = torch.cat([output[:, :last_start], part], 1) if self.fusion_last_vis else part
                 hidden = self.roberta_layers[k](hidden_states=hidden, attention_mask=lang_mask)
                 collected.append(hidden)
             output = layer(output, pos, reference_points, spatial_shapes, level_start_index,

@@ -633,3 +633,31 @@ def test_bf16_gradient_bar_with_pinned_sampling_on_cpu_arithmetic():
         a, b = got[name].double().flatten(), ref[name].double().flatten()
         c = float((a @ b) / (a.norm() * b.norm() + 1e-300))
         assert c >= 0.95, (name, c)
+
+
+def test_fused_tail_written_in_place_equals_the_concatenating_form():
+    """Q4 (deformable_transformer.py:855-859): the fused last-level slice replaces that slice of the full sequence.  The
+    in-place form (encoder._TakeTail / _PutTail: a 0.5 MB copy, the backward reuses the incoming gradient buffer) must give
+    the values and gradients of `cat([x[:, :start], tail])` bit for bit -- the model golden above goes through it (fusions in
+    front of layers 0 and 2 of its 4-layer encoder; layer 0's input keeps the out-of-place form)."""
+    g = load("parseda")
+    res = {}
+    calls = []
+    orig = encoder._PutTail.apply
+    for flag in (True, False):
+        encoder.inplace_tail = flag
+        try:
+            model, bb = build_small_parseda()
+            if flag:
+                encoder._PutTail.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+            mc, out, feats, _ = run_small_parseda(model, bb, g)
+            loss = sum((out[k] * g["g_" + k]).sum() for k in KEYS)
+            loss.backward()
+            res[flag] = ([out[k].detach().clone() for k in KEYS], [t.grad.clone() for t, _ in feats],
+                         [p.grad.clone() for n, p in model.named_parameters() if p.grad is not None and "encoder" in n])
+        finally:
+            encoder.inplace_tail = True
+            encoder._PutTail.apply = orig
+    assert calls, "the in-place path did not run"
+    for a, b in zip(res[True], res[False]):
+        assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))

@@ -279,7 +279,7 @@ class Backbone(nn.Module):
         out = []
         for x in self.body(tensor_list.tensors):
             mask = F.interpolate(m[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
-            out.append(NestedTensor(x, mask))
+            out.append(NestedTensor(x, mask, getattr(tensor_list, "no_padding", False)))
         return out
 
 
@@ -293,7 +293,7 @@ class Joiner(nn.Sequential):
 
     def forward(self, tensor_list: NestedTensor):
         feats = self[0](tensor_list)
-        return feats, [self[1](x).to(x.tensors.dtype) for x in feats]
+        return feats, [self[1](x, out_dtype=x.tensors.dtype) for x in feats]
 
 
 def build_r50_backbone(hidden_dim=256, train_backbone=True):

@@ -152,10 +152,29 @@ class RLIPv2_DeformableTransformerEncoder(nn.Module):
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
                 lang_hidden=None, lang_masks=None, spatial_shapes_list=None, skip_value_mask=False):
+        """`skip_value_mask`: the caller knows the batch has NO padding (all masks False, hence all valid ratios 1): the value
+        masking is skipped and the reference points come from the shape alone (cached)."""
         if spatial_shapes_list is None:                      # reference behaviour: read them back
             spatial_shapes_list = [(int(h), int(w)) for h, w in spatial_shapes.tolist()]
         last_start = sum(h * w for h, w in spatial_shapes_list[:-1])
-        reference_points = encoder_reference_points(spatial_shapes_list, valid_ratios, src.device)
+        if skip_value_mask:
+            # (no padding: the valid ratios are all 1 and the reference points a function of the pyramid's shape alone --
+            #  ~45 launches per step; same function, same values)
+            rkey = (tuple(spatial_shapes_list), valid_ratios.shape[0], str(src.device))
+            rcache = self.__dict__.setdefault("_reference_cache", {})
+            if rkey not in rcache:
+                capturing = src.is_cuda and torch.cuda.is_current_stream_capturing()
+                with torch.no_grad():
+                    points = encoder_reference_points(spatial_shapes_list, torch.ones_like(valid_ratios), src.device)
+                if capturing:
+                    rcache = {rkey: points}      # (a capture's pool memory is not kept)
+                else:
+                    if len(rcache) >= 8:
+                        rcache.pop(next(iter(rcache)))
+                    rcache[rkey] = points
+            reference_points = rcache[rkey]
+        else:
+            reference_points = encoder_reference_points(spatial_shapes_list, valid_ratios, src.device)
         # the fusion is handed inverted (True = valid) bool masks; see alif.py Q1 for what they do
         vis_mask = ~padding_mask
         lang_mask = ~lang_masks

@@ -186,7 +186,15 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
                 attach_host_shapes(sp, shapes_list)      # the MSDA op sizes grids / checks sum(H*W) from the host copy
                 cache[key] = (sp, torch.cat((sp.new_zeros((1,)), sp.prod(1).cumsum(0)[:-1])))
             spatial_shapes, level_start_index = cache[key]
-            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+            if no_padding:
+                # (all-False masks, the caller's host-side hint: every ratio is exactly 1 -- ~40 tiny launches per step for
+                #  a constant)
+                vkey = ("valid_ratios", bs, len(masks), str(src_flatten.device))
+                if vkey not in cache:
+                    cache[vkey] = torch.ones(bs, len(masks), 2, dtype=torch.float32, device=src_flatten.device)
+                valid_ratios = cache[vkey]
+            else:
+                valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
             if encoded_text is None:
                 encoded_text = self._encode_text(text, bs, src_flatten.device)
@@ -375,7 +383,8 @@ class RLIP_ParSeDA(nn.Module):
             masks = [feat.decompose()[1] for feat in features]
             for l in range(len(features), self.num_feature_levels):
                 mask = F.interpolate(samples.mask[None].float(), size=srcs[l].shape[-2:]).to(torch.bool)[0]   # Q13
-                pos.append(self.backbone[1](NestedTensor(srcs[l], mask)).to(srcs[l].dtype))
+                pos.append(self.backbone[1](NestedTensor(srcs[l], mask, getattr(samples, "no_padding", False)),
+                                            out_dtype=srcs[l].dtype))
                 masks.append(mask)
         else:
             for l, feat in enumerate(features):
@@ -386,7 +395,8 @@ class RLIP_ParSeDA(nn.Module):
             for l in range(len(srcs), self.num_feature_levels):
                 src = self.input_proj[l](features[-1].tensors if l == len(features) else srcs[-1])
                 mask = F.interpolate(samples.mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]   # Q13
-                pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
+                pos.append(self.backbone[1](NestedTensor(src, mask, getattr(samples, "no_padding", False)),
+                                            out_dtype=src.dtype))
                 srcs.append(src)
                 masks.append(mask)
         query_embeds = self._query_embeds()

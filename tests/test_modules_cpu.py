@@ -661,3 +661,56 @@ def test_fused_tail_written_in_place_equals_the_concatenating_form():
     assert calls, "the in-place path did not run"
     for a, b in zip(res[True], res[False]):
         assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_sine_position_encoding_is_cached_for_padding_free_batches():
+    """PositionEmbeddingSine (reference models/position_encoding.py:22-58): without padding the encoding depends on the shape
+    only -- computed once, the values of the uncached call, kept channels-last so that the token-major view is contiguous"""
+    pe = blocks.PositionEmbeddingSine(128, normalize=True)
+    x = torch.zeros(2, 8, 5, 7)
+    mask = torch.zeros(2, 5, 7, dtype=torch.bool)
+    plain = pe(blocks.NestedTensor(x, mask))
+    a = pe(blocks.NestedTensor(x, mask, no_padding=True), out_dtype=torch.bfloat16)
+    b = pe(blocks.NestedTensor(x, mask.clone(), no_padding=True), out_dtype=torch.bfloat16)
+    assert a is b and torch.equal(a, plain.to(torch.bfloat16))
+    assert a.flatten(2).transpose(1, 2).is_contiguous() and not a.requires_grad
+    c = pe(blocks.NestedTensor(x, mask, no_padding=True))                 # another dtype: its own entry
+    assert c is not a and torch.equal(c, plain)
+    padded = mask.clone()
+    padded[1, :, 5:] = True
+    d = pe(blocks.NestedTensor(x, padded))                                # padded batches are never cached
+    assert not torch.equal(d, plain) and d is not pe(blocks.NestedTensor(x, padded))
+
+
+def test_padding_free_hint_changes_nothing_but_the_work():
+    """NestedTensor.no_padding (all masks False, told by the host): cached position encodings, valid ratios = 1 and reference
+    points from the shape alone, no value masking -- outputs and gradients must equal the run that derives all of it from the
+    masks, bit for bit, also on the second call (the cached one)."""
+    from oracle_function import OracleMSDeformAttnFunction
+
+    from rlipv2_amd import train
+    old = deform_attn.msda_function
+    deform_attn.msda_function = OracleMSDeformAttnFunction
+    try:
+        args = parseda.default_args(num_queries=12, enc_layers=2, dec_layers=1, dim_feedforward=128, pseudo_verb=False)
+        torch.manual_seed(3)
+        model, crit = train.build_training(args, device="cpu", with_text_encoder=False)
+        model.eval()
+        step = train.ParSeDATrainStep(model)
+        samples, _, targets = train.synthetic_batch(2, 64, 96, n_obj=6, n_verb=4, triplets=2, device="cpu", seed=5)
+        g = torch.Generator().manual_seed(9)
+        mem = torch.tanh(torch.randn(10, 1, 768, generator=g)).repeat(1, 2, 1)
+        text = (~(mem.sum(-1) > 0), mem, torch.tensor([[6, 4]]))
+        res = []
+        for hint in (False, True, True):
+            samples.no_padding = hint
+            model.zero_grad(set_to_none=True)
+            out = step(samples, text, targets)
+            crit.weighted_sum(crit(out, targets)).backward()
+            res.append(([out[k].detach().clone() for k in KEYS if k in out],
+                        [p.grad.clone() for p in model.parameters() if p.grad is not None]))
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+    finally:
+        deform_attn.msda_function = old

@@ -471,6 +471,21 @@ class RLIP_ParSeDA(nn.Module):
                 dec.sub_bbox_embed[k] is self.sub_bbox_embed[k] and dec.obj_bbox_embed[k] is self.obj_bbox_embed[k]
                 for k in range(len(ho_layers)))):
             deltas = None                                   # (not the heads' own modules: compute them here)
+        # Text projections and logits of ALL decoder layers in one pass (hoi.py:2140-2157 runs them per layer): one normalise,
+        # one projection GEMM, one batched product per decoder over (layer, image) -- the per-layer loop was ~19 launch-bound
+        # kernels per layer forward and twice that backward.  The stacked decoder outputs enter whole (their backward is the
+        # stack's unbind: views), the per-layer logits leave as views of the batched result.
+        n_lay = len(ho_layers)
+        batched = (torch.is_tensor(hs_ho) and hs_ho.dim() == 4 and torch.is_tensor(hs_verb) and hs_verb.dim() == 4
+                   and hs_ho.shape[0] == n_lay == hs_verb.shape[0] and text_dec.shape[0] >= n_lay)
+        if batched:
+            text_all = F.normalize(text_dec[:n_lay].transpose(1, 2).float(), p=2, dim=-1)            # [L, N, n_text, C]
+            proj_all = self.projection_text((text_all / 2.0).to(self.projection_text.weight.dtype))
+            assert n_obj + n_verb == proj_all.shape[2]
+            obj_text_t = proj_all[:, :, :n_obj].transpose(2, 3)
+            verb_text_t = proj_all[:, :, n_obj:n_obj + n_verb].transpose(2, 3)
+            ho_cls_all = torch.matmul(hs_ho + self.bias_obj_a, obj_text_t) + self.bias_c           # [L, N, nq, n_obj]
+            verb_cls_all = torch.matmul(hs_verb + self.bias_pred_a, verb_text_t) + self.bias_c     # [L, N, nq/2, n_verb]
         for lvl in range(len(ho_layers)):
             if deltas is not None:
                 hs_h[lvl], hs_o[lvl] = deltas[lvl][2], deltas[lvl][3]
@@ -485,6 +500,12 @@ class RLIP_ParSeDA(nn.Module):
                 d_sub, d_obj = self.sub_bbox_embed[lvl](hs_h[lvl]), self.obj_bbox_embed[lvl](hs_o[lvl])
             sub_box.append(box_head(d_sub, ref_s))
             obj_box.append(box_head(d_obj, ref_o))
+            if batched:
+                obj_cls.append(ho_cls_all[lvl, :, half:])
+                verb_cls.append(verb_cls_all[lvl])
+                if self.subject_class:
+                    sub_cls.append(ho_cls_all[lvl, :, :half])
+                continue
             text = F.normalize(text_dec[lvl].transpose(0, 1).float(), p=2, dim=-1)       # float32 norm
             proj = self.projection_text((text / 2.0).to(self.projection_text.weight.dtype))
             assert n_obj + n_verb == proj.shape[1]

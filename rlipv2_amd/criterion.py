@@ -25,9 +25,26 @@ from scipy.optimize import linear_sum_assignment
 from torch import nn
 
 
+class _CxcywhToXyxy(torch.autograd.Function):
+    """(cx, cy, w, h) -> (cx - w/2, cy - h/2, cx + w/2, cy + h/2) on the two coordinate pairs at once: 4 launches forward and
+    4 backward.  As unbind + four scaled differences + stack it is 9 launches forward and ~11 backward on tensors of a few
+    hundred boxes, eight times per train step.  Same values bit for bit (the same subtraction / addition per coordinate; the
+    backward's 0.5 * (g1 - g0) equals -0.5 g0 + 0.5 g1: scaling by a power of two is exact)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        half = 0.5 * x[..., 2:]
+        return torch.cat((x[..., :2] - half, x[..., :2] + half), -1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lo, hi = g[..., :2], g[..., 2:]
+        return torch.cat((lo + hi, 0.5 * (hi - lo)), -1)
+
+
 def box_cxcywh_to_xyxy(x):
-    cx, cy, w, h = x.unbind(-1)
-    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+    return _CxcywhToXyxy.apply(x)
 
 
 def _area(b):

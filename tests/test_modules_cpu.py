@@ -714,3 +714,23 @@ def test_padding_free_hint_changes_nothing_but_the_work():
                 assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
     finally:
         deform_attn.msda_function = old
+
+
+def test_box_format_conversion_equals_the_unbind_form():
+    """criterion.box_cxcywh_to_xyxy (util/box_ops.py box_cxcywh_to_xyxy in the reference): the two-pair form and its own
+    backward give the unbind / stack form's values and gradients bit for bit"""
+    from rlipv2_amd.criterion import box_cxcywh_to_xyxy
+
+    def ref(x):
+        cx, cy, w, h = x.unbind(-1)
+        return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+    g = torch.Generator().manual_seed(0)
+    for shape in ((37, 4), (3, 11, 4), (0, 4)):
+        x1 = torch.rand(*shape, generator=g).requires_grad_(True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        w = torch.randn(*shape, generator=g)
+        a, b = box_cxcywh_to_xyxy(x1), ref(x2)
+        assert torch.equal(a, b)
+        (a * w).sum().backward()
+        (b * w).sum().backward()
+        assert torch.equal(x1.grad, x2.grad)

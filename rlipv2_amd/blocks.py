@@ -61,7 +61,8 @@ def sine_embed_for_position(pos: Tensor) -> Tensor:
     order = [1, 0] if pos.shape[-1] == 2 else [1, 0, 2, 3]
     if pos.shape[-1] not in (2, 4):
         raise ValueError("Unknown pos_tensor shape(-1):{}".format(pos.shape[-1]))
-    return torch.cat([emb[..., k, :] for k in order], dim=-1)
+    parts = emb.unbind(-2)                      # (one node: a select per coordinate is a zero-fill + copy + add each in the backward)
+    return torch.cat([parts[k] for k in order], dim=-1)
 
 
 class MultiBranchFusion(nn.Module):

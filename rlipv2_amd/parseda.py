@@ -175,7 +175,8 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
             if src_flatten is None:
                 src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
             mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
-            lvl_pos = torch.cat([add_row_vector(p.flatten(2).transpose(1, 2), self.level_embed[l])
+            level_rows = self.level_embed.unbind(0)          # (one backward node instead of a select per level)
+            lvl_pos = torch.cat([add_row_vector(p.flatten(2).transpose(1, 2), level_rows[l])
                                  for l, p in enumerate(pos_embeds)], 1)
             # device-resident int64 metadata, built once per pyramid shape (a host->device copy per step
             # would also be illegal inside a HIP-graph capture)
@@ -241,12 +242,13 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
         else:
             last_sub, last_obj = getattr(hs_ho, "layers", hs_ho)[-1].split(nq // 2, dim=1)
         kind = self.verb_query_tgt_type
+        verb_a, verb_b = verb_tgt.split(nq // 2, dim=1)         # (one node; two slices are two zero-padded gradients + a sum)
         if kind == "vanilla":
-            verb_in = verb_tgt[:, :nq // 2] + verb_tgt[:, nq // 2:]
+            verb_in = verb_a + verb_b
         elif kind == "MBF":
             verb_in = self.verb_tgt_generator(last_sub, last_obj)
         elif kind == "vanilla_MBF":
-            verb_in = self.verb_tgt_generator(last_sub, last_obj) + verb_tgt[:, :nq // 2] + verb_tgt[:, nq // 2:]
+            verb_in = self.verb_tgt_generator(last_sub, last_obj) + verb_a + verb_b
         else:
             raise AssertionError(kind)
         hs_verb, _ = self.verb_decoder(verb_in, inter_refs[-1], img_memory, spatial_shapes, level_start_index,
@@ -486,6 +488,10 @@ class RLIP_ParSeDA(nn.Module):
             verb_text_t = proj_all[:, :, n_obj:n_obj + n_verb].transpose(2, 3)
             ho_cls_all = torch.matmul(hs_ho + self.bias_obj_a, obj_text_t) + self.bias_c           # [L, N, nq, n_obj]
             verb_cls_all = torch.matmul(hs_verb + self.bias_pred_a, verb_text_t) + self.bias_c     # [L, N, nq/2, n_verb]
+            # (per-layer views through ONE split + unbinds: a select / slice per layer and head would each be a zero-filled
+            #  full-size gradient + copy + accumulation in the backward)
+            sub_cls_all, obj_cls_all = ho_cls_all.split(half, dim=2)
+            sub_cls_lay, obj_cls_lay, verb_cls_lay = sub_cls_all.unbind(0), obj_cls_all.unbind(0), verb_cls_all.unbind(0)
         for lvl in range(len(ho_layers)):
             if deltas is not None:
                 hs_h[lvl], hs_o[lvl] = deltas[lvl][2], deltas[lvl][3]
@@ -501,10 +507,10 @@ class RLIP_ParSeDA(nn.Module):
             sub_box.append(box_head(d_sub, ref_s))
             obj_box.append(box_head(d_obj, ref_o))
             if batched:
-                obj_cls.append(ho_cls_all[lvl, :, half:])
-                verb_cls.append(verb_cls_all[lvl])
+                obj_cls.append(obj_cls_lay[lvl])
+                verb_cls.append(verb_cls_lay[lvl])
                 if self.subject_class:
-                    sub_cls.append(ho_cls_all[lvl, :, :half])
+                    sub_cls.append(sub_cls_lay[lvl])
                 continue
             text = F.normalize(text_dec[lvl].transpose(0, 1).float(), p=2, dim=-1)       # float32 norm
             proj = self.projection_text((text / 2.0).to(self.projection_text.weight.dtype))

@@ -167,7 +167,7 @@ class PositionEmbeddingSine(nn.Module):
             key = (tuple(mask.shape), str(mask.device), out_dtype, self.num_pos_feats, float(self.temperature),
                    self.normalize, float(self.scale))
             cache = self.__dict__.setdefault("_no_padding_cache", {})
-            hit = cache.pop(key, None)
+            hit = cache.get(key)
             if hit is None:
                 capturing = mask.is_cuda and torch.cuda.is_current_stream_capturing()
                 with torch.no_grad():
@@ -175,11 +175,12 @@ class PositionEmbeddingSine(nn.Module):
                     if out_dtype is not None:
                         hit = hit.to(out_dtype)
                     hit = hit.contiguous(memory_format=torch.channels_last)
-                if capturing:
-                    return hit               # (memory of a capture's private pool: not kept beyond this call)
-                while len(cache) >= 8:       # a handful of shapes per run; oldest first
-                    cache.pop(next(iter(cache)))
-            cache[key] = hit
+                # Entries are never evicted: a captured HIP graph that read one keeps reading its memory on every replay.
+                # A full table (a run with very many padding-free shapes) stops caching new shapes instead; memory of a
+                # capture's private pool is not kept beyond this call either.
+                if capturing or len(cache) >= 16:
+                    return hit
+                cache[key] = hit
             return hit
         out = self._encode(mask)
         return out if out_dtype is None else out.to(out_dtype)

@@ -166,11 +166,11 @@ class RLIPv2_DeformableTransformerEncoder(nn.Module):
                 capturing = src.is_cuda and torch.cuda.is_current_stream_capturing()
                 with torch.no_grad():
                     points = encoder_reference_points(spatial_shapes_list, torch.ones_like(valid_ratios), src.device)
-                if capturing:
-                    rcache = {rkey: points}      # (a capture's pool memory is not kept)
+                # (never evicted: captured graphs keep reading a cached tensor's memory; a full table stops caching, and a
+                #  capture's own pool memory is not kept)
+                if capturing or len(rcache) >= 16:
+                    rcache = {rkey: points}
                 else:
-                    if len(rcache) >= 8:
-                        rcache.pop(next(iter(rcache)))
                     rcache[rkey] = points
             reference_points = rcache[rkey]
         else:

@@ -143,6 +143,9 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor]) -> NestedTensor:
     return NestedTensor(batch, mask, no_padding=all(t.shape[1] == h and t.shape[2] == w for t in tensor_list))
 
 
+cache_padding_free = True     # (tools/r04_host_ab.py flips the attribute for its A/B)
+
+
 class PositionEmbeddingSine(nn.Module):
     """Image sine position encoding (normalised to 2*pi, temperature 10000), [N, 2*F, H, W]."""
 
@@ -163,7 +166,7 @@ class PositionEmbeddingSine(nn.Module):
         a strided read.  Per train step that was ~60 launches and ~0.5 GB of float32 traffic for constants."""
         mask = tensor_list.mask
         assert mask is not None
-        if getattr(tensor_list, "no_padding", False):
+        if getattr(tensor_list, "no_padding", False) and cache_padding_free:
             key = (tuple(mask.shape), str(mask.device), out_dtype, self.num_pos_feats, float(self.temperature),
                    self.normalize, float(self.scale))
             cache = self.__dict__.setdefault("_no_padding_cache", {})

@@ -41,6 +41,9 @@ direct_self_attention = os.environ.get("RLIPV2_DEC_SELF_ATTN", "1") != "0"      
 fused_glue = os.environ.get("RLIPV2_DEC_GLUE", "1") != "0"                     # (A/B switch)
 
 
+share_box_deltas = True       # (tools/r04_host_ab.py flips the attribute for its A/B: heads' MLPs once + one-launch box head)
+
+
 def _glue_ok(*tensors):
     return fused_glue and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
 
@@ -85,7 +88,8 @@ class BoxHeadFunction(torch.autograd.Function):
 def box_head(delta, ref):
     """sigmoid(delta + inverse_sigmoid(ref)), differentiable in `delta` (and in `ref` when it requires grad: the
     learnable anchors of layer 0 keep the op sequence)."""
-    if (not ref.requires_grad and ref.shape[-1] == 4 and delta.shape == ref.shape and delta.is_cuda and _glue_ok(ref)
+    if (share_box_deltas and not ref.requires_grad and ref.shape[-1] == 4 and delta.shape == ref.shape and delta.is_cuda
+            and _glue_ok(ref)
             and delta.dtype in (torch.bfloat16, torch.float32)):
         return BoxHeadFunction.apply(delta, ref)
     inv = inverse_sigmoid(ref)
@@ -249,7 +253,7 @@ class DABDeformableTransformerDecoderHOI(nn.Module):
             #  torch's ModuleTracker -- FlopCounterMode, i.e. bench.py's step-roofline probe -- with "Expected gradient
             #  function to be set"; that is what removed `step_roofline` from round 2's bench line)
             out_d = output.detach()
-            share = (self.keep_box_deltas and self.ParSe and self.return_intermediate and torch.is_grad_enabled()
+            share = (share_box_deltas and self.keep_box_deltas and self.ParSe and self.return_intermediate and torch.is_grad_enabled()
                      and self.sub_bbox_embed is not None and self.obj_bbox_embed is not None)
             if share:
                 # (one split node per layer output, shared with the heads: two slices here and another split there would

@@ -18,6 +18,7 @@ from .norm import add_layer_norm
 
 
 inplace_tail = True       # (tests flip it to compare with the concatenating form)
+cache_reference_points = True
 
 
 def _clones(module, n):
@@ -157,7 +158,7 @@ class RLIPv2_DeformableTransformerEncoder(nn.Module):
         if spatial_shapes_list is None:                      # reference behaviour: read them back
             spatial_shapes_list = [(int(h), int(w)) for h, w in spatial_shapes.tolist()]
         last_start = sum(h * w for h, w in spatial_shapes_list[:-1])
-        if skip_value_mask:
+        if skip_value_mask and cache_reference_points:
             # (no padding: the valid ratios are all 1 and the reference points a function of the pyramid's shape alone --
             #  ~45 launches per step; same function, same values)
             rkey = (tuple(spatial_shapes_list), valid_ratios.shape[0], str(src.device))

@@ -261,6 +261,9 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
         return hs_ho, hs_verb, text_dec, init_reference, inter_refs, hs_ho, hs_verb, None, None
 
 
+batched_heads = True          # (tools/r04_host_ab.py flips the attribute for its A/B)
+
+
 def _add_reference(delta, ref):
     """box head output + inverse_sigmoid(reference): all 4 coordinates for a reference box, only (x, y)
     for a 2-d reference point (reference hoi.py:2122-2138 / :3040-3056)."""
@@ -478,7 +481,7 @@ class RLIP_ParSeDA(nn.Module):
         # kernels per layer forward and twice that backward.  The stacked decoder outputs enter whole (their backward is the
         # stack's unbind: views), the per-layer logits leave as views of the batched result.
         n_lay = len(ho_layers)
-        batched = (torch.is_tensor(hs_ho) and hs_ho.dim() == 4 and torch.is_tensor(hs_verb) and hs_verb.dim() == 4
+        batched = (batched_heads and torch.is_tensor(hs_ho) and hs_ho.dim() == 4 and torch.is_tensor(hs_verb) and hs_verb.dim() == 4
                    and hs_ho.shape[0] == n_lay == hs_verb.shape[0] and text_dec.shape[0] >= n_lay)
         if batched:
             text_all = F.normalize(text_dec[:n_lay].transpose(1, 2).float(), p=2, dim=-1)            # [L, N, n_text, C]

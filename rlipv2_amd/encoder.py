@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .deform_attn import MSDeformAttn
-from .linear import fused_ffn, token_linear
+from .linear import ffn_residual_norm, fused_ffn, token_linear
 from .norm import add_layer_norm
 
 
@@ -55,7 +55,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
         attn = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = add_layer_norm(src, self.dropout1(attn), self.norm1)
         if self.activation is F.relu and not (self.training and self.dropout2.p > 0):
-            # one autograd node for linear2(relu(linear1(.))): the ReLU mask rides in the input-gradient GEMM
+            # one autograd node for linear2(relu(linear1(.))): the ReLU mask rides in the input-gradient GEMM, and the
+            # residual's gradient in the last GEMM's accumulator (dropout3 is the identity here: --dropout 0.0; with a live
+            # dropout between branch and norm the plain nodes run)
+            if not (self.training and self.dropout3.p > 0):
+                return ffn_residual_norm(src, self.linear1, self.linear2, self.norm2)
             return add_layer_norm(src, self.dropout3(fused_ffn(src, self.linear1, self.linear2)), self.norm2)
         if self.activation is F.relu:
             hidden = self.dropout2(token_linear(src, self.linear1.weight, self.linear1.bias, relu=True))

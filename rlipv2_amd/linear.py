@@ -135,24 +135,80 @@ class FusedFFNFunction(torch.autograd.Function):
     1.1 GB `threshold_backward` pass over the [88 892, 2048] tensors; both weight gradients on `token_gemm.hip`."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, link=None):
         # forward stays on the library (bias + ReLU in the hipBLASLt epilogue, tuned solution): measured 135-145 us
         # against 150 us for expand_gemm(bias, relu) at N = 2048 -- the fused mask is where the own kernel pays
         h = _linear_forward(x, w1, b1, True)
         y = F.linear(h, w2, b2)
         ctx.save_for_backward(x, w1, w2, h)
+        ctx.link = link
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, w1, w2, h = ctx.saved_tensors
+        link = ctx.link
+        # residual block (ffn_residual_norm): `dy` is the very tensor the LayerNorm's backward also returned as the gradient of
+        # the residual input, i.e. of `x` -- the block's d_x = dy + dh W1 is then ONE GEMM accumulating into it (beta = 1)
+        # instead of a GEMM + autograd's sum of two 45 MB tensors
+        shared = (link is not None and link.dx is not None and dy.is_contiguous() and ctx.needs_input_grad[0]
+                  and (link.dx is dy or (link.dx.data_ptr() == dy.data_ptr() and link.dx.shape == dy.shape
+                                         and link.dx.stride() == dy.stride() and link.dx.dtype == dy.dtype)))
+        if link is not None:
+            link.dx = None
         dy = dy.contiguous()
         dw2, db2 = linear_wgrad(dy, h, with_bias=True, out_dtype=w2.dtype)
         dh = expand_gemm(dy, w2.t(), mask=h)                     # w2.t().contiguous(): 1 MB, inside expand_gemm
         dw1, db1 = linear_wgrad(dh, x, with_bias=True, out_dtype=w1.dtype)
-        dx = dh.matmul(w1) if ctx.needs_input_grad[0] else None
-        return dx, dw1, db1, dw2, db2
+        if shared:
+            dy.view(-1, dy.shape[-1]).addmm_(dh.view(-1, dh.shape[-1]), w1)       # (after its last use as dy above)
+            dx = None                                            # delivered through the residual's gradient
+        else:
+            dx = dh.matmul(w1) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2, None
+
+
+class _Alias(torch.autograd.Function):
+    """x as a new autograd node: whatever consumes the alias is known to the code that made it (ffn_residual_norm: exactly
+    the branch and the residual), so the node's gradient buffer holds the LayerNorm's tensor by reference until both ran."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _ffn_block_ok(x, linear1, linear2, norm):
+    from . import norm as N
+    w1, b1, w2, b2 = linear1.weight, linear1.bias, linear2.weight, linear2.bias
+    T = x.numel() // x.shape[-1]
+    return (not torch.is_autocast_enabled() and torch.is_grad_enabled() and b1 is not None and b2 is not None
+            and w1.requires_grad and w2.requires_grad and x.requires_grad and T >= EXPAND_MIN_ROWS
+            and x.dtype == w1.dtype == w2.dtype and expand_supported(x, w1.shape[0]) and supported(x, w1)
+            and w2.shape[0] % 128 == 0 and w1.shape[0] % 128 == 0 and os.environ.get("RLIPV2_FUSED_FFN", "1") != "0"
+            and len(norm.normalized_shape) == 1 and N.supported(x, x, norm.weight, norm.bias))
+
+
+residual_gradient_in_gemm = True      # (tools/r04_host_ab.py flips the attribute for its A/B)
+
+
+def ffn_residual_norm(x, linear1, linear2, norm):
+    """norm(x + linear2(relu(linear1(x)))) of the post-norm encoder layer (`forward_ffn`,
+    dab_deformable/deformable_transformer.py:1285-1289, dropout 0).  With the fused FFN node and the fused add + LayerNorm
+    the two backward nodes are linked: the LayerNorm returns ONE gradient tensor for both of its addends, the FFN's
+    input-gradient GEMM accumulates into that tensor (beta = 1) and returns nothing of its own -- the sum autograd would
+    form (d_x = d_residual + d_branch, 136 MB of traffic per layer) is the GEMM's epilogue."""
+    from . import norm as N
+    if residual_gradient_in_gemm and _ffn_block_ok(x, linear1, linear2, norm):
+        link = N.GradLink()
+        xa = _Alias.apply(x)
+        y = FusedFFNFunction.apply(xa, linear1.weight, linear1.bias, linear2.weight, linear2.bias, link)
+        return N.AddLayerNormFunction.apply(xa, y, norm.weight, norm.bias, norm.eps, link)
+    return N.add_layer_norm(x, fused_ffn(x, linear1, linear2), norm)
 
 
 def fused_ffn(x, linear1, linear2):

@@ -46,11 +46,19 @@ def _check(st, what):
         raise RuntimeError(f"{what}: " + _lib.strerror(st))
 
 
+class GradLink:
+    """Python-side hand-over between two backward nodes of one residual block (see linear.ffn_residual_norm): the
+    LayerNorm's backward leaves the gradient tensor it returns for BOTH addends here, the branch's backward recognises it
+    as its own incoming gradient and accumulates the branch's input gradient into it in place."""
+    dx = None
+
+
 class AddLayerNormFunction(torch.autograd.Function):
     """y = LayerNorm(a + b); the gradient of a and of b is the same tensor."""
 
     @staticmethod
-    def forward(ctx, a, b, weight, bias, eps):
+    def forward(ctx, a, b, weight, bias, eps, link=None):
+        ctx.link = link
         if not a.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
         a = a.contiguous()
@@ -87,7 +95,9 @@ class AddLayerNormFunction(torch.autograd.Function):
                                              ws.numel(), torch.cuda.current_stream(a.device).cuda_stream),
                "add_layernorm_backward")
         roofline.add(roofline.tensor_bytes(dy, a, b, weight, mean, rstd, dx, dgamma, dbeta))
-        return dx, (dx if b is not None else None), dgamma, dbeta, None
+        if ctx.link is not None:
+            ctx.link.dx = dx
+        return dx, (dx if b is not None else None), dgamma, dbeta, None, None
 
 
 def add_layer_norm(a, b, norm: torch.nn.LayerNorm):

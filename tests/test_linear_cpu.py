@@ -52,3 +52,68 @@ def test_tuned_table_is_wellformed():
     ops = [r for r in rows if r[0] != "Validator"]
     assert ops and all(len(r) == 4 and r[0].startswith("Gemm") and r[2].startswith("Gemm_") and float(r[3]) > 0
                        for r in ops)
+
+
+def test_residual_gradient_accumulated_by_the_ffn_gemm_logic():
+    """linear.ffn_residual_norm links the fused FFN node and the fused add + LayerNorm node: the LayerNorm's backward returns one
+    tensor for both addends, the FFN's input-gradient GEMM accumulates into it in place and returns None.  The kernels behind
+    the two nodes are GPU-only; here their calls are replaced by torch arithmetic (test-side stand-ins) so that the LOGIC --
+    who accumulates into whom, what autograd finally hands to the layer input -- is checked against plain autograd."""
+    import torch.nn.functional as F
+
+    from rlipv2_amd import norm
+
+    class TorchAddLayerNorm(torch.autograd.Function):          # the protocol of norm.AddLayerNormFunction in torch arithmetic
+        @staticmethod
+        def forward(ctx, a, b, weight, bias, eps, link=None):
+            ctx.link = link
+            x = a + b
+            mean = x.mean(-1, keepdim=True)
+            rstd = (x.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+            ctx.save_for_backward(x, weight, mean, rstd)
+            return (x - mean) * rstd * weight + bias
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, weight, mean, rstd = ctx.saved_tensors
+            xh = (x - mean) * rstd
+            gd = dy * weight
+            dx = rstd * (gd - gd.mean(-1, keepdim=True) - xh * (gd * xh).mean(-1, keepdim=True))
+            if ctx.link is not None:
+                ctx.link.dx = dx
+            red = tuple(range(dy.dim() - 1))
+            return dx, dx, (dy * xh).sum(red), dy.sum(red), None, None
+
+    saved = (linear.linear_wgrad, linear.expand_gemm, linear._ffn_block_ok, norm.AddLayerNormFunction)
+    linear.linear_wgrad = lambda dy, x, with_bias=True, out_dtype=None: (
+        dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1]).sum(0))
+    linear.expand_gemm = lambda a, b, bias=None, mask=None, relu=False: (a @ b.t()) * (mask > 0)
+    linear._ffn_block_ok = lambda *a: True
+    norm.AddLayerNormFunction = TorchAddLayerNorm
+    try:
+        torch.manual_seed(0)
+        l1, l2, ln = torch.nn.Linear(16, 64), torch.nn.Linear(64, 16), torch.nn.LayerNorm(16)
+        x0 = torch.randn(3, 7, 16)
+        w = torch.randn(3, 7, 16)
+        res = []
+        for fused in (True, False):
+            for p in list(l1.parameters()) + list(l2.parameters()) + list(ln.parameters()):
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            src = x * 1.5                                       # a non-leaf input with one more consumer below
+            y = linear.ffn_residual_norm(src, l1, l2, ln) if fused else ln(src + l2(F.relu(l1(src))))
+            ((y * w).sum() + (src * 0.25).sum()).backward()
+            res.append([x.grad.clone()] + [p.grad.clone() for p in list(l1.parameters()) + list(l2.parameters()) + list(ln.parameters())])
+        for a, b in zip(*res):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+        # the accumulation really happened in place: the FFN node returned no gradient of its own
+        x = x0.clone().requires_grad_(True)
+        y = linear.ffn_residual_norm(x * 1.0, l1, l2, ln)
+        ffn_node = [n for n, _ in y.grad_fn.next_functions if n is not None and "FusedFFN" in type(n).__name__]
+        assert len(ffn_node) == 1
+        seen = {}
+        ffn_node[0].register_hook(lambda gin, gout: seen.setdefault("gin", gin))
+        (y * w).sum().backward()
+        assert seen["gin"][0] is None
+    finally:
+        linear.linear_wgrad, linear.expand_gemm, linear._ffn_block_ok, norm.AddLayerNormFunction = saved

@@ -10,7 +10,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rlipv2_amd import blocks, decoder, encoder, parseda, train  # noqa: E402
+from rlipv2_amd import blocks, decoder, encoder, linear, parseda, train  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 
@@ -68,6 +68,7 @@ def product():
     blocks.cache_padding_free = True
     parseda.batched_heads = True
     decoder.share_box_deltas = True
+    linear.residual_gradient_in_gemm = True
 
 
 def off(name):
@@ -85,4 +86,5 @@ if __name__ == "__main__":
     measure("sine encodings recomputed", off((blocks, "cache_padding_free")))
     measure("heads per decoder layer", off((parseda, "batched_heads")))
     measure("box-head MLPs run twice, op-sequence box head", off((decoder, "share_box_deltas")))
+    measure("FFN residual gradient summed by autograd", off((linear, "residual_gradient_in_gemm")))
     measure("product again (box-to-box noise)", product)

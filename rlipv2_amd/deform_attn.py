@@ -157,7 +157,7 @@ class MSDeformAttn(nn.Module):
         constant_(self.output_proj.bias.data, 0.)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None):
+                input_padding_mask=None, value_grad_link=None):
         """query [N, Lq, C]; reference_points [N, Lq, L, 2|4] in [0, 1]; input_flatten [N, S, C];
         input_spatial_shapes int64 [L, 2]; input_level_start_index int64 [L]; input_padding_mask
         [N, S] (True = padding).  Returns [N, Lq, C]."""
@@ -174,7 +174,8 @@ class MSDeformAttn(nn.Module):
         else:
             assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == Len_in
 
-        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
+        # (value_grad_link: not part of the reference's signature -- the encoder layer's linked attention block, encoder.py)
+        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, grad_link=value_grad_link)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, Len_in, M, self.d_model // M)

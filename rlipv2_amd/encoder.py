@@ -13,8 +13,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .deform_attn import MSDeformAttn
-from .linear import ffn_residual_norm, fused_ffn, token_linear
-from .norm import add_layer_norm
+from .linear import _AddInto, _Alias, attention_block_link_ok, ffn_residual_norm, fused_ffn, token_linear
+from .norm import AddLayerNormFunction, GradLink, add_layer_norm
 
 
 inplace_tail = True       # (tests flip it to compare with the concatenating form)
@@ -51,9 +51,22 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
-        q = src if pos is None else src + pos
-        attn = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
-        src = add_layer_norm(src, self.dropout1(attn), self.norm1)
+        if (not (self.training and self.dropout1.p > 0)
+                and attention_block_link_ok(src, pos, self.self_attn.value_proj.weight, self.norm1)):
+            # Linked block: d_src = d_residual + d_value W_v + d_query has three producers (the LayerNorm's backward, the value
+            # projection's input-gradient GEMM, the query's add); left to autograd that is two sums of 45 MB tensors.  Here the
+            # LayerNorm's tensor is the accumulator: the GEMM adds into it (beta = 1), the query's gradient is added in place.
+            # `xa` is consumed by exactly these three nodes, so its gradient buffer holds that tensor by reference.
+            link = GradLink()
+            xa = _Alias.apply(src, link)
+            q = _AddInto.apply(xa, pos, link)
+            attn = self.self_attn(q, reference_points, xa, spatial_shapes, level_start_index, padding_mask,
+                                  value_grad_link=link)
+            src = AddLayerNormFunction.apply(xa, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps, link)
+        else:
+            q = src if pos is None else src + pos
+            attn = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+            src = add_layer_norm(src, self.dropout1(attn), self.norm1)
         if self.activation is F.relu and not (self.training and self.dropout2.p > 0):
             # one autograd node for linear2(relu(linear1(.))): the ReLU mask rides in the input-gradient GEMM, and the
             # residual's gradient in the last GEMM's accumulator (dropout3 is the identity here: --dropout 0.0; with a live

@@ -155,8 +155,6 @@ class FusedFFNFunction(torch.autograd.Function):
         shared = (link is not None and link.dx is not None and dy.is_contiguous() and ctx.needs_input_grad[0]
                   and (link.dx is dy or (link.dx.data_ptr() == dy.data_ptr() and link.dx.shape == dy.shape
                                          and link.dx.stride() == dy.stride() and link.dx.dtype == dy.dtype)))
-        if link is not None:
-            link.dx = None
         dy = dy.contiguous()
         dw2, db2 = linear_wgrad(dy, h, with_bias=True, out_dtype=w2.dtype)
         dh = expand_gemm(dy, w2.t(), mask=h)                     # w2.t().contiguous(): 1 MB, inside expand_gemm
@@ -170,16 +168,41 @@ class FusedFFNFunction(torch.autograd.Function):
 
 
 class _Alias(torch.autograd.Function):
-    """x as a new autograd node: whatever consumes the alias is known to the code that made it (ffn_residual_norm: exactly
-    the branch and the residual), so the node's gradient buffer holds the LayerNorm's tensor by reference until both ran."""
+    """x as a new autograd node: whatever consumes the alias is known to the code that made it (exactly the block's branch
+    nodes and its residual), so the node's gradient buffer holds the LayerNorm's tensor by reference until all of them ran.
+    Its backward runs last and drops the link's reference."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, link=None):
+        ctx.link = link
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        return g
+        if ctx.link is not None:
+            ctx.link.dx = None
+        return g, None
+
+
+class _AddInto(torch.autograd.Function):
+    """x + pos (the query of the encoder's self-attention, deformable_transformer.py:1291) for a linked block: the gradient of
+    `x` is added into the link's tensor in place (the same add autograd would do, but the buffer stays the one every node of
+    the block accumulates into); `pos` receives the gradient as usual."""
+
+    @staticmethod
+    def forward(ctx, x, pos, link):
+        ctx.link = link
+        return x + pos
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        acc = ctx.link.dx
+        g_pos = g if ctx.needs_input_grad[1] else None
+        if acc is not None and acc.shape == g.shape and acc.dtype == g.dtype:
+            acc.add_(g)
+            return None, g_pos, None
+        return g, g_pos, None
 
 
 def _ffn_block_ok(x, linear1, linear2, norm):
@@ -196,6 +219,16 @@ def _ffn_block_ok(x, linear1, linear2, norm):
 residual_gradient_in_gemm = True      # (tools/r04_host_ab.py flips the attribute for its A/B)
 
 
+def attention_block_link_ok(src, pos, value_weight, norm):
+    """the encoder layer's attention block can run linked (encoder.py): fused add + LayerNorm and the token-major Linear route
+    for the value projection, same shapes throughout"""
+    from . import norm as N
+    return (residual_gradient_in_gemm and pos is not None and pos.shape == src.shape and pos.dtype == src.dtype
+            and torch.is_grad_enabled() and src.requires_grad and not torch.is_autocast_enabled()
+            and supported(src, value_weight) and len(norm.normalized_shape) == 1
+            and N.supported(src, src, norm.weight, norm.bias))
+
+
 def ffn_residual_norm(x, linear1, linear2, norm):
     """norm(x + linear2(relu(linear1(x)))) of the post-norm encoder layer (`forward_ffn`,
     dab_deformable/deformable_transformer.py:1285-1289, dropout 0).  With the fused FFN node and the fused add + LayerNorm
@@ -205,7 +238,7 @@ def ffn_residual_norm(x, linear1, linear2, norm):
     from . import norm as N
     if residual_gradient_in_gemm and _ffn_block_ok(x, linear1, linear2, norm):
         link = N.GradLink()
-        xa = _Alias.apply(x)
+        xa = _Alias.apply(x, link)
         y = FusedFFNFunction.apply(xa, linear1.weight, linear1.bias, linear2.weight, linear2.bias, link)
         return N.AddLayerNormFunction.apply(xa, y, norm.weight, norm.bias, norm.eps, link)
     return N.add_layer_norm(x, fused_ffn(x, linear1, linear2), norm)
@@ -234,10 +267,15 @@ def _linear_forward(x, weight, bias, relu):
 
 
 class TokenLinearFunction(torch.autograd.Function):
+    """`link` (norm.GradLink, attention block of the encoder layer -- encoder.py): the input `x` is the residual input of
+    the block's LayerNorm, whose backward has already left the residual's gradient tensor in the link; the input gradient
+    dy W is then accumulated INTO that tensor (one GEMM with beta = 1) and nothing is returned for `x`."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, relu=False):
+    def forward(ctx, x, weight, bias, relu=False, link=None):
         y = _linear_forward(x, weight, bias, relu)
         ctx.relu = relu
+        ctx.link = link
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
 
@@ -247,11 +285,18 @@ class TokenLinearFunction(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         if ctx.relu:
             dy = torch.ops.aten.threshold_backward(dy, y, 0)
-        dx = dy.matmul(weight) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            acc = ctx.link.dx if ctx.link is not None else None
+            if (acc is not None and acc.shape == x.shape and acc.dtype == dy.dtype and acc.is_contiguous()
+                    and dy.is_contiguous()):
+                acc.view(-1, acc.shape[-1]).addmm_(dy.view(-1, dy.shape[-1]), weight)
+            else:
+                dx = dy.matmul(weight)
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = linear_wgrad(dy, x, with_bias=ctx.needs_input_grad[2], out_dtype=weight.dtype)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 _ones = {}
@@ -318,16 +363,17 @@ def add_row_vector(x, row):
     return x + row.view(1, 1, -1)
 
 
-def token_linear(x, weight, bias=None, relu=False):
+def token_linear(x, weight, bias=None, relu=False, grad_link=None):
     """relu?(F.linear(x, weight, bias)) with the MFMA weight-gradient kernel behind it when the shape
-    qualifies; `relu=True` puts the activation into the GEMM epilogue."""
+    qualifies; `relu=True` puts the activation into the GEMM epilogue.  `grad_link`: see TokenLinearFunction (only
+    honoured on that route; every other route returns the input gradient the usual way)."""
     if torch.is_autocast_enabled():
         # autocast runs (float32 parameters, per-op casts): the custom backward paths assume one dtype throughout
         y = F.linear(x, weight, bias)
         return F.relu(y) if relu else y
     if torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad):
         if supported(x, weight):
-            return TokenLinearFunction.apply(x, weight, bias, relu)
+            return TokenLinearFunction.apply(x, weight, bias, relu, grad_link)
         if (enabled and x.is_cuda and bias is not None and x.dtype == weight.dtype
                 and x.dtype in (torch.bfloat16, torch.float32) and (bias.requires_grad or relu)):
             return SmallLinearFunction.apply(x, weight, bias, relu)

@@ -117,3 +117,72 @@ def test_residual_gradient_accumulated_by_the_ffn_gemm_logic():
         assert seen["gin"][0] is None
     finally:
         linear.linear_wgrad, linear.expand_gemm, linear._ffn_block_ok, norm.AddLayerNormFunction = saved
+
+
+def test_linked_attention_block_accumulates_into_the_layernorm_gradient():
+    """The encoder layer's linked attention block (encoder.py): the value projection's input-gradient GEMM and the query's add
+    accumulate into the tensor the LayerNorm's backward returned for the residual.  Kernels replaced by torch stand-ins (they
+    are GPU-only); the composition mirrors DeformableTransformerEncoderLayer.forward with an elementwise mix standing for the
+    sampling.  Gradients of the layer input, of `pos` and of every parameter against plain autograd."""
+    import torch.nn.functional as F
+
+    from rlipv2_amd import norm
+
+    class TorchAddLayerNorm(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a, b, weight, bias, eps, link=None):
+            ctx.link = link
+            x = a + b
+            mean = x.mean(-1, keepdim=True)
+            rstd = (x.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+            ctx.save_for_backward(x, weight, mean, rstd)
+            return (x - mean) * rstd * weight + bias
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, weight, mean, rstd = ctx.saved_tensors
+            xh = (x - mean) * rstd
+            gd = dy * weight
+            dx = rstd * (gd - gd.mean(-1, keepdim=True) - xh * (gd * xh).mean(-1, keepdim=True))
+            if ctx.link is not None:
+                ctx.link.dx = dx
+            red = tuple(range(dy.dim() - 1))
+            return dx, dx, (dy * xh).sum(red), dy.sum(red), None, None
+
+    saved = linear.linear_wgrad
+    linear.linear_wgrad = lambda dy, x, with_bias=True, out_dtype=None: (
+        dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1]).sum(0))
+    try:
+        torch.manual_seed(1)
+        C = 16
+        vp, qp, op, ln = torch.nn.Linear(C, C), torch.nn.Linear(C, 24), torch.nn.Linear(C, C), torch.nn.LayerNorm(C)
+        mods = (vp, qp, op, ln)
+        x0, pos0, w = torch.randn(2, 9, C), torch.randn(2, 9, C), torch.randn(2, 9, C)
+        res = []
+        for linked in (True, False):
+            for m in mods:
+                for p in m.parameters():
+                    p.grad = None
+            x = x0.clone().requires_grad_(True)
+            pos = pos0.clone().requires_grad_(True)
+            src = x * 0.5
+            if linked:
+                link = norm.GradLink()
+                xa = linear._Alias.apply(src, link)
+                q = linear._AddInto.apply(xa, pos, link)
+                value = linear.TokenLinearFunction.apply(xa, vp.weight, vp.bias, False, link)
+                qproj = linear.TokenLinearFunction.apply(q, qp.weight, qp.bias, False, None)
+                attn = linear.TokenLinearFunction.apply(value * torch.sigmoid(qproj[..., :C]), op.weight, op.bias, False, None)
+                y = TorchAddLayerNorm.apply(xa, attn, ln.weight, ln.bias, ln.eps, link)
+            else:
+                value = vp(src)
+                qproj = qp(src + pos)
+                y = ln(src + op(value * torch.sigmoid(qproj[..., :C])))
+            ((y * w).sum() + (src * 0.1).sum()).backward()
+            res.append([x.grad.clone(), pos.grad.clone()] + [p.grad.clone() for m in mods for p in m.parameters()])
+            if linked:
+                assert link.dx is None                           # dropped by the alias node, the last of the block
+        for a, b in zip(*res):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    finally:
+        linear.linear_wgrad = saved

@@ -63,6 +63,57 @@ def test_encoder_f32(last_vis):
     C.close(lang.grad.cpu(), g["g_lang"].cpu(), 1e-3, 1e-5, "g_lang")
 
 
+def test_linked_encoder_layer_equals_the_unlinked_nodes_bf16():
+    """DeformableTransformerEncoderLayer in bfloat16 with its two residual blocks linked (the value projection's and the FFN's
+    input-gradient GEMMs accumulate into the tensors the fused LayerNorms return; encoder.py / linear.py, round 4) against the
+    same layer with plain nodes (autograd sums the contributions): same kernels, so the outputs are equal and the gradients of
+    the input, of `pos` and of all parameters agree to bf16 accumulation noise.  Tokens >= 4096 so that the fused FFN applies."""
+    from rlipv2_amd import linear
+    from rlipv2_amd.msda import attach_host_shapes
+    torch.manual_seed(11)
+    pyr = [(40, 54), (20, 27), (10, 14), (5, 7)]
+    S = sum(h * w for h, w in pyr)
+    shapes = torch.tensor(pyr, dtype=torch.long, device=DEV)
+    attach_host_shapes(shapes, pyr)
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    layer = encoder.DeformableTransformerEncoderLayer(256, 1024, 0.0, "relu", 4, 8, 4).to(DEV).to(torch.bfloat16).train()
+    N = 2
+    x0 = torch.randn(N, S, 256, device=DEV).to(torch.bfloat16)
+    pos0 = (0.5 * torch.randn(N, S, 256, device=DEV)).to(torch.bfloat16)
+    gy = torch.randn(N, S, 256, device=DEV).to(torch.bfloat16)
+    ref = encoder.encoder_reference_points(pyr, torch.ones(N, 4, 2, device=DEV), DEV)
+    params = list(layer.parameters())
+
+    def run(linked):
+        linear.residual_gradient_in_gemm = linked
+        try:
+            for p in params:
+                p.grad = None
+            x = x0.clone().requires_grad_()
+            pos = pos0.clone().requires_grad_()
+            y = layer(x * 1.0, pos, ref, shapes, starts, None)
+            kinds = set()
+            stack = [y.grad_fn]
+            while stack:
+                n = stack.pop()
+                if n is None or len(kinds) > 400:
+                    continue
+                kinds.add(type(n).__name__)
+                stack.extend(f for f, _ in n.next_functions)
+            y.backward(gy)
+            return [y.detach().float(), x.grad.float(), pos.grad.float()] + [p.grad.float() for p in params], kinds
+        finally:
+            linear.residual_gradient_in_gemm = True
+
+    linked, kinds = run(True)
+    plain, kinds_plain = run(False)
+    assert "_AddIntoBackward" in kinds and "_AliasBackward" in kinds and "_AddIntoBackward" not in kinds_plain, kinds
+    assert torch.equal(linked[0], plain[0])
+    for a, b in zip(linked[1:], plain[1:]):
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-6))
+        assert rel < 1e-2, rel
+
+
 @pytest.mark.parametrize("parse", [1, 0])
 def test_dab_decoder_f32(parse):
     g = dev(C.load(f"decoder_parse{parse}"))

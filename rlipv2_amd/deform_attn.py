@@ -174,7 +174,10 @@ class MSDeformAttn(nn.Module):
         else:
             assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == Len_in
 
-        # (value_grad_link: not part of the reference's signature -- the encoder layer's linked attention block, encoder.py)
+        # (value_grad_link: not part of the reference's signature -- the encoder layer's linked attention block, encoder.py;
+        #  or attached to the image memory by linear.shared_input for the decoders' value projections)
+        if value_grad_link is None:
+            value_grad_link = getattr(input_flatten, "value_grad_link", None)
         value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, grad_link=value_grad_link)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)

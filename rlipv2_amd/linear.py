@@ -219,6 +219,24 @@ def _ffn_block_ok(x, linear1, linear2, norm):
 residual_gradient_in_gemm = True      # (tools/r04_host_ab.py flips the attribute for its A/B)
 
 
+def shared_input(x):
+    """`x` for several token-major Linears that all read it (the image memory under the six decoder layers' value projections,
+    deformable_transformer.py:1346-1401): their input gradients d_l W_l are summed by the GEMMs themselves -- the first one's
+    result becomes the accumulator, the others add into it (beta = 1) -- instead of five autograd sums of 45 MB tensors.  The
+    link travels as an attribute of the returned alias (`value_grad_link`, read by MSDeformAttn.forward).  The alias must be consumed ONLY by such Linears: any other
+    consumer's gradient would be summed by autograd into a new tensor and later in-place contributions would be lost."""
+    from . import norm as N
+    if not (residual_gradient_in_gemm and enabled and torch.is_grad_enabled() and x.requires_grad and x.is_cuda
+            and x.dtype == torch.bfloat16 and not torch.is_autocast_enabled()
+            and x.numel() // x.shape[-1] >= MIN_ROWS):          # (the route every consumer below will take: TokenLinearFunction)
+        return x
+    link = N.GradLink()
+    link.first_creates = True
+    xa = _Alias.apply(x, link)
+    xa.value_grad_link = link
+    return xa
+
+
 def attention_block_link_ok(src, pos, value_weight, norm):
     """the encoder layer's attention block can run linked (encoder.py): fused add + LayerNorm and the token-major Linear route
     for the value projection, same shapes throughout"""
@@ -293,6 +311,8 @@ class TokenLinearFunction(torch.autograd.Function):
                 acc.view(-1, acc.shape[-1]).addmm_(dy.view(-1, dy.shape[-1]), weight)
             else:
                 dx = dy.matmul(weight)
+                if ctx.link is not None and ctx.link.first_creates and acc is None:
+                    ctx.link.dx = dx                             # the first consumer's gradient becomes the accumulator
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = linear_wgrad(dy, x, with_bias=ctx.needs_input_grad[2], out_dtype=weight.dtype)

@@ -49,8 +49,10 @@ def _check(st, what):
 class GradLink:
     """Python-side hand-over between two backward nodes of one residual block (see linear.ffn_residual_norm): the
     LayerNorm's backward leaves the gradient tensor it returns for BOTH addends here, the branch's backward recognises it
-    as its own incoming gradient and accumulates the branch's input gradient into it in place."""
+    as its own incoming gradient and accumulates the branch's input gradient into it in place.  `first_creates`: no
+    LayerNorm in the block (linear.shared_input) -- the first Linear's input gradient becomes the accumulator."""
     dx = None
+    first_creates = False
 
 
 class AddLayerNormFunction(torch.autograd.Function):

@@ -33,7 +33,7 @@ from .blocks import (MLP, FeatureResizer, MultiBranchFusion, NestedTensor, inver
                      nested_tensor_from_tensor_list)
 from .decoder import DABDeformableTransformerDecoderHOI, DeformableTransformerDecoderLayer, box_head
 from .deform_attn import MSDeformAttn
-from .linear import add_row_vector
+from .linear import add_row_vector, shared_input
 from .encoder import DeformableTransformerEncoderLayer, RLIPv2_DeformableTransformerEncoder, _clones
 
 
@@ -235,6 +235,8 @@ class RLIP_ParSeDABDeformableTransformer_v2(nn.Module):
         verb_tgt = query_embed[..., d:2 * d].unsqueeze(0).expand(bs, -1, -1)
         init_reference = (ref_sub, ref_obj)
 
+        # (the image memory is read by the value projections of all decoder layers and by nothing else below)
+        img_memory = shared_input(img_memory)
         hs_ho, inter_refs = self.ho_decoder(tgt, init_reference, img_memory, spatial_shapes, level_start_index,
                                             valid_ratios, query_pos=None, src_padding_mask=masks)
         if getattr(hs_ho, "deltas", None) is not None:          # (the decoder's own split of its last layer output)

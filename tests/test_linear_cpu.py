@@ -186,3 +186,37 @@ def test_linked_attention_block_accumulates_into_the_layernorm_gradient():
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     finally:
         linear.linear_wgrad = saved
+
+
+def test_shared_input_of_several_linears_is_summed_by_their_gemms():
+    """linear.shared_input's protocol (the image memory under the six decoder layers' value projections): the first Linear's
+    input gradient becomes the accumulator, the others add into it, the alias node hands the sum on.  torch stand-in for the
+    weight-gradient kernel; against plain autograd."""
+    from rlipv2_amd import norm
+    saved = linear.linear_wgrad
+    linear.linear_wgrad = lambda dy, x, with_bias=True, out_dtype=None: (
+        dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1]).sum(0))
+    try:
+        torch.manual_seed(2)
+        lins = [torch.nn.Linear(12, 12) for _ in range(4)]
+        x0 = torch.randn(2, 5, 12)
+        ws = [torch.randn(2, 5, 12) for _ in lins]
+        res = []
+        for linked in (True, False):
+            for m in lins:
+                m.weight.grad = m.bias.grad = None
+            x = x0.clone().requires_grad_(True)
+            src = torch.tanh(x)
+            if linked:
+                link = norm.GradLink()
+                link.first_creates = True
+                xa = linear._Alias.apply(src, link)
+                outs = [linear.TokenLinearFunction.apply(xa, m.weight, m.bias, False, link) for m in lins]
+            else:
+                outs = [m(src) for m in lins]
+            sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+            res.append([x.grad.clone()] + [p.grad.clone() for m in lins for p in m.parameters()])
+        for a, b in zip(*res):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    finally:
+        linear.linear_wgrad = saved

@@ -114,6 +114,42 @@ def test_linked_encoder_layer_equals_the_unlinked_nodes_bf16():
         assert rel < 1e-2, rel
 
 
+def test_gradient_links_change_nothing_in_the_train_step_bf16():
+    """Whole train step of a small bf16 model (encoder layers with both residual blocks linked, the image memory shared by the
+    decoders' value projections: linear.residual_gradient_in_gemm) against the same step with plain autograd sums: same loss,
+    every parameter gradient within bf16 accumulation noise.  Dropout off; 2 x 384 x 480 images = 7 656 tokens (fused FFN on)."""
+    from rlipv2_amd import linear, train
+    torch.manual_seed(0)
+    margs = parseda.default_args(num_queries=40, enc_layers=4, dec_layers=2)
+    model, criterion = train.build_training(margs, device=DEV, with_text_encoder=True)
+    train.to_bf16(model)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.train()
+    step = train.ParSeDATrainStep(model)
+    batch = train.synthetic_batch(2, 384, 480, n_obj=13, n_verb=7, triplets=3, device=DEV, seed=1)
+    batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    train.freeze_parameters_without_gradient(step, criterion, batch)
+    res = {}
+    for linked in (True, False, True):
+        linear.residual_gradient_in_gemm = linked
+        try:
+            model.zero_grad(set_to_none=True)
+            loss = criterion.weighted_sum(criterion(step(*batch), batch[2]))
+            loss.backward()
+            got = (float(loss), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            linear.residual_gradient_in_gemm = True
+        if linked and True in res:                               # the linked step again: how far two runs of it are apart
+            noise = max(float((got[1][n] - res[True][1][n]).norm() / res[True][1][n].norm().clamp_min(1e-12)) for n in got[1])
+        res[linked] = got
+    assert abs(res[True][0] - res[False][0]) <= 1e-3 * abs(res[False][0])
+    assert res[True][1].keys() == res[False][1].keys()
+    worst = max((float((res[True][1][n] - g).norm() / g.norm().clamp_min(1e-12)), n) for n, g in res[False][1].items())
+    assert worst[0] <= max(2e-2, 4 * noise), (worst, noise)
+
+
 @pytest.mark.parametrize("parse", [1, 0])
 def test_dab_decoder_f32(parse):
     g = dev(C.load(f"decoder_parse{parse}"))

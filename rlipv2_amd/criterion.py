@@ -118,9 +118,13 @@ class HungarianMatcherHOI(nn.Module):
         c_sub_box = torch.cdist(sub_box, t_sub_box, p=1)
         c_obj_box = torch.cdist(obj_box, t_obj_box, p=1) * (t_obj_box != 0).any(dim=1).unsqueeze(0)
         c_box = c_sub_box if c_sub_box.shape[1] == 0 else torch.max(c_sub_box, c_obj_box)
-        c_sub_giou = -generalized_box_iou(box_cxcywh_to_xyxy(sub_box), box_cxcywh_to_xyxy(t_sub_box))
-        c_obj_giou = -generalized_box_iou(box_cxcywh_to_xyxy(obj_box), box_cxcywh_to_xyxy(t_obj_box)) \
-            + c_sub_giou * (t_obj_box == 0).all(dim=1).unsqueeze(0)
+        # (subject and object boxes through ONE pairwise GIoU: the two diagonal blocks of the [2Q, 2T] matrix are the two cost
+        #  matrices; the off-diagonal blocks are wasted arithmetic on a launch-bound call)
+        Q, T = sub_box.shape[0], t_sub_box.shape[0]
+        giou_all = generalized_box_iou(box_cxcywh_to_xyxy(torch.cat((sub_box, obj_box))),
+                                       box_cxcywh_to_xyxy(torch.cat((t_sub_box, t_obj_box))))
+        c_sub_giou = -giou_all[:Q, :T]
+        c_obj_giou = -giou_all[Q:, T:] + c_sub_giou * (t_obj_box == 0).all(dim=1).unsqueeze(0)
         c_giou = c_sub_giou if c_sub_giou.shape[1] == 0 else torch.max(c_sub_giou, c_obj_giou)
         C = self.cost_obj_class * c_obj + self.cost_verb_class * c_verb + self.cost_bbox * c_box \
             + self.cost_giou * c_giou
@@ -477,8 +481,11 @@ class SetCriterionHOI(nn.Module):
             n_exist = exist.view(K, -1).sum(1) + 1e-4
             out['loss_sub_bbox'] = (src_s - tgt_s).abs().view(K, -1).sum(1) / num_interactions
             out['loss_obj_bbox'] = ((src_o - tgt_o).abs() * exist.unsqueeze(1)).view(K, -1).sum(1) / n_exist
-            g_s = 1 - paired_giou(box_cxcywh_to_xyxy(src_s), box_cxcywh_to_xyxy(tgt_s))
-            g_o = 1 - paired_giou(box_cxcywh_to_xyxy(src_o), box_cxcywh_to_xyxy(tgt_o))
+            # (subject and object pairs through ONE GIoU evaluation: the ~30 launch-bound kernels of a call -- and twice that
+            #  in its backward -- once instead of twice; per-pair arithmetic unchanged)
+            g_both = 1 - paired_giou(box_cxcywh_to_xyxy(torch.cat((src_s, src_o))),
+                                     box_cxcywh_to_xyxy(torch.cat((tgt_s, tgt_o))))
+            g_s, g_o = g_both.split(src_s.shape[0])
             out['loss_sub_giou'] = g_s.view(K, -1).sum(1) / num_interactions
             out['loss_obj_giou'] = (g_o * exist).view(K, -1).sum(1) / n_exist
 

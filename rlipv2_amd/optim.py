@@ -59,17 +59,27 @@ class FusedMasterAdamW:
         self.chunk = sizes[3].value
         self._tables = {}        # tuple of gradient pointers -> (tensor table, chunk table, n_chunks)
         self._relayout = {}
+        self._checked = [None] * len(self.params)    # per parameter: the gradient OBJECT whose dtype / layout passed last
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             p.grad = None
 
     def _grads(self):
+        """(indices, gradients) of the parameters that have one.  The graphed step hands over the SAME gradient tensors every
+        step (static buffers): a gradient object that passed the dtype / layout check once is not checked again -- the
+        per-parameter shape / stride comparison was ~1 ms of Python per step for ~750 parameters, between the end of the
+        backward graph and the optimiser's two launches."""
         idx, grads = [], []
+        checked = self._checked
         for i, p in enumerate(self.params):
             g = p.grad
             if g is None:
                 continue                                   # torch.optim skips parameters without gradient
+            if g is checked[i]:
+                idx.append(i)
+                grads.append(g)
+                continue
             if g.dtype != torch.bfloat16 or not _same_layout(g, p):
                 # e.g. a convolution weight kept channels-last whose gradient arrives contiguous: re-lay it
                 # out into a persistent buffer (stable address -> the pointer table stays cached)
@@ -78,6 +88,8 @@ class FusedMasterAdamW:
                     buf = self._relayout[i] = torch.empty_like(p)
                 g = buf.copy_(g)
                 self.grad_copies = getattr(self, "grad_copies", 0) + 1
+            else:
+                checked[i] = g
             idx.append(i)
             grads.append(g)
         return idx, grads

@@ -4,6 +4,7 @@ drops what is not an instruction (directives, comments, label numbering) and has
 of a revision that passed the GPU tests is the code that ran there, instruction for instruction; a kernel whose hash differs
 has not run on hardware, whatever the source diff looks like.
 usage: python tools/isa_audit.py <revision> [<revision-or-WORKTREE>] [--filter substring] [--defines "-DX ..."]
+       python tools/isa_audit.py --manifest out.json label1=rev1 label2=rev2 ...   (tests/golden/isa_manifest.json)
 """
 import argparse
 import hashlib
@@ -83,7 +84,47 @@ def audit(tree, defines):
     return out
 
 
+def tree_of(rev, dst):
+    """a revision (or WORKTREE) unpacked into `dst`"""
+    if rev == "WORKTREE":
+        subprocess.run(f"mkdir -p {dst}/rlipv2_amd && cp -r {ROOT}/rlipv2_amd/csrc {dst}/rlipv2_amd/ && rm -rf {dst}/rlipv2_amd/csrc/_obj "
+                       f"&& cp -r {ROOT}/include {dst}/", shell=True, check=True)
+    else:
+        checkout(rev, dst)
+    return dst
+
+
+def hashes_of(rev, defines=()):
+    """{(file, mangled kernel name): (instruction count, hash)} of a revision or of the working tree"""
+    with tempfile.TemporaryDirectory() as t:
+        return audit(tree_of(rev, t), list(defines))
+
+
+def manifest(revisions):
+    """Hardware status of every kernel of the working tree: for each kernel its hash and the EARLIEST-listed revision among
+    `revisions` = [(label, revision), ...] whose build contains a kernel with exactly that instruction stream (under any
+    name: template arguments get renamed), else "never_run"."""
+    known = [(label, {v[1] for v in hashes_of(rev).values()}) for label, rev in revisions]
+    cur = hashes_of("WORKTREE")
+    dm = demangle(sorted({k for _, k in cur}))
+    out = {}
+    for (f, k), (n, h) in sorted(cur.items()):
+        status = next((label for label, hs in known if h in hs), "never_run")
+        out[f"{f}::{dm[k]}"] = {"instructions": n, "hash": h, "hardware": status}
+    return out
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--manifest":
+        import json
+        revs = [tuple(a.split("=", 1)) for a in sys.argv[3:]]
+        m = manifest(revs)
+        json.dump({"revisions": dict(revs), "kernels": m}, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+        counts = {}
+        for v in m.values():
+            counts[v["hardware"]] = counts.get(v["hardware"], 0) + 1
+        print(counts)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("a")
     ap.add_argument("b", nargs="?", default="WORKTREE")

@@ -30,4 +30,6 @@ def test_device_code_equals_the_manifest():
     assert not changed, f"device code changed (hardware status lost): {changed[:5]}"
     # what the product's default train step runs must have run on hardware, with two known exceptions
     never = sorted(k for k, v in want.items() if v["hardware"] == "never_run")
-    assert all("cell_forward_kernel" in k or "fused_adamw.hip::" in k for k in never), never
+    # (cell_forward_kernel: opt-in experiment; step_scaled_kernel: the optimiser's data-parallel form, grad_scale != 1 -- the
+    #  one-GPU step runs round 2's step_kernel)
+    assert all("cell_forward_kernel" in k or "step_scaled_kernel" in k for k in never), never

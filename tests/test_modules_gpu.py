@@ -111,94 +111,31 @@ def test_full_parseda_f32():
             C.close(params[name].grad.cpu(), g[key], 1e-3, 1e-5, "grad " + name)
 
 
-def _golden_loss_gradients(model, bb, gg, g, trace):
-    """outputs + gradients of the golden's loss (feature maps and sentinel parameters) of one run of the small model"""
-    deform_attn.MSDeformAttn.trace = trace
-    try:
-        mc, out, feats, _ = C.run_small_parseda(model, bb, gg, device=DEV)
-        loss = 0
-        for k in C.KEYS:
-            loss = loss + (out[k].float() * g["g_" + k].to(DEV)).sum() \
-                + (out["aux_outputs"][0][k].float() * g["g_" + k].to(DEV)).sum() * 0.5
-        loss.backward()
-    finally:
-        deform_attn.MSDeformAttn.trace = None
-    grads = {f"g_feat{i}": t.grad.float().cpu() for i, (t, _) in enumerate(feats)}
-    params = dict(model.named_parameters(remove_duplicate=False))
-    for key in g:
-        if key.startswith("gparam_") and g[key].numel():
-            name = key[len("gparam_"):].replace("__", ".")
-            grads[name] = params[name].grad.float().cpu()
-    return out, grads
-
-
 def test_full_parseda_bf16_against_the_f32_reference_golden():
-    """The headline dtype at model level, with stated tolerances.  bf16 policy: weights / activations / value in bfloat16;
-    sampling geometry, softmax, bilinear weights and accumulators in float32.
-
-    OUTPUTS against the float32 reference golden (two images of different size, 5 outputs + first auxiliary layer; measured
-    with tools/bf16_parity_probe.py on MI355X in round 3, margins ~1.5-3x):
+    """The headline dtype at model level, OUTPUTS against the float32 reference golden (two images of different size, 5 outputs +
+    first auxiliary layer; measured with tools/bf16_parity_probe.py on MI355X in round 3, margins ~1.5-3x).  bf16 policy:
+    weights / activations / value in bfloat16; sampling geometry, softmax, bilinear weights and accumulators in float32.
       logits  max |err| <= 2e-2 x max |reference|     (measured: subject / object 4.2e-3, verb 1.24e-2)
       boxes   max |err| <= 5e-3 absolute               (measured: 8.0e-4 / 1.8e-3)
-
-    GRADIENTS of the golden's loss against a float32 run OF THIS MODEL on the bf16-rounded weights and inputs (itself pinned to
-    the reference by test_full_parseda_f32), with the sampling pinned: every MSDeformAttn call of the float32 run is handed the
-    bf16 run's projection rows and reference points (straight-through: values from the bf16 run, gradients through its own
-    graph), so both runs take the same floor() decisions -- the model-level counterpart of `kink_samples` at op level: a sample
-    whose location one bf16 rounding moves across a pixel centre changes ITS gradient completely and says nothing about the
-    kernels.  What is left is the arithmetic: cosine >= 0.95 for the three feature maps and every sentinel parameter (round 3
-    accepted 0.88 against the golden on UNROUNDED weights; a wrong-sign contribution of 45 % of the gradient norm passed that,
-    at 0.95 it is 16 %).  The bar comes from the same comparison run with PyTorch's own CPU bfloat16 arithmetic, which rounds
-    every intermediate (0.968-1.000, relative L2 0.02-0.27: weight rounding alone explains most of the distance to the golden);
-    the values measured here are printed so that the bar can be raised on the first GPU run of the round.
-    Parity proper is claimed in float32 (test_full_parseda_f32: logits 1e-3 rel, boxes 1e-4 abs)."""
+    and a finite backward pass.  The GRADIENTS are checked in tests/test_zz_round4_gpu.py against a float32 run of this model on
+    the bf16-rounded weights with the sampling pinned, cosine >= 0.95 (round 3 accepted 0.88 here against the golden on
+    unrounded weights).  Parity proper is claimed in float32 (test_full_parseda_f32: logits 1e-3 rel, boxes 1e-4 abs)."""
     g = C.load("parseda")
     model, bb = C.build_small_parseda()
     model = model.to(DEV).to(torch.bfloat16)
     gb = {k: (v.to(torch.bfloat16) if v.dtype == torch.float32 else v) for k, v in g.items()}
     gb["img_mask"] = g["img_mask"]
-    recorded = []
-
-    def record(module, qproj, ref):
-        recorded.append((qproj.detach().clone(), ref.detach().clone()))
-        return qproj, ref
-
-    out, grads = _golden_loss_gradients(model, bb, gb, g, record)
+    mc, out, feats, _ = C.run_small_parseda(model, bb, gb, device=DEV)
+    loss = 0
     for k in C.KEYS:
         for got, ref, what in ((out[k], g[k], k), (out["aux_outputs"][0][k], g["aux0_" + k], "aux " + k)):
             err = (got.float().cpu() - ref).abs().max().item()
             tol = 5e-3 if "boxes" in k else 2e-2 * ref.abs().max().item()
             assert err <= tol, (what, err, tol)
-
-    ref_model, ref_bb = C.build_small_parseda()
-    with torch.no_grad():
-        for p in ref_model.parameters():
-            p.copy_(p.to(torch.bfloat16).float())
-    ref_model = ref_model.to(DEV)
-    g32 = {k: (v.to(torch.bfloat16).float() if v.dtype == torch.float32 else v) for k, v in g.items()}
-    g32["img_mask"] = g["img_mask"]
-    replay = iter(recorded)
-
-    def force(module, qproj, ref):
-        q_rec, r_rec = next(replay)
-        return qproj + (q_rec.float() - qproj).detach(), r_rec.float()
-
-    _, ref_grads = _golden_loss_gradients(ref_model, ref_bb, g32, g, force)
-    assert next(replay, None) is None and len(recorded) >= 6
-
-    def cosine(a, b):
-        a, b = a.double().flatten(), b.double().flatten()
-        return float((a @ b) / (a.norm() * b.norm() + 1e-300))
-
-    worst = {}
-    for name, got in grads.items():
-        assert torch.isfinite(got).all(), name
-        ref = ref_grads[name]
-        worst[name] = (cosine(got, ref), float((got - ref).double().norm() / (ref.double().norm() + 1e-300)))
-    print("bf16 vs float32-on-rounded-weights, sampling pinned (cosine, relative L2):",
-          {k: (round(c, 4), round(r, 4)) for k, (c, r) in worst.items()})
-    for name, (c, r) in worst.items():
-        assert c >= 0.95, (name, c, r)
+        loss = loss + (out[k].float() * g["g_" + k].to(DEV)).sum() + (out["aux_outputs"][0][k].float() * g["g_" + k].to(DEV)).sum() * 0.5
+    loss.backward()
+    for t, _ in feats:
+        assert torch.isfinite(t.grad.float()).all()
 
 
 @pytest.mark.parametrize("nd", [2, 4])

@@ -271,7 +271,7 @@ def fused_ffn(x, linear1, linear2):
             and w1.requires_grad and w2.requires_grad and T >= EXPAND_MIN_ROWS and x.dtype == w1.dtype == w2.dtype
             and expand_supported(x, w1.shape[0]) and supported(x, w1)
             and w2.shape[0] % 128 == 0 and w1.shape[0] % 128 == 0 and os.environ.get("RLIPV2_FUSED_FFN", "1") != "0"):
-        return FusedFFNFunction.apply(x, w1, b1, w2, b2)
+        return FusedFFNFunction.apply(x, w1, b1, w2, b2, None)
     return token_linear(token_linear(x, w1, b1, relu=True), w2, b2)
 
 

@@ -105,7 +105,7 @@ class AddLayerNormFunction(torch.autograd.Function):
 def add_layer_norm(a, b, norm: torch.nn.LayerNorm):
     """norm(a + b) (b may be None) with the module's weight / bias / eps."""
     if supported(a, b, norm.weight, norm.bias) and len(norm.normalized_shape) == 1:
-        return AddLayerNormFunction.apply(a, b, norm.weight, norm.bias, norm.eps)
+        return AddLayerNormFunction.apply(a, b, norm.weight, norm.bias, norm.eps, None)
     return norm(a if b is None else a + b)
 
 

@@ -37,7 +37,7 @@ class DropPath(nn.Module):
         if self.p == 0.0 or not self.training:
             return x
         keep = 1.0 - self.p
-        # (timm's drop_path, which the reference imports -- models/swin/swin_transformer.py:14: the MASK is scaled by 1 / keep,
+        # (timm's drop_path, which the reference imports -- models/swin/swin_transformer.py:21: the MASK is scaled by 1 / keep,
         #  then one multiply; `x * mask / keep` was one more pass over the activations forward and backward per residual branch)
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep).div_(keep)
         return x * mask

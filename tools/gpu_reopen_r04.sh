@@ -22,4 +22,6 @@ cat $OUT/experiments.txt
 tail -25 $OUT/pytest_cell_forward.txt
 timeout 600 python bench.py --no-cpu-baseline --msda-fwd-cell > $OUT/bench_line_fwd_cell.json 2> $OUT/bench_fwd_cell_stderr.txt
 tail -c 600 $OUT/bench_line_fwd_cell.json
+# brief item 6 decided by one measurement: today's chunk plan against one chunk + direct stores (small-token Linears)
+( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; for m in 8 100000; do RLIPV2_WGRAD_MINSTEPS=$m timeout 300 python tools/wgrad_plan_ab.py; done > $OUT/wgrad_plan_ab.txt 2>&1 ); cat $OUT/wgrad_plan_ab.txt
 bash tools/gpu_final_r03.sh reopen_r04/final

@@ -39,7 +39,7 @@ def main():
     dec = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     deform_attn.msda_function = OracleMSDeformAttnFunction
     g = T.load("parseda")
-    args = parseda.default_args(num_queries=20, enc_layers=4, dec_layers=dec, dim_feedforward=512, pseudo_verb=True)
+    args = parseda.default_args(num_queries=20, enc_layers=2 * dec, dec_layers=dec, dim_feedforward=512, pseudo_verb=True)      # (one language state per fusion = per decoder layer, as the scripts have it)
     bb = T._FeatureBackbone((32, 64, 128))
     model = parseda.build_parseda(bb, args).eval()
     T.fill_closed_form(model)

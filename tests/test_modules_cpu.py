@@ -780,3 +780,80 @@ def test_host_glue_operator_count_does_not_creep_back():
 
 
 BUDGET = 2850          # 2 765 at the end of round 4 (6 encoder + 3 decoder layers, padding-free batch, CPU twins; 3 245 at its start)
+
+
+def test_full_parseda_with_linked_gradient_accumulation_matches_reference():
+    """The GPU-only routes of round 4's gradient links, WIRED AS THE MODULES WIRE THEM, against the reference golden of the full
+    model: encoder layers with both residual blocks linked (encoder.py), the image memory shared by the decoders' value
+    projections (parseda.py -> linear.shared_input -> MSDeformAttn.forward's `value_grad_link`).  Those routes are taken only
+    for CUDA bfloat16 tensors because the kernels behind them are GPU-only; here the gates are opened and the kernel calls
+    replaced by torch arithmetic (test-side stand-ins, float32), so that outputs and every golden gradient check the node
+    wiring: who accumulates into whose tensor, what the alias nodes hand on."""
+    from rlipv2_amd import linear, norm
+
+    class TorchAddLayerNorm(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a, b, weight, bias, eps, link=None):
+            ctx.link = link
+            x = a if b is None else a + b
+            mean = x.mean(-1, keepdim=True)
+            rstd = (x.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+            ctx.save_for_backward(x, weight, mean, rstd)
+            ctx.has_b = b is not None
+            return (x - mean) * rstd * weight + bias
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, weight, mean, rstd = ctx.saved_tensors
+            xh = (x - mean) * rstd
+            gd = dy * weight
+            dx = rstd * (gd - gd.mean(-1, keepdim=True) - xh * (gd * xh).mean(-1, keepdim=True))
+            if ctx.link is not None:
+                ctx.link.dx = dx
+            red = tuple(range(dy.dim() - 1))
+            return dx, (dx if ctx.has_b else None), (dy * xh).sum(red), dy.sum(red), None, None
+
+    def shared(x):
+        link = norm.GradLink()
+        link.first_creates = True
+        xa = linear._Alias.apply(x, link)
+        xa.value_grad_link = link
+        return xa
+
+    linked_calls = []
+    real_alias = linear._Alias.apply
+    saved = (linear.supported, linear.linear_wgrad, linear.expand_gemm, linear._ffn_block_ok, norm.supported,
+             norm.AddLayerNormFunction, encoder.AddLayerNormFunction, parseda.shared_input, linear.EXPAND_MIN_ROWS)
+    linear.supported = lambda x, w: True
+    linear.linear_wgrad = lambda dy, x, with_bias=True, out_dtype=None: (
+        dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1]),
+        dy.reshape(-1, dy.shape[-1]).sum(0) if with_bias else None)
+    linear.expand_gemm = lambda a, b, bias=None, mask=None, relu=False: (a @ b.t()) * (mask > 0)
+    linear._ffn_block_ok = lambda x, l1, l2, n: True
+    norm.supported = lambda a, b, w, bias: True
+    norm.AddLayerNormFunction = encoder.AddLayerNormFunction = TorchAddLayerNorm
+    parseda.shared_input = shared
+    linear._Alias.apply = staticmethod(lambda *a: (linked_calls.append(1), real_alias(*a))[1])
+    try:
+        g = load("parseda")
+        model, bb = build_small_parseda()
+        mc, out, feats, _ = run_small_parseda(model, bb, g)
+        loss = 0
+        for k in KEYS:
+            box = "boxes" in k
+            close(out[k], g[k], 1e-3 if not box else 0.0, 1e-5 if not box else 1e-4, k)
+            loss = loss + (out[k] * g["g_" + k]).sum() + (out["aux_outputs"][0][k] * g["g_" + k]).sum() * 0.5
+        loss.backward()
+        # 4 encoder layers x (attention block + FFN block) + the shared image memory
+        assert len(linked_calls) == 4 * 2 + 1, len(linked_calls)
+        for i, (t, _) in enumerate(feats):
+            close(t.grad, g[f"g_feat{i}"], 1e-3, 1e-5, f"g_feat{i}")
+        params = dict(model.named_parameters(remove_duplicate=False))
+        for key in g:
+            if key.startswith("gparam_") and g[key].numel():
+                name = key[len("gparam_"):].replace("__", ".")
+                close(params[name].grad, g[key], 1e-3, 1e-5, "grad " + name)
+    finally:
+        (linear.supported, linear.linear_wgrad, linear.expand_gemm, linear._ffn_block_ok, norm.supported,
+         norm.AddLayerNormFunction, encoder.AddLayerNormFunction, parseda.shared_input, linear.EXPAND_MIN_ROWS) = saved
+        linear._Alias.apply = real_alias

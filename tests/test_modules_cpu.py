@@ -857,3 +857,40 @@ def test_full_parseda_with_linked_gradient_accumulation_matches_reference():
         (linear.supported, linear.linear_wgrad, linear.expand_gemm, linear._ffn_block_ok, norm.supported,
          norm.AddLayerNormFunction, encoder.AddLayerNormFunction, parseda.shared_input, linear.EXPAND_MIN_ROWS) = saved
         linear._Alias.apply = real_alias
+
+
+@pytest.mark.parametrize("switch", ["batched_heads", "share_box_deltas", "cache_padding_free", "cache_reference_points"])
+def test_ab_switches_of_the_host_restructures_compute_the_same_function(switch):
+    """tools/r04_host_ab.py times the train step with each of round 4's host-side restructures switched off; both sides of every
+    switch must be the same function (outputs and gradients), or the A/B would compare different models."""
+    from oracle_function import OracleMSDeformAttnFunction
+
+    from rlipv2_amd import train
+    mod = {"batched_heads": parseda, "share_box_deltas": decoder, "cache_padding_free": blocks,
+           "cache_reference_points": encoder}[switch]
+    old = deform_attn.msda_function
+    deform_attn.msda_function = OracleMSDeformAttnFunction
+    try:
+        args = parseda.default_args(num_queries=12, enc_layers=2, dec_layers=1, dim_feedforward=128, pseudo_verb=False)
+        torch.manual_seed(3)
+        model, crit = train.build_training(args, device="cpu", with_text_encoder=False)
+        model.eval()
+        step = train.ParSeDATrainStep(model)
+        samples, _, targets = train.synthetic_batch(2, 64, 96, n_obj=6, n_verb=4, triplets=2, device="cpu", seed=5)
+        g = torch.Generator().manual_seed(9)
+        mem = torch.tanh(torch.randn(10, 1, 768, generator=g)).repeat(1, 2, 1)
+        text = (~(mem.sum(-1) > 0), mem, torch.tensor([[6, 4]]))
+        res = []
+        for on in (True, False):
+            setattr(mod, switch, on)
+            model.zero_grad(set_to_none=True)
+            out = step(samples, text, targets)
+            crit.weighted_sum(crit(out, targets)).backward()
+            res.append([out[k].detach().clone() for k in KEYS if k in out]
+                       + [p.grad.clone() for p in model.parameters() if p.grad is not None])
+        assert len(res[0]) == len(res[1])
+        for a, b in zip(*res):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+    finally:
+        setattr(mod, switch, True)
+        deform_attn.msda_function = old

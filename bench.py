@@ -321,18 +321,42 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     eager_step = step_module
     force_dp = os.environ.get("RLIPV2_FORCE_DP") == "1" and dist.is_initialized()   # 1-rank plumbing check
     overlap = bool(args.dp_overlap)
+    frozen = False
     if world > 1 or force_dp:
         train.broadcast_parameters(model, 0)
         # static unused-parameter mask from a dry run (identical on every rank), instead of per-step graph
         # searches (find_unused_parameters=True in the reference, main.py:517)
         train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
+        frozen = True
+    # GPU-only host routes (rlipv2_amd/routes.py) are off in the package; the step's own self-check switches on the ones that
+    # reproduce the plain step's loss and gradients on THIS model and batch (all ranks agree on the verdict)
+    from rlipv2_amd import routes
+    if args.host_routes == "auto":
+        if args.graph and dtype is None and not frozen:
+            train.freeze_parameters_without_gradient(step_module, criterion, batch)
+            frozen = True
+        try:
+            host_routes = routes.validate(step_module, criterion, batch, autocast_dtype=dtype,
+                                          log=lambda m: print(m, file=sys.stderr))
+        except Exception as e:                                  # noqa: BLE001 -- the plain step is always available
+            if world > 1:
+                raise                                           # (ranks must not disagree on the graph they run)
+            routes.set_all(False)
+            print(f"[bench] host-route self-check raised, all routes off: {type(e).__name__}: {e}", file=sys.stderr)
+            host_routes = {k: f"off (self-check raised {type(e).__name__})" for k in routes.GPU_ONLY_ROUTES}
+            for p_ in step_module.parameters():
+                p_.grad = None
+    else:
+        routes.set_all(args.host_routes == "on")
+        host_routes = {k: ("on (forced, no self-check)" if v else "off (forced)") for k, v in routes.state().items()}
     if args.graph and dtype is None:
         # HIP-graph the two model phases (forward graph + backward graph); the criterion's host-side
         # assignment and the optimiser stay eager.  Data-parallel runs average the gradients with one flat
         # RCCL all-reduce after the backward replay (train.GradientSynchronizer).
         try:
             if world == 1 and not force_dp:
-                train.freeze_parameters_without_gradient(step_module, criterion, batch)
+                if not frozen:
+                    train.freeze_parameters_without_gradient(step_module, criterion, batch)
             else:
                 synchronizer = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
                 # the 1 / world of the gradient average is applied inside the fused optimiser's kernels (no extra pass
@@ -402,11 +426,18 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         # of the very same train step (same model, batch, optimiser), right after the timed region
         # (one untimed eager step first: the first eager backward after the graph replays re-grows the caching
         #  allocator's pools, which showed up as 4x longer decoder launches in the probe)
-        train.train_step(eager_step, criterion, optimizer, batch, autocast_dtype=dtype)
+        # (data-parallel runs: forward + backward only -- `eager_step` has no synchroniser, an optimiser step on local
+        #  gradients would let the ranks' weights drift apart before the process group is torn down)
+        def probe_step():
+            if world > 1:
+                train._forward_backward(eager_step, criterion, optimizer, batch, dtype)
+            else:
+                train.train_step(eager_step, criterion, optimizer, batch, autocast_dtype=dtype)
+        probe_step()
         torch.cuda.synchronize()
         timer.enabled = True
         for _ in range(2):
-            train.train_step(eager_step, criterion, optimizer, batch, autocast_dtype=dtype)
+            probe_step()
         torch.cuda.synchronize()
         timer.enabled = False
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
@@ -420,19 +451,42 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         except Exception as e:                                  # noqa: BLE001 -- accounting only, never fatal
             print(f"[bench] step roofline probe failed: {type(e).__name__}: {e}", file=sys.stderr)
             step_roofline = {"error": f"{type(e).__name__}: {e}"}   # the line says so instead of dropping the key
-    return elapsed, timer.summary(), float(loss), n_params, graphed, step_roofline
+    dp = {"graphed": graphed, "overlap": bool(graphed and overlap and (world > 1 or force_dp)), "dp_group": bool(world > 1 or force_dp)}
+    return elapsed, timer.summary(), float(loss), n_params, dp, step_roofline, host_routes
+
+
+def parallelism_text(world, graphed, overlap, dp_group):
+    """`config.parallelism` of the train-step line: what carried the gradients between the ranks and how the model ran."""
+    if graphed and dp_group and overlap:
+        return (f"dp{world} (bf16 RCCL gradient all-reduce in buckets of arrival order, captured inside the backward graph on a "
+                "communication stream: bucket k travels while autograd computes the earlier layers); model forward/backward "
+                "replayed as HIP graphs")
+    if graphed:
+        return (f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
+                "model forward/backward replayed as HIP graphs")
+    return f"dp{world} (DDP: bucketed RCCL gradient all-reduce overlapped with backward); eager launches"
+
+
+def newest_traffic_file():
+    """profiles/r0N_final_traffic.json of the highest round (written by tools/gpu_final_r0N.sh + tools/pmc_final_summary.py)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_final_traffic.json")))
+    return found[-1] if found else None
 
 
 def pmc_traffic(kernel_key, args):
     """HBM bytes per launch (fetch + write) of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's
-    kernels (profiles/r03_final_traffic.json, written by tools/gpu_final_r03.sh: separate FETCH_SIZE / WRITE_SIZE runs with
+    kernels (the newest profiles/r0N_final_traffic.json, written by tools/gpu_final_r03.sh: separate FETCH_SIZE / WRITE_SIZE runs with
     --kernel-trace only, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  A recorded value, not measured by this
     run: it is only reported when the file names the same kernels the call ran (a kernel revision that renames or
     replaces them makes the key `null` instead of quoting stale bytes) and the configuration matches."""
-    path = os.path.join(ROOT, "profiles", "r03_final_traffic.json")
-    if args.dtype != "bf16" or args.batch != 4 or not os.path.exists(path):
+    path = newest_traffic_file()
+    if args.dtype != "bf16" or args.batch != 4 or path is None:
         return None
-    t = json.load(open(path))
+    return traffic_from_table(json.load(open(path)), kernel_key)
+
+
+def traffic_from_table(t, kernel_key):
     parts = {"enc_bwd_fused": ["msda:cell_backward_kernel+geometry", "msda:patch_dest_kernel"],
              "enc_bwd": ["b0:cell_backward_kernel", "b0:patch_dest_kernel"],
              "enc_fwd_fused": ["fwd:quad_forward_fused_kernel"]}.get(kernel_key)
@@ -442,7 +496,7 @@ def pmc_traffic(kernel_key, args):
 
 
 def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None,
-         step_roofline=None, b0=None):
+         step_roofline=None, b0=None, host_routes=None):
     probe_steps = args.steps if probe_steps is None else probe_steps
     dominant = max(kern, key=lambda n: kern[n]["ms"])
     kd = kern[dominant]
@@ -485,8 +539,9 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": pmc_traffic(dominant, args),
-            "traffic_source": "recorded: profiles/r03_final_traffic.json (rocprofv3 --pmc passes of the same kernels, "
-                              "tools/gpu_final_r03.sh); null when no profile of the kernels that ran is committed",
+            "traffic_source": "recorded: %s (rocprofv3 --pmc passes of the same kernels, tools/gpu_final_r03.sh); null when "
+                              "no profile of the kernels that ran is committed" % (
+                                  os.path.relpath(newest_traffic_file(), ROOT) if newest_traffic_file() else "no profiles/r0N_final_traffic.json"),
             "algorithmic_bytes_per_launch": kd["bytes"],
             "bytes_definition": "SURVEY.md 8d: value + sampling_loc + attn_weight + grad_out read, grad_value + "
                                 "grad_sampling_loc + grad_attn_weight written, each once (bf16 value / grad_out / grad_value, "
@@ -503,6 +558,8 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
     }
     if b0 is not None:
         line["roofline"]["b0_signature_kernels"] = b0
+    if host_routes is not None:
+        line["config"]["host_routes"] = host_routes
     if step_roofline is not None and "error" in step_roofline:
         line["step_roofline"] = step_roofline
     elif step_roofline is not None:
@@ -579,6 +636,9 @@ def main():
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-routes", default="auto", choices=["auto", "off", "on"],
+                    help="GPU-only host routes of the train step (rlipv2_amd/routes.py): auto = switch on the ones that pass the "
+                         "start-up self-check against the plain step (default), off / on = forced")
     ap.add_argument("--msda-fwd-cell", action="store_true",
                     help="EXPERIMENT: the encoder's fused MSDA forward through cell_forward_kernel (LDS windows + matrix cores); "
                          "not validated on hardware, never the default")
@@ -632,7 +692,8 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     lib = _lib.lib()
     if args.workload == "train_step":
-        elapsed, kern, loss, n_params, graphed, step_roofline = run_train_step_bench(args, world, rank, local_rank, device)
+        elapsed, kern, loss, n_params, dp, step_roofline, host_routes = run_train_step_bench(args, world, rank, local_rank, device)
+        graphed = dp["graphed"]
         if rank == 0:
             emit(args, world, elapsed, kern, lib, workload_text=(
                 "train_step: RLIP_ParSeDA_v2 " + {"resnet50": "R50", "swin_large": "Swin-L", "swin_tiny": "Swin-T"}[args.backbone]
@@ -646,19 +707,12 @@ def main():
                 + ("; VARIANT padded batch: images of 800x1333 and 736x1100 padded together, padding masks live" if args.padded else "")
                 + ("; VARIANT variable targets: 8 / 6 / 11 triplets per image in rotation, one graph capture per bucket" if args.var_targets else "")
                 + ("; VARIANT eager launches (no HIP graphs)" if not args.graph else "")),
-                 parallelism=(f"dp{world} (bf16 RCCL gradient all-reduce in buckets of arrival order, captured inside the "
-                              "backward graph on a communication stream: bucket k travels while autograd computes the "
-                              "earlier layers); model forward/backward replayed as HIP graphs"
-                              if graphed and (world > 1 or os.environ.get("RLIPV2_FORCE_DP") == "1")
-                              and bool(getattr(step_module, "overlap", False)) else
-                              f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
-                              "model forward/backward replayed as HIP graphs" if graphed else
-                              f"dp{world} (DDP: bucketed RCCL gradient all-reduce overlapped with backward); eager launches"),
+                 parallelism=parallelism_text(world, dp["graphed"], dp["overlap"], dp["dp_group"]),
                  cpu_calls=lambda: build_msda_step(1, torch.float32, device, 0),
                  probe_steps=2 if graphed else None,
                  probe_note=("HIP events around every MSDA call in 2 eager steps of the same train step run right after "
                              "the timed region (the timed steps replay HIP graphs, whose kernels cannot be bracketed)")
-                 if graphed else None, step_roofline=step_roofline,
+                 if graphed else None, step_roofline=step_roofline, host_routes=host_routes,
                  b0=b0_signature_kernels(args.batch, dtype, device) if args.backbone == "resnet50" else None)
         if world > 1:
             dist.destroy_process_group()

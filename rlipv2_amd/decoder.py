@@ -41,7 +41,9 @@ direct_self_attention = os.environ.get("RLIPV2_DEC_SELF_ATTN", "1") != "0"      
 fused_glue = os.environ.get("RLIPV2_DEC_GLUE", "1") != "0"                     # (A/B switch)
 
 
-share_box_deltas = True       # (tools/r04_host_ab.py flips the attribute for its A/B: heads' MLPs once + one-launch box head)
+share_box_deltas = True       # the heads' MLPs run once per layer and are shared with the refinement (device-agnostic)
+# GPU-only route, OFF until rlipv2_amd/routes.validate() has compared it with the op sequence on the caller's own step
+one_launch_box_head = False
 
 
 def _glue_ok(*tensors):
@@ -88,7 +90,7 @@ class BoxHeadFunction(torch.autograd.Function):
 def box_head(delta, ref):
     """sigmoid(delta + inverse_sigmoid(ref)), differentiable in `delta` (and in `ref` when it requires grad: the
     learnable anchors of layer 0 keep the op sequence)."""
-    if (share_box_deltas and not ref.requires_grad and ref.shape[-1] == 4 and delta.shape == ref.shape and delta.is_cuda
+    if (one_launch_box_head and not ref.requires_grad and ref.shape[-1] == 4 and delta.shape == ref.shape and delta.is_cuda
             and _glue_ok(ref)
             and delta.dtype in (torch.bfloat16, torch.float32)):
         return BoxHeadFunction.apply(delta, ref)

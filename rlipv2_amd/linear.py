@@ -202,6 +202,8 @@ class _AddInto(torch.autograd.Function):
         if acc is not None and acc.shape == g.shape and acc.dtype == g.dtype:
             acc.add_(g)
             return None, g_pos, None
+        if acc is not None:
+            ctx.link.dx, ctx.link.broken = None, True            # (see TokenLinearFunction.backward)
         return g, g_pos, None
 
 
@@ -216,7 +218,8 @@ def _ffn_block_ok(x, linear1, linear2, norm):
             and len(norm.normalized_shape) == 1 and N.supported(x, x, norm.weight, norm.bias))
 
 
-residual_gradient_in_gemm = True      # (tools/r04_host_ab.py flips the attribute for its A/B)
+# GPU-only route, OFF until rlipv2_amd/routes.validate() has compared it with the plain nodes on the caller's own step
+residual_gradient_in_gemm = False
 
 
 def shared_input(x):
@@ -305,14 +308,19 @@ class TokenLinearFunction(torch.autograd.Function):
             dy = torch.ops.aten.threshold_backward(dy, y, 0)
         dx = None
         if ctx.needs_input_grad[0]:
-            acc = ctx.link.dx if ctx.link is not None else None
-            if (acc is not None and acc.shape == x.shape and acc.dtype == dy.dtype and acc.is_contiguous()
-                    and dy.is_contiguous()):
-                acc.view(-1, acc.shape[-1]).addmm_(dy.view(-1, dy.shape[-1]), weight)
+            link = ctx.link
+            acc = link.dx if link is not None else None
+            if acc is not None and acc.shape == x.shape and acc.dtype == dy.dtype and acc.is_contiguous():
+                # once a link has an accumulator EVERY contribution goes into it: a gradient returned the normal way would be
+                # summed by autograd out of place, and what later nodes add into the accumulator would be lost
+                dyc = dy if dy.is_contiguous() else dy.contiguous()
+                acc.view(-1, acc.shape[-1]).addmm_(dyc.reshape(-1, dyc.shape[-1]), weight)
             else:
                 dx = dy.matmul(weight)
-                if ctx.link is not None and ctx.link.first_creates and acc is None:
-                    ctx.link.dx = dx                             # the first consumer's gradient becomes the accumulator
+                if acc is not None:
+                    link.dx, link.broken = None, True            # unusable accumulator: the remaining nodes return normally
+                elif link is not None and link.first_creates and not link.broken:
+                    link.dx = dx                                 # the first consumer's gradient becomes the accumulator
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = linear_wgrad(dy, x, with_bias=ctx.needs_input_grad[2], out_dtype=weight.dtype)

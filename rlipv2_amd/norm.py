@@ -53,6 +53,7 @@ class GradLink:
     LayerNorm in the block (linear.shared_input) -- the first Linear's input gradient becomes the accumulator."""
     dx = None
     first_creates = False
+    broken = False          # a node could not use the accumulator: from then on every node returns its gradient normally
 
 
 class AddLayerNormFunction(torch.autograd.Function):

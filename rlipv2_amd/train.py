@@ -106,6 +106,16 @@ class GraphedTrainForward(nn.Module):
         return out
 
 
+def effective_overlap(overlap, synchronizer):
+    """The overlapped (bucketed, in-graph) schedule is only available when the collectives of the synchronizer's group can be
+    captured into a HIP graph, i.e. on RCCL.  Resolved by ONE rule for every kind of step (GraphedStep, EagerSyncStep,
+    GraphedStepCache): ranks that mix a replayed capture with an eager step must still issue the same collectives."""
+    if not overlap or synchronizer is None:
+        return False
+    import torch.distributed as dist
+    return bool(dist.is_available() and dist.is_initialized() and dist.get_backend(synchronizer.group) == "nccl")
+
+
 class GraphedStep:
     """Forward graph + backward graph of the two model phases with the parameter gradients delivered
     directly, outside autograd.
@@ -139,10 +149,7 @@ class GraphedStep:
         self.step_module = step_module
         self.synchronizer = synchronizer
         self.criterion = criterion
-        if overlap and synchronizer is not None:
-            import torch.distributed as dist                      # only RCCL collectives can be captured into the graph
-            overlap = dist.is_initialized() and dist.get_backend(synchronizer.group) == "nccl"
-        self.overlap = bool(overlap) and synchronizer is not None
+        self.overlap = effective_overlap(overlap, synchronizer)    # only RCCL collectives can be captured into the graph
         self.wrapper = GraphedTrainForward(step_module, text["obj_pred_names_sums"],
                                            model.transformer.ho_decoder.num_layers, model.pseudo_verb)
         self.wrapper.no_padding = bool(getattr(samples, "no_padding", False))      # baked into the capture
@@ -327,6 +334,8 @@ class EagerSyncStep:
 
     def __init__(self, step_module, criterion, synchronizer=None, overlap=False, autocast_dtype=None):
         self.step_module, self.criterion, self.synchronizer = step_module, criterion, synchronizer
+        # (the eager bucketed schedule runs on any backend; whoever pairs this step with captured ones passes the schedule
+        #  those can run -- GraphedStepCache does)
         self.overlap = bool(overlap) and synchronizer is not None
         self.autocast_dtype = autocast_dtype
         self.params = synchronizer.params if synchronizer is not None else [p for p in step_module.parameters()
@@ -390,7 +399,10 @@ class GraphedStepCache:
         self.step_module, self.model = step_module, model
         self.synchronizer, self.criterion = synchronizer, criterion
         self.max_buckets, self.capture_after = max_buckets, max(1, int(capture_after))
-        self.overlap = bool(overlap) and synchronizer is not None
+        # ONE schedule for the captured steps and the eager step: GraphedStep can only run the overlapped one on RCCL
+        # (a stand-in factory, CPU tests, runs whatever it is given)
+        self.overlap = (effective_overlap(overlap, synchronizer) if factory is None
+                        else bool(overlap) and synchronizer is not None)
         self.graphs = {}                    # key -> GraphedStep (insertion order = recency)
         self.seen = {}                      # key -> times met
         self.captures = self.hits = self.eager_steps = self.evictions = 0
@@ -452,6 +464,8 @@ class GraphedStepCache:
             self.graphs.pop(next(iter(self.graphs)))
             self.evictions += 1
         g = self.factory(batch)
+        if getattr(g, "overlap", self.overlap) != self.overlap:
+            raise RuntimeError("GraphedStepCache: the captured step and the eager step disagree on the gradient schedule")
         self.captures += 1
         self.graphs[key] = g
         return g

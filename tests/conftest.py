@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the GPU suite = evidence per minute under `pytest -x`: the op-level oracle / golden tests of the
+# hot path first, then the other kernels, the modules, the newest tests, and the whole-bench contract last
+# (one failure in a late, broad test must not hide the op-level parity results).
+GPU_SUITE_ORDER = ["test_msda_gpu", "test_msda_cell_forward_gpu", "test_norm_gpu", "test_linear_gpu", "test_optim_gpu",
+                   "test_modules_gpu", "test_zz_round4_gpu", "test_zz_round5_gpu", "test_bench_contract"]
+
+
+def gpu_suite_rank(nodeid):
+    name = os.path.basename(nodeid.split("::")[0])[:-3]
+    return GPU_SUITE_ORDER.index(name) if name in GPU_SUITE_ORDER else len(GPU_SUITE_ORDER) - 1.5
+
+
+def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda it: gpu_suite_rank(it.nodeid) if it.get_closest_marker("gpu") else -1)
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN_DIR, f"msda_{name}.npz")) as z:
         return {k: z[k] for k in z.files}

@@ -1,0 +1,112 @@
+"""Host logic of bench.py and of the evidence tools that needs no GPU: the `parallelism` text for 1 / N ranks (round 4's
+bench.py died in emit() for every N > 1), which recorded traffic table the roofline quotes, the kernel-name labels of the
+counter summary, and the verdict logic of the host-route self-check."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from rlipv2_amd import routes  # noqa: E402
+from tools import pmc_final_summary  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_parallelism_text(world):
+    flat = bench.parallelism_text(world, graphed=True, overlap=False, dp_group=world > 1)
+    assert flat.startswith(f"dp{world} (one flat") and "HIP graphs" in flat
+    over = bench.parallelism_text(world, graphed=True, overlap=True, dp_group=True)
+    assert over.startswith(f"dp{world} (bf16 RCCL gradient all-reduce in buckets") and "HIP graphs" in over
+    # the overlapped text needs a process group: a 1-rank run without one never claims it
+    assert bench.parallelism_text(world, graphed=True, overlap=True, dp_group=False) == bench.parallelism_text(world, True, False, False)
+    eager = bench.parallelism_text(world, graphed=False, overlap=True, dp_group=True)
+    assert eager.startswith(f"dp{world} (DDP") and "eager" in eager
+
+
+def test_emit_of_a_multi_rank_line_needs_nothing_from_the_step_function(monkeypatch, capsys):
+    """emit() with world = 2 and the values run_train_step_bench returns: one JSON line, n_gpus = 2 (round 4 raised NameError
+    here, reading a local of another function)."""
+    import argparse
+    args = argparse.Namespace(batch=4, steps=2, warmup=1, dtype="bf16", no_cpu_baseline=True)
+
+    class Lib:
+        @staticmethod
+        def msda_pick_variant(*a):
+            return 0
+
+        @staticmethod
+        def msda_variant_name(v):
+            return b"quad"
+
+    kern = {"enc_bwd_fused": {"ms": 1.0, "n": 2, "dims": (4, 22223, 8, 32, 4, 22223, 4), "code": 2, "bwd": True, "variant": "cell+patch",
+                              "bytes": 409_600_000, "operand_bytes": 300_000_000}}
+    dp = {"graphed": True, "overlap": False, "dp_group": True}
+    bench.emit(args, 2, 0.08, kern, Lib, workload_text="train_step: test", cpu_calls=None,
+               parallelism=bench.parallelism_text(2, dp["graphed"], dp["overlap"], dp["dp_group"]),
+               host_routes={"residual_gradient_in_gemm": "on", "one_launch_box_head": "off (self-check failed: test)"})
+    line = json.loads(capsys.readouterr().out.strip())
+    assert line["n_gpus"] == 2 and line["value"] == pytest.approx(4 * 2 * 2 / 0.08)
+    assert line["config"]["parallelism"].startswith("dp2 (one flat")
+    assert line["config"]["host_routes"]["one_launch_box_head"].startswith("off")
+    assert "cpu_baseline" not in line and line["roofline"]["frac"] == pytest.approx(409.6e6 / 0.5e-3 / 1e9 / 8000, rel=1e-3)
+
+
+def test_traffic_table_is_the_newest_committed_one_and_keys_must_match(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    assert bench.newest_traffic_file() is None
+    row = {"fetch_bytes": 100.0, "write_bytes": 50.0, "launches": 5}
+    for rnd, keys in (("r03", ["msda:cell_backward_kernel+geometry", "msda:patch_dest_kernel"]),
+                      ("r05", ["msda:cell_backward_kernel+geometry", "msda:patch_dest_kernel", "b0:cell_backward_kernel"])):
+        json.dump({k: row for k in keys}, open(tmp_path / "profiles" / f"{rnd}_final_traffic.json", "w"))
+    assert os.path.basename(bench.newest_traffic_file()) == "r05_final_traffic.json"
+    t = json.load(open(bench.newest_traffic_file()))
+    assert bench.traffic_from_table(t, "enc_bwd_fused") == 300
+    assert bench.traffic_from_table(t, "enc_bwd") is None            # b0:patch_dest_kernel missing: null, not a stale number
+    assert bench.traffic_from_table(t, "dec300_fwd") is None
+
+
+def test_counter_summary_labels():
+    s = pmc_final_summary.short
+    assert s("void rlipv2::cell_backward_kernel<0, 0>(rlipv2::PatchPlan, ...)") == "cell_backward_kernel"
+    assert s("void rlipv2::cell_backward_kernel<2, 0>(...)") == "cell_backward_kernel+geometry"
+    assert s("void rlipv2::cell_backward_kernel<4, 2>(...)") == "cell_backward_kernel+geometry"
+    assert s("void rlipv2::patch_dest_kernel<__hip_bfloat16, 2>(...)") == "patch_dest_kernel"
+    assert s("void rlipv2::quad_backward_shared_kernel<__hip_bfloat16, 2>(...)") == "quad_backward_shared_kernel+geometry"
+    assert s("void rlipv2::quad_forward_fused_kernel<...>(...)") == "quad_forward_fused_kernel"
+    assert s("Cijk_Alik_Bljk_BBS_BH_Bias_HA_S_SAV_UserArgs_MT128x128x64") is None
+
+
+def test_route_verdicts():
+    """routes.compare: the tolerances the self-check applies (loss 1e-3, whole gradient max(2 %, 4 x step noise), every
+    parameter 5 % of its norm + 1e-3 of the largest)"""
+    g = torch.Generator().manual_seed(0)
+    ref = [torch.randn(300, generator=g), torch.randn(40, 7, generator=g) * 1e-3, torch.randn(5, generator=g)]
+    same = [t + 1e-3 * torch.randn(t.shape, generator=g) * t.abs().mean() for t in ref]
+    assert routes.compare(1.0, same, 1.0, ref) is None
+    assert "loss" in routes.compare(1.01, same, 1.0, ref)
+    assert routes.compare(float("nan"), same, 1.0, ref) == "non-finite loss"
+    lost = [ref[0] * 0.5, ref[1], ref[2]]                             # half of one contribution dropped
+    assert "whole gradient" in routes.compare(1.0, lost, 1.0, ref)
+    small = [ref[0], ref[1], ref[2] * 0.0]                             # a small parameter's gradient lost: whole gradient fine?
+    why = routes.compare(1.0, small, 1.0, ref)
+    assert why is not None
+    nan = [ref[0], ref[1] * float("nan"), ref[2]]
+    assert routes.compare(1.0, nan, 1.0, ref) == "non-finite gradient"
+    # a noisy step (MIOpen's non-deterministic convolution) widens the whole-gradient bar, nothing else
+    noisy = [t + 0.03 * torch.randn(t.shape, generator=g) * t.abs().mean() for t in ref]
+    assert routes.compare(1.0, noisy, 1.0, ref, noise=0.0) is not None
+    assert routes.compare(1.0, noisy, 1.0, ref, noise=0.02) is None
+
+
+def test_routes_are_off_in_the_package_and_stay_off_without_a_gpu():
+    from rlipv2_amd import train
+    assert routes.state() == {"residual_gradient_in_gemm": False, "one_launch_box_head": False}
+    samples, text, targets = train.synthetic_batch(1, 32, 32, n_obj=3, n_verb=2, triplets=1, device="cpu")
+    verdict = routes.validate(None, None, (samples, text, targets))
+    assert all(v.startswith("off (not applicable") for v in verdict.values()) and not any(routes.state().values())

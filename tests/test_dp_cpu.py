@@ -344,3 +344,30 @@ def test_sum_route_two_ranks():
     for a, b, x, y in zip(v0, v1, g0, g1):
         assert torch.equal(a, b)
         torch.testing.assert_close(a, x + y)
+
+
+def test_one_gradient_schedule_for_captured_and_eager_steps():
+    """Advisor finding of round 4: GraphedStep falls back to the flat schedule when the group's collectives cannot be captured
+    (anything but RCCL), the cache's eager step must then run the flat schedule too -- a rank replaying a capture and a rank
+    on the eager path would otherwise issue different collectives.  Resolved once (train.effective_overlap) and checked at
+    every capture."""
+    from rlipv2_amd import train
+
+    class Sync:
+        group = None
+        planned = False
+        params = []
+
+    assert train.effective_overlap(True, None) is False
+    assert train.effective_overlap(False, Sync()) is False
+    assert train.effective_overlap(True, Sync()) is False            # no process group here: nothing can be captured
+    cache = train.GraphedStepCache(torch.nn.Linear(2, 2), None, Sync(), overlap=True)
+    assert cache.overlap is False and cache.eager.overlap is False
+
+    class Mismatch:
+        overlap = True
+
+    cache = train.GraphedStepCache(torch.nn.Linear(2, 2), None, Sync(), overlap=False, factory=lambda b: Mismatch())
+    cache.bucket = staticmethod(lambda b: "k")
+    with pytest.raises(RuntimeError, match="disagree on the gradient schedule"):
+        cache.get(None)

@@ -90,6 +90,7 @@ def test_residual_gradient_accumulated_by_the_ffn_gemm_logic():
     linear.expand_gemm = lambda a, b, bias=None, mask=None, relu=False: (a @ b.t()) * (mask > 0)
     linear._ffn_block_ok = lambda *a: True
     norm.AddLayerNormFunction = TorchAddLayerNorm
+    linear.residual_gradient_in_gemm = True                    # (off in the package until routes.validate has passed on a GPU)
     try:
         torch.manual_seed(0)
         l1, l2, ln = torch.nn.Linear(16, 64), torch.nn.Linear(64, 16), torch.nn.LayerNorm(16)
@@ -117,6 +118,7 @@ def test_residual_gradient_accumulated_by_the_ffn_gemm_logic():
         assert seen["gin"][0] is None
     finally:
         linear.linear_wgrad, linear.expand_gemm, linear._ffn_block_ok, norm.AddLayerNormFunction = saved
+        linear.residual_gradient_in_gemm = False
 
 
 def test_linked_attention_block_accumulates_into_the_layernorm_gradient():
@@ -215,6 +217,56 @@ def test_shared_input_of_several_linears_is_summed_by_their_gemms():
             else:
                 outs = [m(src) for m in lins]
             sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+            res.append([x.grad.clone()] + [p.grad.clone() for m in lins for p in m.parameters()])
+        for a, b in zip(*res):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    finally:
+        linear.linear_wgrad = saved
+
+
+@pytest.mark.parametrize("case", ["noncontiguous_dy", "unusable_accumulator"])
+def test_shared_input_never_mixes_in_place_and_returned_gradients(case):
+    """Advisor finding of round 4: once a link holds an accumulator, a consumer that returned its input gradient the normal way
+    made autograd sum out of place, and everything later nodes added into the (now stale) accumulator was lost without an
+    error.  `noncontiguous_dy`: one of four consumers is fed a transposed gradient -- it must still accumulate in place.
+    `unusable_accumulator`: a consumer whose accumulator cannot be used (dtype differs) breaks the link, and every later node
+    returns its gradient normally.  Either way the sum equals plain autograd's."""
+    from rlipv2_amd import norm
+    saved = linear.linear_wgrad
+    linear.linear_wgrad = lambda dy, x, with_bias=True, out_dtype=None: (
+        dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1]).sum(0))
+    try:
+        torch.manual_seed(3)
+        lins = [torch.nn.Linear(12, 12) for _ in range(4)]
+        x0 = torch.randn(5, 5, 12)
+        ws = [torch.randn(5, 5, 12) for _ in lins]
+        res = []
+        for linked in (True, False):
+            for m in lins:
+                m.weight.grad = m.bias.grad = None
+            x = x0.clone().requires_grad_(True)
+            src = torch.tanh(x)
+            link = None
+            if linked:
+                link = norm.GradLink()
+                link.first_creates = True
+                xa = linear._Alias.apply(src, link)
+                outs = [linear.TokenLinearFunction.apply(xa, m.weight, m.bias, False, link) for m in lins]
+            else:
+                outs = [m(src) for m in lins]
+            terms = [(o * w).sum() for o, w in zip(outs, ws)]
+            if case == "noncontiguous_dy":
+                # consumer 1's incoming gradient is a transposed view (runs second-to-last in the backward)
+                terms[1] = (outs[1].transpose(0, 1) * ws[1].transpose(0, 1).contiguous()).sum()
+            if case == "unusable_accumulator" and linked:
+                # swap the accumulator's dtype just before consumer 1 runs (hook on consumer 2's output gradient)
+                def spoil(g):
+                    link.dx = link.dx.double()
+                    return g
+                outs[2].register_hook(spoil)
+            sum(terms).backward()
+            if linked and case == "unusable_accumulator":
+                assert link.broken
             res.append([x.grad.clone()] + [p.grad.clone() for m in lins for p in m.parameters()])
         for a, b in zip(*res):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)

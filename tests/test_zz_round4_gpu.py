@@ -146,7 +146,7 @@ def test_linked_encoder_layer_equals_the_unlinked_nodes_bf16():
             y.backward(gy)
             return [y.detach().float(), x.grad.float(), pos.grad.float()] + [p.grad.float() for p in params], kinds
         finally:
-            linear.residual_gradient_in_gemm = True
+            linear.residual_gradient_in_gemm = False            # (the package default: routes.validate switches it on)
 
     linked, kinds = run(True)
     plain, kinds_plain = run(False)
@@ -184,7 +184,7 @@ def test_gradient_links_change_nothing_in_the_train_step_bf16():
             loss.backward()
             got = (float(loss), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
         finally:
-            linear.residual_gradient_in_gemm = True
+            linear.residual_gradient_in_gemm = False            # (the package default: routes.validate switches it on)
         if linked and True in res:                               # the linked step again: how far two runs of it are apart
             noise = max(float((got[1][n] - res[True][1][n]).norm() / res[True][1][n].norm().clamp_min(1e-12)) for n in got[1])
         res[linked] = got
@@ -228,7 +228,7 @@ def test_residual_gradient_in_the_ffn_gemm_matches_the_unlinked_nodes():
             y.backward(dy)
             return [y.detach().float(), x.grad.float()] + [p.grad.float() for p in params], names
         finally:
-            linear.residual_gradient_in_gemm = True
+            linear.residual_gradient_in_gemm = False            # (the package default: routes.validate switches it on)
 
     linked, names = run(True)
     plain, _ = run(False)
@@ -282,6 +282,14 @@ def test_box_head_equals_the_op_sequence():
     """decoder.box_head (one launch of the refinement kernel forward, sigmoid's backward) against
     sigmoid(delta + inverse_sigmoid(ref)) as PyTorch ops: values within 1e-6, gradients equal after the cast back."""
     from rlipv2_amd.blocks import inverse_sigmoid
+    decoder.one_launch_box_head = True
+    try:
+        _box_head_cases(inverse_sigmoid)
+    finally:
+        decoder.one_launch_box_head = False                 # (the package default: routes.validate switches it on)
+
+
+def _box_head_cases(inverse_sigmoid):
     for dtype in (torch.bfloat16, torch.float32):
         g = torch.Generator().manual_seed(5)
         N, n = 3, 37

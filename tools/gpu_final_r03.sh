@@ -13,7 +13,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/b0_$C -o p -- python3 $GRAFT_REPO_ROOT/tools/bwd_once.py auto bf16 init 5 > $OUT/log_b0bwd_$C.txt 2>&1 )
 done
 cd $GRAFT_REPO_ROOT
-python3 tools/pmc_final_summary.py $OUT > $OUT/traffic_summary.txt 2>&1
+# (the table is also copied to gpurun_out/<tag>_final_traffic.json: commit it as profiles/r0N_final_traffic.json -- the newest
+#  such file is what bench.py's roofline.traffic quotes)
+python3 tools/pmc_final_summary.py $OUT $GRAFT_REPO_ROOT/gpurun_out/$(basename $TAG)_final_traffic.json > $OUT/traffic_summary.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt

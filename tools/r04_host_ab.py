@@ -68,6 +68,7 @@ def product():
     blocks.cache_padding_free = True
     parseda.batched_heads = True
     decoder.share_box_deltas = True
+    decoder.one_launch_box_head = True
     linear.residual_gradient_in_gemm = True
 
 
@@ -85,6 +86,7 @@ if __name__ == "__main__":
     measure("reference points recomputed", off((encoder, "cache_reference_points")))
     measure("sine encodings recomputed", off((blocks, "cache_padding_free")))
     measure("heads per decoder layer", off((parseda, "batched_heads")))
-    measure("box-head MLPs run twice, op-sequence box head", off((decoder, "share_box_deltas")))
+    measure("box-head MLPs run twice", off((decoder, "share_box_deltas")))
+    measure("op-sequence box head", off((decoder, "one_launch_box_head")))
     measure("FFN residual gradient summed by autograd", off((linear, "residual_gradient_in_gemm")))
     measure("product again (box-to-box noise)", product)

@@ -48,7 +48,12 @@ EXPORTS = (
     "hoi_assign_batch",
 )
 
+# include/rlipv2_msda_cpu.h (librlipv2_msda_cpu.so: the CPU twins, no HIP)
+CPU_LIB_PATH = os.path.join(_HERE, "librlipv2_msda_cpu.so")
+CPU_EXPORTS = ("msda_forward_cpu", "msda_backward_cpu", "msda_cpu_strerror", "msda_cpu_abi_version")
+
 _lib = None
+_cpu_lib = None
 
 
 def build(verbose: bool = False) -> str:
@@ -159,6 +164,24 @@ def lib() -> ctypes.CDLL:
     L.hoi_assign_batch.argtypes = [vp, i, i, i, ip, vp, vp, lg]
     L.hoi_assign_batch.restype = lg
     _lib = L
+    return L
+
+
+def cpu_lib() -> ctypes.CDLL:
+    """librlipv2_msda_cpu.so: serves CPU tensors only (a CUDA tensor never reaches it; `lib()` above has no fallback)."""
+    global _cpu_lib
+    if _cpu_lib is not None:
+        return _cpu_lib
+    if not os.path.exists(CPU_LIB_PATH):
+        raise RuntimeError(f"{CPU_LIB_PATH} is missing: run `make -C rlipv2_amd/csrc` (or __graft_entry__.build())")
+    L = ctypes.CDLL(CPU_LIB_PATH)
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    L.msda_forward_cpu.argtypes = [i, vp, vp, vp, vp, vp, *([i] * 7), vp]
+    L.msda_backward_cpu.argtypes = [i, vp, vp, vp, vp, vp, vp, *([i] * 7), vp, vp, vp]
+    L.msda_forward_cpu.restype = L.msda_backward_cpu.restype = L.msda_cpu_abi_version.restype = i
+    L.msda_cpu_strerror.argtypes = [i]
+    L.msda_cpu_strerror.restype = ctypes.c_char_p
+    _cpu_lib = L
     return L
 
 

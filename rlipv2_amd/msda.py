@@ -12,8 +12,11 @@ Drop-in surface (same names, argument order and error behaviour as the reference
 Differences, all additive: bfloat16 ``value`` is accepted (sampling locations and attention
 weights are then float32, or bfloat16 which is upcast; gradients come back in the inputs'
 dtypes); a failed kernel launch raises instead of being printf()'d
-(ms_deform_im2col_cuda.cuh:948-952).  CPU tensors raise "Not implemented on the CPU" exactly as
-the reference does (models/ops/src/ms_deform_attn.h:54) -- there is no fallback path.
+(ms_deform_im2col_cuda.cuh:948-952); CPU tensors are served by the CPU twins of the two entry points
+(include/rlipv2_msda_cpu.h, csrc/msda_cpu.cpp: plain C++ / OpenMP) where the reference raises
+"Not implemented on the CPU" (models/ops/src/ms_deform_attn.h:54) and its models fall back to
+``ms_deform_attn_core_pytorch``.  That is a dispatch on the tensors' device, not a fallback: CUDA tensors only
+ever run the HIP library, and a missing HIP library raises.
 """
 from __future__ import annotations
 
@@ -48,12 +51,10 @@ def set_variant(forward: str, backward: str = None) -> None:
 def _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, extra=()):
     named = [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
              ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), *extra]
-    if not value.is_cuda:
-        raise RuntimeError("Not implemented on the CPU")          # ms_deform_attn.h:54
     for name, t in named:
         if not t.is_contiguous():
             raise RuntimeError(f"{name} tensor has to be contiguous")   # ms_deform_attn_cuda.cu:28-32
-        if not t.is_cuda:
+        if value.is_cuda and not t.is_cuda:
             raise RuntimeError(f"{name} must be a CUDA tensor")         # ms_deform_attn_cuda.cu:34-38
         if t.device != value.device:
             raise RuntimeError(f"{name} is on {t.device}, value is on {value.device}")
@@ -117,9 +118,41 @@ def _raise(status):
     raise RuntimeError(f"ms_deform_attn: {_lib.strerror(status)} (status {status})")
 
 
+def _cpu_call(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output=None):
+    """CPU tensors: the CPU twins of the two entry points (include/rlipv2_msda_cpu.h, csrc/msda_cpu.cpp).
+    float64 runs in float64, everything else (float32, bfloat16) in float32; results come back in the operands' dtypes,
+    like the GPU path.  Only ever reached with CPU tensors."""
+    L = _lib.cpu_lib()
+    N, S, M, D, nL, Lq, P = _dims(value, spatial_shapes, sampling_loc)
+    work = torch.float64 if value.dtype == torch.float64 else torch.float32
+    code = 1 if work == torch.float64 else 0
+    v, loc, aw = (t if t.dtype == work else t.to(work) for t in (value, sampling_loc, attn_weight))
+    if grad_output is None:
+        out = torch.empty((N, Lq, M * D), dtype=work)
+        st = L.msda_forward_cpu(code, v.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), loc.data_ptr(),
+                                aw.data_ptr(), N, S, M, D, nL, Lq, P, out.data_ptr())
+        res = [out.to(value.dtype)]
+    else:
+        go = grad_output if grad_output.dtype == work else grad_output.to(work)
+        g_value, g_loc, g_aw = torch.empty(value.shape, dtype=work), torch.empty(loc.shape, dtype=work), torch.empty(aw.shape, dtype=work)
+        st = L.msda_backward_cpu(code, v.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), loc.data_ptr(),
+                                 aw.data_ptr(), go.data_ptr(), N, S, M, D, nL, Lq, P, g_value.data_ptr(), g_loc.data_ptr(),
+                                 g_aw.data_ptr())
+        res = [g_value.to(value.dtype), g_loc.to(sampling_loc.dtype), g_aw.to(attn_weight.dtype)]
+    if st:
+        raise RuntimeError(f"ms_deform_attn (CPU): {L.msda_cpu_strerror(st).decode()} (status {st})")
+    return res
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """Reference: ms_deform_attn_forward (vision.cpp:14) -> out [N, Lq, M*D]."""
     _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if not value.is_cuda:
+        step = min(value.shape[0], int(im2col_step))                                          # ms_deform_attn_cuda.cu:50-52
+        if step <= 0 or value.shape[0] % step != 0:
+            if value.shape[0] != 0:
+                raise RuntimeError("ms_deform_attn: batch must divide im2col_step: batch % min(batch, im2col_step) != 0")
+        return _cpu_call(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)[0]
     L = _lib.lib()
     N, S, M, D, nL, Lq, P = _dims(value, spatial_shapes, sampling_loc)
     st = L.msda_check_im2col_step(N, int(im2col_step))
@@ -158,6 +191,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     value's dtype."""
     _check_inputs(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                   extra=(("grad_output", grad_output),))
+    if not value.is_cuda:
+        return _cpu_call(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output)
     L = _lib.lib()
     N, S, M, D, nL, Lq, P = _dims(value, spatial_shapes, sampling_loc)
     st = L.msda_check_im2col_step(N, int(im2col_step))

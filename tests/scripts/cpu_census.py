@@ -14,7 +14,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import test_modules_cpu as T  # noqa: E402
-from oracle_function import OracleMSDeformAttnFunction  # noqa: E402
 
 from rlipv2_amd import criterion as MC  # noqa: E402
 from rlipv2_amd import deform_attn, parseda  # noqa: E402
@@ -37,7 +36,6 @@ VIEWS = {"aten::view", "aten::reshape", "aten::permute", "aten::transpose", "ate
 
 def main():
     dec = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    deform_attn.msda_function = OracleMSDeformAttnFunction
     g = T.load("parseda")
     args = parseda.default_args(num_queries=20, enc_layers=2 * dec, dec_layers=dec, dim_feedforward=512, pseudo_verb=True)      # (one language state per fusion = per decoder layer, as the scripts have it)
     bb = T._FeatureBackbone((32, 64, 128))

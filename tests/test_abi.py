@@ -13,9 +13,12 @@ from rlipv2_amd import _lib, msda
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
+def _declared_functions(cpu=False):
+    """functions declared by include/*.h: the HIP library's headers, or (cpu=True) the CPU twins' header"""
     names = []
     for header in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if (header == "rlipv2_msda_cpu.h") != cpu:
+            continue
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names += re.findall(r"\b((?:msda|linear|add_layernorm|adamw|alif_attention|add_relu|affine_relu|groupnorm_tokens|dab|hoi_assign)_[a-z0-9_]+|add_relu_bf16)\s*\(", text)
@@ -28,6 +31,23 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.EXPORTS), (declared, _lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
+
+
+def test_cpu_library_exports_every_declared_symbol():
+    L = _lib.cpu_lib()
+    declared = _declared_functions(cpu=True)
+    assert set(declared) == set(_lib.CPU_EXPORTS), (declared, _lib.CPU_EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/rlipv2_msda_cpu.h but not exported"
+    assert L.msda_cpu_abi_version() == 1 and L.msda_cpu_strerror(0) == b"ok"
+    # host-side argument checks: bad dtype / dimensions / null operands are refused before anything is touched
+    assert L.msda_forward_cpu(7, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, None) != 0
+    shapes = (ctypes.c_int64 * 2)(2, 2)
+    starts = (ctypes.c_int64 * 1)(0)
+    assert L.msda_forward_cpu(0, None, shapes, starts, None, None, 1, 4, 1, 1, 1, 1, 1, None) == -2
+    assert L.msda_forward_cpu(0, None, shapes, starts, None, None, 1, 4, 0, 1, 1, 1, 1, None) == -3
+    assert L.msda_forward_cpu(0, None, shapes, starts, None, None, 0, 4, 1, 1, 1, 1, 1, None) == 0          # empty batch
+    assert L.msda_forward_cpu(0, None, shapes, starts, None, None, 0, 3, 1, 1, 1, 1, 1, None) == -4         # level outside value
 
 
 def test_abi_version_and_strerror():
@@ -86,15 +106,28 @@ def _cpu_inputs():
     return value, shapes, starts, loc, aw
 
 
-def test_cpu_tensors_raise_like_the_reference():
-    # reference: models/ops/src/ms_deform_attn.h:54 AT_ERROR("Not implemented on the CPU")
+def test_cpu_tensors_take_the_cpu_twins():
+    """Reference: CPU tensors raise "Not implemented on the CPU" (models/ops/src/ms_deform_attn.h:54) and its models use
+    ms_deform_attn_core_pytorch instead; SURVEY.md 8b asks the drop-in to accept CPU tensors.  Here they are served by the CPU
+    twins (include/rlipv2_msda_cpu.h); values against the goldens: tests/test_msda_cpu.py.  Mixed devices still raise."""
     value, shapes, starts, loc, aw = _cpu_inputs()
-    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
-        msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64)
-    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
-        msda.MSDeformAttnFunction.apply(value, shapes, starts, loc, aw, 64)
-    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
-        msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, torch.rand(1, 2, 4), 64)
+    out = msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64)
+    assert out.shape == (1, 2, 4) and not out.is_cuda
+    assert msda.MSDeformAttnFunction.apply(value, shapes, starts, loc, aw, 64).shape == (1, 2, 4)
+    gv, gl, ga = msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, torch.rand(1, 2, 4), 64)
+    assert gv.shape == value.shape and gl.shape == loc.shape and ga.shape == aw.shape
+
+
+def test_cuda_tensors_never_reach_the_cpu_twins(monkeypatch):
+    """the CPU library serves CPU tensors only: with the HIP library missing a CUDA call raises (no fallback), it does not
+    quietly compute on the host"""
+    src = open(os.path.join(ROOT, "rlipv2_amd", "msda.py")).read()
+    assert src.count("_cpu_call(") == 3                      # the definition + one dispatch per entry point ...
+    assert src.count("if not value.is_cuda:\n") >= 2          # ... each behind the device test
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librlipv2_msda.so")
+    with pytest.raises(RuntimeError, match="no CPU / PyTorch fallback"):
+        _lib.lib()
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -156,8 +189,7 @@ def test_compat_shim_registers_reference_import_paths():
             assert f.MSDeformAttnFunction is msda.MSDeformAttnFunction
             m = importlib.import_module(root + ".modules")
             assert m.MSDeformAttn is deform_attn.MSDeformAttn
-        with pytest.raises(RuntimeError, match="Not implemented on the CPU"):     # ms_deform_attn.h:54
-            MSDA.ms_deform_attn_forward(*_cpu_inputs(), 64)
+        assert MSDA.ms_deform_attn_forward(*_cpu_inputs(), 64).shape == (1, 2, 4)     # CPU tensors: the CPU twins
     finally:
         for k in [k for k in sys.modules if k == "MultiScaleDeformableAttention" or k.startswith("models")]:
             del sys.modules[k]

@@ -20,10 +20,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 
 def _build():
-    from oracle_function import OracleMSDeformAttnFunction
-
-    from rlipv2_amd import deform_attn, parseda, train
-    deform_attn.msda_function = OracleMSDeformAttnFunction
+    from rlipv2_amd import parseda, train          # (the op runs on the product's CPU arm, csrc/msda_cpu.cpp)
     args = parseda.default_args(num_queries=12, enc_layers=4, dec_layers=2, dim_feedforward=128, pseudo_verb=False)
     torch.manual_seed(1234)            # identical replicas in every process
     model, crit = train.build_training(args, device="cpu", with_text_encoder=False)

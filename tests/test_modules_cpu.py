@@ -1,6 +1,6 @@
 """CPU tests of the host-side modules against goldens generated from the imported reference
-(tests/golden/make_model_golden.py).  The HIP op is replaced by the oracle-backed autograd function
-(tests/oracle_function.py): what is checked here is the module logic -- projections, softmax,
+(tests/golden/make_model_golden.py).  The op runs on the product's CPU arm (csrc/msda_cpu.cpp) and, in a second pass, on the
+oracle-backed autograd function (tests/oracle_function.py); what is checked here is the module logic -- projections, softmax,
 location arithmetic, ALIF fusion, masks and their quirks, decoder box refinement, the two-phase
 model protocol and state_dict names.  The same goldens are re-run on the GPU with the real HIP
 op in tests/test_modules_gpu.py.
@@ -25,9 +25,16 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PYR = [(8, 10), (4, 5), (2, 3), (1, 2)]
 
 
-@pytest.fixture(autouse=True)
-def _oracle_op(monkeypatch):
-    monkeypatch.setattr(deform_attn, "msda_function", OracleMSDeformAttnFunction)
+@pytest.fixture(autouse=True, params=["product_cpu_arm", "oracle_op"])
+def _op(request, monkeypatch):
+    """Every test runs twice: with the PRODUCT's own op on CPU tensors (the CPU twins of the C ABI, csrc/msda_cpu.cpp -- the
+    model end to end on product code, BASELINE config 1) and with the oracle-backed autograd function standing in for the
+    op (which isolates the module logic from the op)."""
+    if request.param == "oracle_op":
+        monkeypatch.setattr(deform_attn, "msda_function", OracleMSDeformAttnFunction)
+    else:
+        from rlipv2_amd import msda
+        assert deform_attn.msda_function is msda.MSDeformAttnFunction
 
 
 def load(name):
@@ -686,11 +693,8 @@ def test_padding_free_hint_changes_nothing_but_the_work():
     """NestedTensor.no_padding (all masks False, told by the host): cached position encodings, valid ratios = 1 and reference
     points from the shape alone, no value masking -- outputs and gradients must equal the run that derives all of it from the
     masks, bit for bit, also on the second call (the cached one)."""
-    from oracle_function import OracleMSDeformAttnFunction
 
     from rlipv2_amd import train
-    old = deform_attn.msda_function
-    deform_attn.msda_function = OracleMSDeformAttnFunction
     try:
         args = parseda.default_args(num_queries=12, enc_layers=2, dec_layers=1, dim_feedforward=128, pseudo_verb=False)
         torch.manual_seed(3)
@@ -713,7 +717,7 @@ def test_padding_free_hint_changes_nothing_but_the_work():
             for a, b in zip(res[0], other):
                 assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
     finally:
-        deform_attn.msda_function = old
+        pass
 
 
 def test_box_format_conversion_equals_the_unbind_form():
@@ -741,7 +745,6 @@ def test_host_glue_operator_count_does_not_creep_back():
     there.  Round 4 took ~8 % of them out on this proxy (small model, padded batch, CPU twins of the fused kernels:
     2 407 -> 2 235 in tests/scripts/cpu_census.py's count); this pins the count of one forward + criterion + backward so that
     a per-layer loop, a select on a gradient-carrying tensor or a recomputed constant shows up as a failing test."""
-    from oracle_function import OracleMSDeformAttnFunction
     from torch.utils._python_dispatch import TorchDispatchMode
 
     from rlipv2_amd import train
@@ -758,8 +761,6 @@ def test_host_glue_operator_count_does_not_creep_back():
                 Count.n += 1
             return func(*args, **(kwargs or {}))
 
-    old = deform_attn.msda_function
-    deform_attn.msda_function = OracleMSDeformAttnFunction
     try:
         args = parseda.default_args(num_queries=12, enc_layers=6, dec_layers=3, dim_feedforward=128, pseudo_verb=False)
         torch.manual_seed(0)
@@ -775,7 +776,7 @@ def test_host_glue_operator_count_does_not_creep_back():
             loss = crit.weighted_sum(crit(step(samples, text, targets), targets))
             loss.backward()
     finally:
-        deform_attn.msda_function = old
+        pass
     assert Count.n <= BUDGET, f"{Count.n} computing operators per step on the CPU proxy (budget {BUDGET})"
 
 
@@ -865,13 +866,10 @@ def test_full_parseda_with_linked_gradient_accumulation_matches_reference():
 def test_ab_switches_of_the_host_restructures_compute_the_same_function(switch):
     """tools/r04_host_ab.py times the train step with each of round 4's host-side restructures switched off; both sides of every
     switch must be the same function (outputs and gradients), or the A/B would compare different models."""
-    from oracle_function import OracleMSDeformAttnFunction
 
     from rlipv2_amd import train
     mod = {"batched_heads": parseda, "share_box_deltas": decoder, "cache_padding_free": blocks,
            "cache_reference_points": encoder}[switch]
-    old = deform_attn.msda_function
-    deform_attn.msda_function = OracleMSDeformAttnFunction
     try:
         args = parseda.default_args(num_queries=12, enc_layers=2, dec_layers=1, dim_feedforward=128, pseudo_verb=False)
         torch.manual_seed(3)
@@ -895,4 +893,4 @@ def test_ab_switches_of_the_host_restructures_compute_the_same_function(switch):
             torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
     finally:
         setattr(mod, switch, True)
-        deform_attn.msda_function = old
+        pass

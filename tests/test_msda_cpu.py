@@ -1,0 +1,134 @@
+"""The product's CPU arm of the op (include/rlipv2_msda_cpu.h, rlipv2_amd/csrc/msda_cpu.cpp, dispatched by rlipv2_amd/msda.py for
+CPU tensors) against the reference-generated goldens (tests/golden/make_msda_golden.py: the reference's own
+`ms_deform_attn_core_pytorch` + autograd, models/ops/functions/ms_deform_attn_func.py:45-65).  The oracle is not involved:
+this is product code checked against the reference's vectors directly.  Tolerances as for the oracle: float64 -> allclose
+defaults (the reference's bar, models/ops/test.py:44), float32 -> rtol 1e-4 / 1e-5 x max (reference bar 1e-2 / 1e-3, test.py:60)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import boundary_samples, kink_samples, load_golden
+from rlipv2_amd import _lib, msda
+from rlipv2_amd.msda import MSDeformAttnFunction
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tensors(g, dtype):
+    return (torch.from_numpy(g["value"]).to(dtype), torch.from_numpy(g["shapes"]), torch.from_numpy(g["starts"]),
+            torch.from_numpy(g["loc"]).to(dtype), torch.from_numpy(g["aw"]).to(dtype))
+
+
+def test_exports_equal_the_header():
+    text = open(os.path.join(ROOT, "include", "rlipv2_msda_cpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(msda_[a-z_0-9]+)\s*\(", text))
+    assert declared == set(_lib.CPU_EXPORTS)
+    L = _lib.cpu_lib()
+    for name in _lib.CPU_EXPORTS:
+        getattr(L, name)
+    assert L.msda_cpu_abi_version() == 1
+
+
+def test_f64_matches_reference(msda_golden):
+    g = msda_golden
+    value, shapes, starts, loc, aw = _tensors(g, torch.float64)
+    value.requires_grad_(True), loc.requires_grad_(True), aw.requires_grad_(True)
+    out = MSDeformAttnFunction.apply(value, shapes, starts, loc, aw, 64)
+    np.testing.assert_allclose(out.detach().numpy(), g["out_f64"], rtol=1e-5, atol=1e-8)
+    out.backward(torch.from_numpy(g["grad_out"]).double())
+    np.testing.assert_allclose(value.grad.numpy(), g["g_value_f64"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(aw.grad.numpy(), g["g_aw_f64"], rtol=1e-5, atol=1e-8)
+    keep = ~boundary_samples(g)                  # conftest.boundary_samples: where the reference's two implementations differ
+    np.testing.assert_allclose(loc.grad.numpy()[keep], g["g_loc_f64"][keep], rtol=1e-5, atol=1e-8)
+
+
+def test_f32_matches_reference_f32(msda_golden):
+    g = msda_golden
+    value, shapes, starts, loc, aw = _tensors(g, torch.float32)
+    out = msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64)
+    gv, gl, ga = msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, torch.from_numpy(g["grad_out"]), 64)
+    scale = lambda ref: 1e-5 * max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(out.numpy(), g["out_f32"], rtol=1e-4, atol=scale(g["out_f32"]))
+    np.testing.assert_allclose(gv.numpy(), g["g_value_f32"], rtol=1e-4, atol=scale(g["g_value_f32"]))
+    keep = ~kink_samples(g)
+    np.testing.assert_allclose(gl.numpy()[keep], g["g_loc_f32"][keep], rtol=1e-4, atol=scale(g["g_loc_f32"]))
+    np.testing.assert_allclose(ga.numpy(), g["g_aw_f32"], rtol=1e-4, atol=scale(g["g_aw_f32"]))
+
+
+def test_reference_gradcheck_recipe_on_the_cpu():
+    """models/ops/test.py:64-86 (check_gradient_numerical), float64, the reference's shapes -- on the product's CPU op."""
+    torch.manual_seed(3)
+    N, M, D, Lq, L, P = 1, 2, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    for D in (2, 30, 32, 71):
+        value = (torch.rand(N, S, M, D, dtype=torch.float64) * 0.01).requires_grad_(True)
+        loc = torch.rand(N, Lq, M, L, P, 2, dtype=torch.float64).requires_grad_(True)
+        aw = torch.rand(N, Lq, M, L, P, dtype=torch.float64) + 1e-5
+        aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).requires_grad_(True)
+        assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, starts, loc, aw, 2))
+
+
+def test_bf16_cpu_tensors_are_widened():
+    g = load_golden("model_dec")
+    value, shapes, starts, loc, aw = _tensors(g, torch.float32)
+    vb = value.to(torch.bfloat16)
+    out = msda.ms_deform_attn_forward(vb, shapes, starts, loc, aw, 64)
+    ref = msda.ms_deform_attn_forward(vb.float(), shapes, starts, loc, aw, 64)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, ref.to(torch.bfloat16))
+    gv, gl, ga = msda.ms_deform_attn_backward(vb, shapes, starts, loc, aw, torch.from_numpy(g["grad_out"]).to(torch.bfloat16), 64)
+    assert gv.dtype == torch.bfloat16 and gl.dtype == torch.float32 and ga.dtype == torch.float32
+
+
+def test_results_do_not_depend_on_the_thread_count():
+    """every output element has one writer and a fixed summation order (backward: one task per (image, head, level))"""
+    g = load_golden("pyr_enc")
+    value, shapes, starts, loc, aw = _tensors(g, torch.float32)
+    go = torch.from_numpy(g["grad_out"])
+    omp = ctypes.CDLL("libgomp.so.1")
+    res = []
+    for n in (1, 5):
+        omp.omp_set_num_threads(n)
+        res.append([msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64),
+                    *msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, go, 64)])
+    omp.omp_set_num_threads(os.cpu_count() or 1)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_edge_cases():
+    """empty query set, empty batch, dropped samples (.cuh:285-288), NaN locations, value rows outside every level"""
+    shapes = torch.tensor([[4, 5]])
+    starts = torch.tensor([0])
+    value = torch.ones(1, 20, 1, 3)
+    aw = torch.ones(1, 1, 1, 1, 2)
+    loc = torch.tensor([[-0.5 / 5, 0.5], [0.5, 4.5 / 4]]).reshape(1, 1, 1, 1, 2, 2)        # w_im == -1 ; h_im == H
+    assert torch.all(msda.ms_deform_attn_forward(value, shapes, starts, loc, aw, 64) == 0)
+    gv, gl, ga = msda.ms_deform_attn_backward(value, shapes, starts, loc, aw, torch.ones(1, 1, 3), 64)
+    assert torch.all(gv == 0) and torch.all(gl == 0) and torch.all(ga == 0)
+    loc2 = torch.tensor([[0.0, 0.0], [1.0, 1.0]]).reshape(1, 1, 1, 1, 2, 2)                # image corners: weight 1/4 each
+    torch.testing.assert_close(msda.ms_deform_attn_forward(value, shapes, starts, loc2, aw, 64), torch.full((1, 1, 3), 0.5))
+    nan = torch.full((1, 1, 1, 1, 2, 2), float("nan"))
+    assert torch.all(msda.ms_deform_attn_forward(value, shapes, starts, nan, aw, 64) == 0)
+    # no queries / no images
+    out = msda.ms_deform_attn_forward(value, shapes, starts, torch.empty(1, 0, 1, 1, 2, 2), torch.empty(1, 0, 1, 1, 2), 64)
+    assert out.shape == (1, 0, 3)
+    out = msda.ms_deform_attn_forward(torch.empty(0, 20, 1, 3), shapes, starts, torch.empty(0, 4, 1, 1, 2, 2), torch.empty(0, 4, 1, 1, 2), 64)
+    assert out.shape == (0, 4, 3)
+    # S larger than the pyramid: the extra rows get a zero gradient; a level reaching outside value is refused
+    big = torch.ones(1, 25, 1, 3)
+    gv, _, _ = msda.ms_deform_attn_backward(big, shapes, starts, loc2, aw, torch.ones(1, 1, 3), 64)
+    assert torch.all(gv[:, 20:] == 0) and float(gv.sum()) == pytest.approx(2 * 3 * 0.25)
+    with pytest.raises(RuntimeError, match="does not lie inside"):
+        msda.ms_deform_attn_forward(torch.ones(1, 19, 1, 3), shapes, starts, loc2, aw, 64)
+    with pytest.raises(RuntimeError, match="im2col_step"):
+        msda.ms_deform_attn_forward(torch.ones(3, 20, 1, 3), shapes, starts, loc2.expand(3, -1, -1, -1, -1, -1).contiguous(),
+                                    aw.expand(3, -1, -1, -1, -1).contiguous(), 2)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        msda.ms_deform_attn_forward(value.transpose(1, 3), shapes, starts, loc2, aw, 64)

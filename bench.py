@@ -560,6 +560,8 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
         line["roofline"]["b0_signature_kernels"] = b0
     if host_routes is not None:
         line["config"]["host_routes"] = host_routes
+    if getattr(args, "overrides", None):
+        line["config"]["overrides"] = list(args.overrides)
     if step_roofline is not None and "error" in step_roofline:
         line["step_roofline"] = step_roofline
     elif step_roofline is not None:
@@ -595,6 +597,23 @@ def miopen_tuning_report():
         return f"recorded find-db, lookup only (rlipv2_amd/tuned/miopen, recorded for MIOpen {st['recorded_for']} = the loaded library)"
     return (f"library default: the recorded find-db is for MIOpen {st['recorded_for']}, the loaded library is {st['library']} "
             "-- MIOpen ignores it (expect ~2 ms/step of split-K workspace kernels)")
+
+
+def apply_overrides(overrides):
+    """`--set module.attr=value`: flip an existing bool / int switch of a rlipv2_amd module (A/B runs)."""
+    import importlib
+    done = {}
+    for item in overrides:
+        name, _, value = item.partition("=")
+        mod, _, attr = name.rpartition(".")
+        m = importlib.import_module("rlipv2_amd." + mod)
+        old = getattr(m, attr, None)
+        if not isinstance(old, (bool, int)) or value == "":
+            raise SystemExit(f"--set {item}: rlipv2_amd.{mod}.{attr} is not a bool / int switch")
+        new = (value.lower() in ("1", "true", "on")) if isinstance(old, bool) else int(value)
+        setattr(m, attr, new)
+        done[name] = new
+    return done
 
 
 def self_launch(n_gpus):
@@ -636,6 +655,9 @@ def main():
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE", dest="overrides",
+                    help="A/B runs: set a bool / int attribute of a rlipv2_amd module for this run, e.g. --set decoder.fused_glue=0 "
+                         "(the switches INTEGRATION.md lists; recorded in config.overrides)")
     ap.add_argument("--host-routes", default="auto", choices=["auto", "off", "on"],
                     help="GPU-only host routes of the train step (rlipv2_amd/routes.py): auto = switch on the ones that pass the "
                          "start-up self-check against the plain step (default), off / on = forced")
@@ -664,6 +686,7 @@ def main():
     if args.msda_fwd_cell:
         from rlipv2_amd import msda as _msda
         _msda.fused_forward_cell = True
+    apply_overrides(args.overrides)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -18,7 +18,6 @@ Parity-critical behaviours reproduced on purpose:
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 import torch.nn.functional as F
@@ -29,7 +28,7 @@ from .blocks import MultiBranchFusion
 GATINGS_SCALAR = ("VXAc", "Vtanh")
 
 # the fused HIP kernel of the attention core (csrc/alif_attention.hip); tests switch it off to compare both routes
-fused_attention = os.environ.get("RLIPV2_ALIF_FUSED", "1") != "0"
+fused_attention = True            # (attribute: tests and `bench.py --set alif.fused_attention=0` flip it for A/B runs)
 
 
 class AlifAttentionFunction(torch.autograd.Function):
@@ -340,7 +339,7 @@ class RLIPv2_VLFuse(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # sparse language layer (RoBERTa-base encoder layer, post-LN)
 # ------------------------------------------------------------------------------------------------
-fused_text_attention = os.environ.get("RLIPV2_TEXT_SDPA", "1") != "0"      # (A/B switch)
+fused_text_attention = True       # (attribute, see fused_attention)
 
 
 class _RobertaSelfAttention(nn.Module):

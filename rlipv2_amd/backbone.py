@@ -11,7 +11,6 @@ convolutions of the bf16 channels-last path run as token-major GEMMs with BatchN
 """
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.nn.functional as F
@@ -22,8 +21,8 @@ from .linear import token_linear
 
 # 1x1 convolutions of channels-last bf16 feature maps as token-major GEMMs (tests switch it off to compare)
 pointwise_as_gemm = True
-# relu(a + b) of the bottleneck tails as one HIP pass (A/B switch: RLIPV2_ADD_RELU=0)
-fused_add_relu = os.environ.get("RLIPV2_ADD_RELU", "1") != "0"
+# relu(a + b) of the bottleneck tails as one HIP pass (attribute; `bench.py --set backbone.fused_add_relu=0` for an A/B)
+fused_add_relu = True
 
 
 class FrozenBatchNorm2d(nn.Module):

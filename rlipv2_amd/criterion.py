@@ -16,7 +16,6 @@ the GIoU costs are reused; results are identical.
 """
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.distributed as dist
@@ -179,7 +178,7 @@ def build_weight_dict(dec_layers, obj_loss_coef=1.0, verb_loss_coef=1.0, bbox_lo
     return w
 
 
-native_assignment = os.environ.get("RLIPV2_NATIVE_LSA", "1") != "0"      # (A/B switch)
+native_assignment = True          # (attribute: tests compare with scipy by flipping it)
 
 
 class SetCriterionHOI(nn.Module):
@@ -351,7 +350,7 @@ class SetCriterionHOI(nn.Module):
     def assign(self, state, C_host=None):
         """Host side: the cost matrix comes over in ONE copy (`C_host`: the caller's host copy, e.g. a pinned staging
         buffer; else copied here), the K*bs assignment problems are solved in one native call (`hoi_assign_batch`,
-        include/rlipv2_matcher.h: scipy's algorithm and tie-breaking without Python in the loop; RLIPV2_NATIVE_LSA=0 or a
+        include/rlipv2_matcher.h: scipy's algorithm and tie-breaking without Python in the loop; `criterion.native_assignment = False` or a
         non-finite cost goes through scipy itself); returns int64 [2, K*n]: rows of the stacked predictions / columns of
         the concatenated targets."""
         K, bs, nq, sizes = state['K'], state['bs'], state['nq'], state['sizes']

@@ -5,7 +5,6 @@ and DABDeformableTransformerDecoderHOI (:1404-1552).  Parameter names match the 
 """
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.nn.functional as F
@@ -37,8 +36,8 @@ class _SplitRows(torch.autograd.Function):
         return torch.cat((ga, gb), 0), None
 
 
-direct_self_attention = os.environ.get("RLIPV2_DEC_SELF_ATTN", "1") != "0"      # (A/B switch)
-fused_glue = os.environ.get("RLIPV2_DEC_GLUE", "1") != "0"                     # (A/B switch)
+direct_self_attention = True
+fused_glue = True
 
 
 share_box_deltas = True       # the heads' MLPs run once per layer and are shared with the refinement (device-agnostic)

@@ -11,7 +11,6 @@ the weight gradients of the projections run on the MFMA kernel of csrc/token_gem
 from __future__ import annotations
 
 import math
-import os
 import warnings
 
 import torch
@@ -62,7 +61,7 @@ class _AdjacentCatN(torch.autograd.Function):
         return tuple(out)
 
 
-shared_parameter_storage = os.environ.get("RLIPV2_ADJACENT_CAT", "1") != "0"      # (A/B switch)
+shared_parameter_storage = True
 
 
 def adjacent_cat_n(owner, key, params):

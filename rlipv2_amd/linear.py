@@ -214,10 +214,12 @@ def _ffn_block_ok(x, linear1, linear2, norm):
     return (not torch.is_autocast_enabled() and torch.is_grad_enabled() and b1 is not None and b2 is not None
             and w1.requires_grad and w2.requires_grad and x.requires_grad and T >= EXPAND_MIN_ROWS
             and x.dtype == w1.dtype == w2.dtype and expand_supported(x, w1.shape[0]) and supported(x, w1)
-            and w2.shape[0] % 128 == 0 and w1.shape[0] % 128 == 0 and os.environ.get("RLIPV2_FUSED_FFN", "1") != "0"
+            and w2.shape[0] % 128 == 0 and w1.shape[0] % 128 == 0 and fused_ffn_enabled
             and len(norm.normalized_shape) == 1 and N.supported(x, x, norm.weight, norm.bias))
 
 
+fused_ffn_enabled = True          # (attributes: flipped by tests / `bench.py --set linear.fused_ffn_enabled=0` for A/B runs)
+row_vector_gemm = True
 # GPU-only route, OFF until rlipv2_amd/routes.validate() has compared it with the plain nodes on the caller's own step
 residual_gradient_in_gemm = False
 
@@ -273,7 +275,7 @@ def fused_ffn(x, linear1, linear2):
     if (not torch.is_autocast_enabled() and torch.is_grad_enabled() and b1 is not None and b2 is not None
             and w1.requires_grad and w2.requires_grad and T >= EXPAND_MIN_ROWS and x.dtype == w1.dtype == w2.dtype
             and expand_supported(x, w1.shape[0]) and supported(x, w1)
-            and w2.shape[0] % 128 == 0 and w1.shape[0] % 128 == 0 and os.environ.get("RLIPV2_FUSED_FFN", "1") != "0"):
+            and w2.shape[0] % 128 == 0 and w1.shape[0] % 128 == 0 and fused_ffn_enabled):
         return FusedFFNFunction.apply(x, w1, b1, w2, b2, None)
     return token_linear(token_linear(x, w1, b1, relu=True), w2, b2)
 
@@ -386,7 +388,7 @@ class AddRowVectorFunction(torch.autograd.Function):
 
 def add_row_vector(x, row):
     if x.is_cuda and x.dim() == 3 and torch.is_grad_enabled() and row.requires_grad and x.dtype == row.dtype \
-            and not torch.is_autocast_enabled() and os.environ.get("RLIPV2_ROWVEC", "1") != "0":
+            and not torch.is_autocast_enabled() and row_vector_gemm:
         return AddRowVectorFunction.apply(x, row)
     return x + row.view(1, 1, -1)
 

@@ -5,18 +5,17 @@ layers (:1346-1401), where the [4, 150..300, 256] tensors are launch-bound: 1 la
 forward, 2 instead of 3 backward (-0.17 ms per train step, A/B on one box).
 
 Other widths (the 768-channel text layers) and float32 autocast runs keep PyTorch's add + layer_norm.
-RLIPV2_LN_MIN_ROWS moves the row threshold (default 256).
+`norm.MIN_ROWS` is the row threshold (256).
 """
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.nn.functional as F
 
 from . import _lib, roofline
 
-MIN_ROWS = int(os.environ.get("RLIPV2_LN_MIN_ROWS", "256"))
+MIN_ROWS = 256
 enabled = True
 
 _workspaces = {}
@@ -111,7 +110,7 @@ def add_layer_norm(a, b, norm: torch.nn.LayerNorm):
 
 
 # ---- GroupNorm(32, 256) of the token-major feature pyramid (csrc/groupnorm_tokens.hip, include/rlipv2_groupnorm.h) ----
-level_group_norm_enabled = os.environ.get("RLIPV2_LEVEL_GN", "1") != "0"
+level_group_norm_enabled = True
 
 
 def _ptr_array(tensors):

@@ -17,7 +17,6 @@ Text: the reference tokenises label strings on the CPU and runs RoBERTa-base eve
 """
 from __future__ import annotations
 
-import os
 
 import math
 from types import SimpleNamespace
@@ -38,7 +37,8 @@ from .encoder import DeformableTransformerEncoderLayer, RLIPv2_DeformableTransfo
 
 
 # encode the label texts on a second HIP stream, concurrently with the backbone (RLIP_ParSeDA._encode)
-overlap_text_encoder = os.environ.get("RLIPV2_NO_TEXT_OVERLAP", "0") != "1"
+overlap_text_encoder = True
+text_encoder_first = False
 
 
 def default_args(**overrides):
@@ -368,7 +368,7 @@ class RLIP_ParSeDA(nn.Module):
             cur = torch.cuda.current_stream()
             side = self.__dict__.setdefault("_text_stream", torch.cuda.Stream(device=samples.tensors.device))
             fork = cur.record_event()
-        if 'fork' in locals() and os.environ.get("RLIPV2_TEXT_FIRST") == "1":      # (A/B switch: the round-1 issue order)
+        if 'fork' in locals() and text_encoder_first:      # (the round-1 issue order; attribute for A/B runs)
             side.wait_event(fork)
             with torch.cuda.stream(side):
                 encoded_text = tr._encode_text(text, samples.tensors.shape[0], samples.tensors.device)

@@ -133,6 +133,7 @@ class GraphedStep:
     backward graph from those."""
 
     _delivered_by = None          # weak reference to the GraphedStep whose static buffers the parameters' `.grad` point at
+    VERIFY_EVERY = 16             # deliveries between full checks that every parameter's `.grad` is still the static buffer
 
     def __init__(self, step_module, model, batch, warmup=3, synchronizer=None, criterion=None, overlap=False):
         """`overlap` (off until a run on >= 2 GPUs has verified it; bench.py --dp-overlap): the gradient all-reduce is
@@ -295,10 +296,14 @@ class GraphedStep:
         # unless somebody cleared them or another bucket's graph delivered in between (train_step does not zero the gradients
         # of a graphed step: the replay overwrites the buffers) -- first and last parameter tell; 750 attribute writes per
         # step were ~0.2 ms of Python between the backward graph and the optimiser.
+        # Every VERIFY_EVERY-th delivery checks all of them: a partial zero_grad / a group frozen mid-run / a user hook that
+        # replaced some `.grad` would otherwise leave those parameters without their gradient for the rest of the run.
         ps, gs = self.params, self.static_grads
         last = GraphedStep._delivered_by
+        self._deliveries = getattr(self, "_deliveries", 0) + 1
         if ps and ps[0].grad is gs[0] and ps[-1].grad is gs[-1] and last is not None and last() is self:
-            return
+            if self._deliveries % self.VERIFY_EVERY or all(p.grad is g for p, g in zip(ps, gs)):
+                return
         for p, g in zip(ps, gs):
             p.grad = g
         import weakref

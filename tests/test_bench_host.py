@@ -110,3 +110,29 @@ def test_routes_are_off_in_the_package_and_stay_off_without_a_gpu():
     samples, text, targets = train.synthetic_batch(1, 32, 32, n_obj=3, n_verb=2, triplets=1, device="cpu")
     verdict = routes.validate(None, None, (samples, text, targets))
     assert all(v.startswith("off (not applicable") for v in verdict.values()) and not any(routes.state().values())
+
+
+def test_set_flag_flips_existing_switches_only():
+    from rlipv2_amd import decoder, norm
+    try:
+        assert bench.apply_overrides(["decoder.fused_glue=0", "norm.MIN_ROWS=512"]) == {"decoder.fused_glue": False, "norm.MIN_ROWS": 512}
+        assert decoder.fused_glue is False and norm.MIN_ROWS == 512
+    finally:
+        decoder.fused_glue, norm.MIN_ROWS = True, 256
+    for bad in ("decoder.no_such_switch=1", "decoder.box_head=0", "decoder.fused_glue"):
+        with pytest.raises(SystemExit):
+            bench.apply_overrides([bad])
+
+
+def test_package_reads_no_code_path_switch_from_the_environment():
+    """~15 environment-variable A/B switches were read inside the product package.  What is left is
+    configuration of the libraries underneath (library path, MIOpen / hipBLASLt tuning tables)."""
+    import re
+    allowed = {"RLIPV2_LIB_PATH", "RLIPV2_TUNED_MIOPEN", "MIOPEN_USER_DB_PATH", "XDG_CACHE_HOME", "RLIPV2_TUNED_GEMM_TABLE",
+               "RLIPV2_TUNED_GEMMS"}
+    pkg = os.path.join(ROOT, "rlipv2_amd")
+    seen = set()
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            seen |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*\"([A-Z0-9_]+)\"", open(os.path.join(pkg, f)).read()))
+    assert seen <= allowed, seen - allowed

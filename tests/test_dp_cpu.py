@@ -368,3 +368,22 @@ def test_one_gradient_schedule_for_captured_and_eager_steps():
     cache.bucket = staticmethod(lambda b: "k")
     with pytest.raises(RuntimeError, match="disagree on the gradient schedule"):
         cache.get(None)
+
+
+def test_graphed_step_redelivers_gradients_somebody_cleared():
+    """Advisor finding of round 4: GraphedStep._deliver samples the first and last parameter's `.grad`; a `.grad` cleared in
+    the middle (partial zero_grad, a group frozen mid-run) is re-attached at the next full check (every VERIFY_EVERY-th step)."""
+    from rlipv2_amd import train
+    g = train.GraphedStep.__new__(train.GraphedStep)
+    g.synchronizer, g.overlap = None, False
+    g.params = [torch.nn.Parameter(torch.zeros(2)) for _ in range(5)]
+    g.static_grads = [torch.ones(2) for _ in range(5)]
+    g._deliver()
+    assert all(p.grad is s for p, s in zip(g.params, g.static_grads))
+    g.params[2].grad = None                                          # somebody cleared one in the middle
+    for _ in range(train.GraphedStep.VERIFY_EVERY):
+        g._deliver()
+    assert g.params[2].grad is g.static_grads[2]
+    g.params[0].grad = None                                          # the sampled ones are noticed at once
+    g._deliver()
+    assert g.params[0].grad is g.static_grads[0]

@@ -117,9 +117,9 @@ def test_full_parseda_bf16_against_the_f32_reference_golden():
     weights / activations / value in bfloat16; sampling geometry, softmax, bilinear weights and accumulators in float32.
       logits  max |err| <= 2e-2 x max |reference|     (measured: subject / object 4.2e-3, verb 1.24e-2)
       boxes   max |err| <= 5e-3 absolute               (measured: 8.0e-4 / 1.8e-3)
-    and a finite backward pass.  The GRADIENTS are checked in tests/test_zz_round4_gpu.py against a float32 run of this model on
-    the bf16-rounded weights with the sampling pinned, cosine >= 0.95 (round 3 accepted 0.88 here against the golden on
-    unrounded weights).  Parity proper is claimed in float32 (test_full_parseda_f32: logits 1e-3 rel, boxes 1e-4 abs)."""
+    and the GRADIENTS of the golden's loss against the reference golden at round 3's hardware-validated bar (cosine >= 0.88,
+    below); tests/test_zz_round4_gpu.py adds the tighter check against a float32 run of this model on the bf16-rounded weights
+    with the sampling pinned (cosine >= 0.95).  Parity proper is claimed in float32 (test_full_parseda_f32: logits 1e-3 rel, boxes 1e-4 abs)."""
     g = C.load("parseda")
     model, bb = C.build_small_parseda()
     model = model.to(DEV).to(torch.bfloat16)
@@ -134,8 +134,26 @@ def test_full_parseda_bf16_against_the_f32_reference_golden():
             assert err <= tol, (what, err, tol)
         loss = loss + (out[k].float() * g["g_" + k].to(DEV)).sum() + (out["aux_outputs"][0][k].float() * g["g_" + k].to(DEV)).sum() * 0.5
     loss.backward()
-    for t, _ in feats:
+
+    # GRADIENTS against the REFERENCE golden (independent of this repository's other code paths): the hardware-validated bar of
+    # round 3, cosine >= 0.88 for the three feature maps and every sentinel parameter (measured then: features 0.920-0.990,
+    # parameters 0.905-1.000; the low ones pass the sampling locations' floor() kinks, which one bf16 rounding moves across).
+    # The tighter check with the sampling pinned (>= 0.95, against a float32 run of this model) is tests/test_zz_round4_gpu.py;
+    # this one stays because a systematic error shared by two of this repository's routes would pass that and fail here.
+    def cosine(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+    for i, (t, _) in enumerate(feats):
         assert torch.isfinite(t.grad.float()).all()
+        c = cosine(t.grad.float().cpu(), g[f"g_feat{i}"])
+        assert c >= 0.88, (f"g_feat{i}", c)
+    params = dict(model.named_parameters(remove_duplicate=False))
+    for key in g:
+        if key.startswith("gparam_") and g[key].numel():
+            name = key[len("gparam_"):].replace("__", ".")
+            c = cosine(params[name].grad.float().cpu(), g[key])
+            assert c >= 0.88, (name, c)
 
 
 @pytest.mark.parametrize("nd", [2, 4])

@@ -496,7 +496,7 @@ def traffic_from_table(t, kernel_key):
 
 
 def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None,
-         step_roofline=None, b0=None, host_routes=None):
+         step_roofline=None, b0=None, host_routes=None, experiments=None):
     probe_steps = args.steps if probe_steps is None else probe_steps
     dominant = max(kern, key=lambda n: kern[n]["ms"])
     kd = kern[dominant]
@@ -579,6 +579,8 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
                     "FlopCounterMode + the library kernels' own operand accounting): inputs + outputs of every op "
                     "once, in the step's dtypes; frac = max(T_mem, T_mfma) / measured ms_per_step",
         }
+    if experiments is not None:
+        line["experiments"] = experiments
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
     print(json.dumps(line), flush=True)
@@ -597,6 +599,27 @@ def miopen_tuning_report():
         return f"recorded find-db, lookup only (rlipv2_amd/tuned/miopen, recorded for MIOpen {st['recorded_for']} = the loaded library)"
     return (f"library default: the recorded find-db is for MIOpen {st['recorded_for']}, the loaded library is {st['library']} "
             "-- MIOpen ignores it (expect ~2 ms/step of split-K workspace kernels)")
+
+
+def under_profiler():
+    return any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB",
+                                                                           "ROCPROFILER_REGISTER_LIBRARY"))
+
+
+def run_experiments(args, world):
+    """After the timed region (nothing of this run is measured any more): the A/B table of the kernel arms that have never been
+    timed on hardware, every arm in a child process with a timeout (tools/experiments_r05.py).  Evidence for the next decision,
+    reported under `experiments`; the product path of this run is not touched.  Single-GPU default configuration only."""
+    if (not args.experiments or args.no_cpu_baseline or world != 1 or args.backbone != "resnet50" or args.dtype != "bf16"
+            or args.batch != 4 or args.overrides or args.padded or args.var_targets or under_profiler()):
+        return None                     # (only the full default evidence run; never under rocprofv3: its preload follows children)
+    try:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()                                  # the children allocate on the same device
+        from tools import experiments_r05
+        return experiments_r05.main()
+    except Exception as e:                                         # noqa: BLE001 -- evidence only, never fatal
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def apply_overrides(overrides):
@@ -655,6 +678,9 @@ def main():
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-experiments", dest="experiments", action="store_false",
+                    help="skip the A/B table of the unmeasured kernel arms that a default 1-GPU run appends after its timed region "
+                         "(tools/experiments_r05.py, ~3 minutes, child processes)")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE", dest="overrides",
                     help="A/B runs: set a bool / int attribute of a rlipv2_amd module for this run, e.g. --set decoder.fused_glue=0 "
                          "(the switches INTEGRATION.md lists; recorded in config.overrides)")
@@ -736,7 +762,8 @@ def main():
                  probe_note=("HIP events around every MSDA call in 2 eager steps of the same train step run right after "
                              "the timed region (the timed steps replay HIP graphs, whose kernels cannot be bracketed)")
                  if graphed else None, step_roofline=step_roofline, host_routes=host_routes,
-                 b0=b0_signature_kernels(args.batch, dtype, device) if args.backbone == "resnet50" else None)
+                 b0=b0_signature_kernels(args.batch, dtype, device) if args.backbone == "resnet50" else None,
+                 experiments=run_experiments(args, world))
         if world > 1:
             dist.destroy_process_group()
         return

@@ -136,3 +136,50 @@ def test_package_reads_no_code_path_switch_from_the_environment():
         if f.endswith(".py"):
             seen |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*\"([A-Z0-9_]+)\"", open(os.path.join(pkg, f)).read()))
     assert seen <= allowed, seen - allowed
+
+
+def test_experiments_leg_only_in_the_full_default_run(monkeypatch):
+    """bench.py appends the A/B table of the unmeasured kernel arms (tools/experiments_r05.py, child processes) to the default
+    1-GPU evidence run only -- never under a profiler, with overrides, on another configuration, or on several ranks."""
+    import argparse
+    from tools import experiments_r05
+    monkeypatch.setattr(experiments_r05, "main", lambda: {"ran": True})
+    monkeypatch.setattr(bench.torch.cuda, "synchronize", lambda: None)
+    monkeypatch.setattr(bench.torch.cuda, "empty_cache", lambda: None)
+    base = dict(experiments=True, no_cpu_baseline=False, backbone="resnet50", dtype="bf16", batch=4, overrides=[], padded=False,
+                var_targets=False)
+    assert bench.run_experiments(argparse.Namespace(**base), 1) == {"ran": True}
+    assert bench.run_experiments(argparse.Namespace(**base), 2) is None
+    for k, v in (("experiments", False), ("no_cpu_baseline", True), ("batch", 8), ("overrides", ["a.b=1"]), ("backbone", "swin_large")):
+        assert bench.run_experiments(argparse.Namespace(**dict(base, **{k: v})), 1) is None
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.run_experiments(argparse.Namespace(**base), 1) is None
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setattr(experiments_r05, "main", lambda: 1 / 0)
+    assert "ZeroDivisionError" in bench.run_experiments(argparse.Namespace(**base), 1)["error"]
+
+
+def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_path):
+    from tools import experiments_r05 as X
+
+    def fake(args, env, timeout):
+        if args[0] == "--fwd":
+            return {"model": {"quad_us": 150.0, "cell_us": 110.0}}
+        k = int(args[1])
+        if k == 3:
+            return {"error": "timed out after 75 s (child killed)"}
+        d = [[1, 2], [3, 4], [5, 6]] if k != 2 else [[1, 2], [3, 4], [5, 7]]
+        return {"b0": {"digest": d, "finite": True, "us": 500.0 - k}, "fused": {"digest": d, "finite": True, "us": 540.0 - k}}
+    monkeypatch.setattr(X, "run_child", fake)
+    monkeypatch.setattr(X, "ABLATION_LIB", os.path.join(ROOT, "bench.py"))
+    rep = X.main()
+    arms = rep["encoder_backward_arms"]
+    names = [n for n, _ in X.ARMS]
+    assert arms[names[0]]["b0"]["equal_bits"] and arms[names[1]]["fused"]["equal_bits"]
+    assert not arms[names[2]]["b0"]["equal_bits"] and "error" in arms[names[3]]
+    assert rep["encoder_forward_cell"]["model"]["cell_us"] == 110.0
+    assert "digest" not in json.dumps(rep)
+    # a real child that produces nothing (here: no GPU) is an error entry, not an exception
+    monkeypatch.undo()
+    out = X.run_child(["--fwd"], dict(os.environ), 120)
+    assert "error" in out

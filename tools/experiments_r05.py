@@ -1,0 +1,149 @@
+"""A/B of the unmeasured kernel arms in ONE call, every arm in its own child process with a timeout (an arm that has never run
+on hardware may hang or fault: the parent only ever loses that arm).  Used two ways:
+
+    python tools/experiments_r05.py                    # prints one JSON object (and a readable table on stderr)
+    bench.py (default, 1 GPU, train_step)              # runs it AFTER its timed region and puts the object into the JSON line
+                                                       # as `experiments` -- evidence only, the product path is not changed
+
+Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_amd/csrc ablation`; csrc/msda_patch.hip):
+  cell 2-4   cell_backward_kernel<., MODE>: geometry once per quad + operand swap | + loads up front, scalar level starts |
+             mode 3 without the swap                                  (reference work: ms_deform_im2col_cuda.cuh:87-159, 301-403)
+  patch multi   patch_dest_multi_kernel (mask-word prefetch not in a branch)
+  fwd cell   cell_forward_kernel (explicit variant "cell" of the product library) against the product forward (.cuh:237-299)
+Every backward arm must reproduce the default's three gradients BIT FOR BIT (64-bit digests of the raw bits, computed on the
+device) on the encoder shape (N = 4, 800x1333 pyramid, bf16, model-like locations), B0 signature and fused geometry route;
+time = HIP events around 20 calls of the whole backward.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ABLATION_LIB = os.path.join(ROOT, "tools", "_build", "librlipv2_msda_ablation.so")
+
+ARMS = [("default", {}),
+        ("cell 2 (geometry once per quad + operand swap)", {"RLIPV2_CELL_SHARED": "2"}),
+        ("cell 3 (2 + loads up front)", {"RLIPV2_CELL_SHARED": "3"}),
+        ("cell 4 (3 without swap)", {"RLIPV2_CELL_SHARED": "4"}),
+        ("patch multi", {"RLIPV2_PATCH_MULTI": "1"}),
+        ("cell 3 + patch multi", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_MULTI": "1"})]
+KEYS = ("RLIPV2_CELL_SHARED", "RLIPV2_PATCH_REPS", "RLIPV2_PATCH_MULTI")
+
+
+def digest(t):
+    """two 64-bit sums over the raw bits of a tensor (position-weighted: a permutation of equal values is seen too)"""
+    import torch
+    raw = t.contiguous().view(torch.int16 if t.element_size() == 2 else torch.int32).reshape(-1).to(torch.int64)
+    pos = torch.arange(raw.numel(), device=raw.device, dtype=torch.int64) % 65521 + 1
+    return [int(raw.sum()), int((raw * pos).sum())]
+
+
+def child_backward(arm):
+    import torch
+    from rlipv2_amd import msda
+    from tools.msda_inputs import PYRAMID_800x1333, make_inputs
+    from tools.patch_check import timed
+    from tools.r03_experiments import fused_problem
+    out = {}
+    inp = make_inputs(4, mode="model", dtype=torch.bfloat16, seed=3)
+    a = (inp["value"], inp["shapes"], inp["starts"], inp["loc"], inp["aw"], inp["grad_out"])
+    res = msda.ms_deform_attn_backward(*a, 64)
+    out["b0"] = {"digest": [digest(t) for t in res], "finite": all(bool(torch.isfinite(t.float()).all()) for t in res),
+                 "us": round(timed(lambda: msda.ms_deform_attn_backward(*a, 64), iters=20), 1)}
+    msda.attach_host_shapes(inp["shapes"], PYRAMID_800x1333)
+    qproj, ref = fused_problem(4, inp)
+    _, loc, aw = msda.ms_deform_attn_fused_forward(inp["value"], inp["shapes"], inp["starts"], qproj, ref, True)
+    hs = msda.host_shapes(inp["shapes"])
+    f = lambda: msda.ms_deform_attn_fused_backward(inp["value"], inp["shapes"], inp["starts"], loc, aw, ref, inp["grad_out"], hs)  # noqa: E731
+    res = [t for t in f() if torch.is_tensor(t)]
+    out["fused"] = {"digest": [digest(t) for t in res], "finite": all(bool(torch.isfinite(t.float()).all()) for t in res),
+                    "us": round(timed(f, iters=20), 1)}
+    print("RESULT " + json.dumps(out), flush=True)
+
+
+def child_forward():
+    import torch
+    from rlipv2_amd import msda
+    from tools.msda_inputs import make_inputs
+    from tools.patch_check import timed
+    out = {}
+    for mode in ("model", "init"):
+        inp = make_inputs(4, mode=mode, dtype=torch.bfloat16, seed=3)
+        a = (inp["value"], inp["shapes"], inp["starts"], inp["loc"], inp["aw"])
+        msda.attach_host_shapes(inp["shapes"], [(100, 167), (50, 84), (25, 42), (13, 21)])
+        res, t = {}, {}
+        for v in ("quad", "cell"):
+            msda.set_variant(v, "quad")
+            try:
+                res[v] = msda.ms_deform_attn_forward(*a, 64).float()
+                torch.cuda.synchronize()
+                t[v] = round(timed(lambda: msda.ms_deform_attn_forward(*a, 64), iters=20), 1)
+            finally:
+                msda.set_variant("auto")
+        d = (res["cell"] - res["quad"]).abs()
+        scale = float(res["quad"].abs().max())
+        out[mode] = {"quad_us": t["quad"], "cell_us": t["cell"], "max_diff_rel_to_max": float(d.max()) / scale,
+                     "mean_diff_rel_to_max": float(d.mean()) / scale, "non_finite": int((~torch.isfinite(res["cell"])).sum())}
+    print("RESULT " + json.dumps(out), flush=True)
+
+
+def run_child(args, env, timeout):
+    t0 = time.time()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), *args], capture_output=True, text=True, timeout=timeout,
+                           env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout} s (child killed)"}
+    for line in r.stdout.splitlines():
+        if line.startswith("RESULT "):
+            out = json.loads(line[7:])
+            out["wall_s"] = round(time.time() - t0, 1)
+            return out
+    return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+
+
+def main(per_child_timeout=75, budget_s=200):
+    """parent: one child per arm; stops starting new children when `budget_s` is used up"""
+    t0 = time.time()
+    report = {"what": "unmeasured kernel arms, A/B in child processes (tools/experiments_r05.py); evidence only, product path unchanged",
+              "shape": "encoder N=4, 800x1333 pyramid, bf16, model-like locations; us = HIP events around 20 whole calls"}
+    base_env = {k: v for k, v in os.environ.items() if k not in KEYS and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if os.path.exists(ABLATION_LIB):
+        arms, base = {}, None
+        for k, (name, env) in enumerate(ARMS):
+            if time.time() - t0 > budget_s:
+                arms[name] = {"error": "not started: time budget used up"}
+                continue
+            e = dict(base_env, RLIPV2_LIB_PATH=ABLATION_LIB, **env)
+            out = run_child(["--arm", str(k)], e, per_child_timeout)
+            if "error" not in out:
+                digests = {case: out[case].pop("digest") for case in ("b0", "fused")}
+                if base is None:
+                    base = digests
+                for case in ("b0", "fused"):
+                    out[case]["equal_bits"] = digests[case] == base[case]
+            arms[name] = out
+            if k == 0 and "error" in out:
+                break                                          # the default itself failed: nothing to compare with
+        report["encoder_backward_arms"] = arms
+    else:
+        report["encoder_backward_arms"] = {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
+    if time.time() - t0 <= budget_s:
+        report["encoder_forward_cell"] = run_child(["--fwd"], base_env, per_child_timeout)
+    report["wall_s"] = round(time.time() - t0, 1)
+    return report
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--arm":
+        child_backward(int(sys.argv[2]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--fwd":
+        child_forward()
+    else:
+        rep = main()
+        for name, v in rep.get("encoder_backward_arms", {}).items():
+            print(f"{name:36s} {json.dumps(v)}", file=sys.stderr)
+        print(json.dumps(rep))

@@ -6,6 +6,6 @@ mkdir -p $out
 i=0
 for flags in "$@"; do
     i=$((i + 1))
-    python bench.py --steps 30 --warmup 8 --no-cpu-baseline $flags > $out/run$i.json 2> $out/run$i.err
+    python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-experiments $flags > $out/run$i.json 2> $out/run$i.err
     echo "[$flags] $(python -c "import json,sys; d=json.loads(open('$out/run$i.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" 2>&1)" | tee -a $out/summary.txt
 done

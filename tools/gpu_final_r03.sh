@@ -6,7 +6,7 @@ TAG=${1:-final_r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1 )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-experiments > $OUT/bench_under_rocprof.log 2>&1 )
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/msda_$C -o p -- python3 $GRAFT_REPO_ROOT/tools/fused_once.py bwd 5 > $OUT/log_fusedbwd_$C.txt 2>&1 )
   ( cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/fwd_$C -o p -- python3 $GRAFT_REPO_ROOT/tools/fused_once.py fwd 5 > $OUT/log_fusedfwd_$C.txt 2>&1 )
@@ -18,6 +18,6 @@ cd $GRAFT_REPO_ROOT
 python3 tools/pmc_final_summary.py $OUT $GRAFT_REPO_ROOT/gpurun_out/$(basename $TAG)_final_traffic.json > $OUT/traffic_summary.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +20M -delete
-python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
+python3 bench.py --no-experiments > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 cat $OUT/traffic_summary.txt
 f=$(find $OUT/bench_stats -name "*kernel_stats.csv" | head -1); head -25 "$f" | cut -c1-160

@@ -8,5 +8,5 @@ rocm-smi --showproductname > $OUT/box.txt 2>&1
 ( timeout 1000 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt )
 tail -30 $OUT/pytest_gpu.txt
 ( timeout 240 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/smoke.txt ); tail -3 $OUT/smoke.txt
-timeout 420 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
+timeout 800 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 tail -c 3000 $OUT/bench_line.json; tail -5 $OUT/bench_stderr.txt

@@ -13,14 +13,14 @@ cd $GRAFT_REPO_ROOT
 ( timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt )
 tail -8 $OUT/pytest_gpu.txt
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/smoke.txt ); tail -3 $OUT/smoke.txt
-timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
+timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 tail -c 1500 $OUT/bench_line.json
 ( timeout 900 python tools/r04_host_ab.py 20 > $OUT/host_ab.txt 2>&1 ); cat $OUT/host_ab.txt | tail -12
 ( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; timeout 900 python tools/r03_experiments.py > $OUT/experiments.txt 2>&1 )
 cat $OUT/experiments.txt
 ( RLIPV2_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_msda_cell_forward_gpu.py -q -m gpu > $OUT/pytest_cell_forward.txt 2>&1; timeout 300 python tools/cell_forward_check.py >> $OUT/pytest_cell_forward.txt 2>&1 )
 tail -25 $OUT/pytest_cell_forward.txt
-timeout 600 python bench.py --no-cpu-baseline --msda-fwd-cell > $OUT/bench_line_fwd_cell.json 2> $OUT/bench_fwd_cell_stderr.txt
+timeout 600 python bench.py --no-cpu-baseline --no-experiments --msda-fwd-cell > $OUT/bench_line_fwd_cell.json 2> $OUT/bench_fwd_cell_stderr.txt
 tail -c 600 $OUT/bench_line_fwd_cell.json
 # brief item 6 decided by one measurement: today's chunk plan against one chunk + direct stores (small-token Linears)
 ( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; for m in 8 100000; do RLIPV2_WGRAD_MINSTEPS=$m timeout 300 python tools/wgrad_plan_ab.py; done > $OUT/wgrad_plan_ab.txt 2>&1 ); cat $OUT/wgrad_plan_ab.txt

@@ -1,3 +1,5 @@
+"""Ablation arms of the window-staged tile forward (csrc/msda_quad.hip: tile_forward_kernel; ablation build): base loop, bounding
+boxes, staging, sampling -- the phase times quoted in DESIGN.md section 4 (a measured negative result for bf16)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlipv2_amd import msda

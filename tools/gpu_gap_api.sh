@@ -1,4 +1,5 @@
 #!/bin/bash
+# rocprofv3 kernel + HIP-API trace of a short bench run: input of tools/gap_api.py (which HIP call the host sits in while the GPU idles)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-gapapi}
 mkdir -p $OUT
 export TMPDIR=/tmp

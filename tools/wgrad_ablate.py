@@ -1,3 +1,5 @@
+"""Ablation arms of the MFMA weight-gradient kernel (csrc/token_gemm.hip; ablation build, RLIPV2_WGRAD_DBG bits): main loop, DMA
+stream, partial-sum round trip -- profiles/r02_wgrad_ablation.txt."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlipv2_amd import linear

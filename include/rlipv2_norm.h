@@ -37,6 +37,24 @@ int add_layernorm_backward_bf16(const void *dy, const void *a, const void *b, co
                                 const float *rstd, long rows, int C, void *dx, void *dgamma, void *dbeta,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the widths of the Swin backbones (csrc/layernorm_wide.hip; round 5, not yet run on hardware) ------------------------
+ * The pre-norm residual block of the Swin Transformer (reference models/swin/swin_transformer.py:304-403):
+ *     x = x + drop_path(branch);  y = norm(x)        -- as add + layer_norm: 5 passes over the tensor forward
+ * here ONE pass per direction, for C in {96, 128, 192, 384, 512, 768, 1024, 1536} (256: the kernels above):
+ *   forward : s = a + b (rounded to bf16, written to `sum` when given), y = LN(s) * gamma + beta, mean / rstd saved
+ *             (b NULL: plain LayerNorm of a; sum NULL with b: post-norm form, the sum stays float32)
+ *   backward: dx = dLN/ds (dy) + dsum   (dsum NULL: no gradient reaches the sum on the residual path)
+ *             x = the tensor the statistics were taken from (the saved `sum`, or `a` when b was NULL)
+ * No gamma / beta gradients: the reference freezes every norm of its Swin backbones (models/swin/backbone.py:66-69); a
+ * caller that trains them keeps PyTorch's op.  Same conventions as above (bf16 data, 16-byte aligned, float32 statistics). */
+int layernorm_wide_supported(long rows, int C);
+
+int layernorm_wide_forward_bf16(const void *a, const void *b, const void *gamma, const void *beta, long rows, int C, float eps,
+                                void *y, void *sum, float *mean, float *rstd, void *stream);
+
+int layernorm_wide_backward_bf16(const void *dy, const void *dsum, const void *x, const void *gamma, const float *mean,
+                                 const float *rstd, long rows, int C, void *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,7 @@ EXPORTS = (
     "linear_expand_supported", "linear_expand_bf16",
     # include/rlipv2_norm.h
     "add_layernorm_supported", "add_layernorm_workspace_bytes", "add_layernorm_forward_bf16",
-    "add_layernorm_backward_bf16",
+    "add_layernorm_backward_bf16", "layernorm_wide_supported", "layernorm_wide_forward_bf16", "layernorm_wide_backward_bf16",
     # include/rlipv2_optim.h
     "adamw_abi_sizes", "adamw_grad_sqnorm_bf16", "adamw_step_bf16", "adamw_step_scaled_bf16",
     # include/rlipv2_alif.h
@@ -130,6 +130,12 @@ def lib() -> ctypes.CDLL:
     L.add_layernorm_forward_bf16.restype = i
     L.add_layernorm_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, lg, i, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.add_layernorm_backward_bf16.restype = i
+    L.layernorm_wide_supported.argtypes = [lg, i]
+    L.layernorm_wide_supported.restype = i
+    L.layernorm_wide_forward_bf16.argtypes = [vp, vp, vp, vp, lg, i, f32, vp, vp, vp, vp, vp]
+    L.layernorm_wide_forward_bf16.restype = i
+    L.layernorm_wide_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, lg, i, vp, vp]
+    L.layernorm_wide_backward_bf16.restype = i
     ip = ctypes.POINTER(ctypes.c_int)
     L.adamw_abi_sizes.argtypes = [ip, ip, ip, ip]
     L.adamw_abi_sizes.restype = i

@@ -109,6 +109,100 @@ def add_layer_norm(a, b, norm: torch.nn.LayerNorm):
     return norm(a if b is None else a + b)
 
 
+# ---- LayerNorm at the Swin widths, with the pre-norm block's residual add (csrc/layernorm_wide.hip) ---------------------------
+# GPU-only route (never run on hardware): OFF until rlipv2_amd/routes.validate() has compared the Swin train step with it
+# against the plain ops (`add` + `F.layer_norm`) on the caller's own model and batch.
+fused_wide_layer_norm = False
+
+
+def wide_supported(x, norm) -> bool:
+    """the fused route can take `norm(x)`: CUDA bfloat16, a supported width, frozen affine parameters (the reference freezes
+    every norm of its Swin backbones, models/swin/backbone.py:66-69; trainable ones keep PyTorch's op and its dgamma / dbeta)"""
+    w, b = norm.weight, norm.bias
+    if not (fused_wide_layer_norm and enabled and x.is_cuda and x.dtype == torch.bfloat16 and w is not None and b is not None
+            and w.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and len(norm.normalized_shape) == 1
+            and not w.requires_grad and not b.requires_grad and not torch.is_autocast_enabled()):
+        return False
+    C = x.shape[-1]
+    return norm.normalized_shape[0] == C and bool(_lib.lib().layernorm_wide_supported(x.numel() // C, C))
+
+
+def _wide_forward(a, b, weight, bias, eps):
+    C = a.shape[-1]
+    rows = a.numel() // C
+    y = torch.empty_like(a)
+    s = torch.empty_like(a) if b is not None else None
+    mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+    _check(_lib.lib().layernorm_wide_forward_bf16(a.data_ptr(), None if b is None else b.data_ptr(), weight.data_ptr(),
+                                                  bias.data_ptr(), rows, C, float(eps), y.data_ptr(),
+                                                  None if b is None else s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                  torch.cuda.current_stream(a.device).cuda_stream), "layernorm_wide_forward")
+    roofline.add(roofline.tensor_bytes(a, b, weight, bias, y, s, mean, rstd))
+    return s, y, mean, rstd
+
+
+def _wide_backward(dy, ds, x, weight, mean, rstd):
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    _check(_lib.lib().layernorm_wide_backward_bf16(dy.data_ptr(), None if ds is None else ds.data_ptr(), x.data_ptr(),
+                                                   weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x.numel() // C, C,
+                                                   dx.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+           "layernorm_wide_backward")
+    roofline.add(roofline.tensor_bytes(dy, ds, x, weight, mean, rstd, dx))
+    return dx
+
+
+class WideLayerNormFunction(torch.autograd.Function):
+    """y = LN(a) at a Swin width (frozen affine parameters): one pass per direction."""
+
+    @staticmethod
+    def forward(ctx, a, weight, bias, eps):
+        a = a.contiguous()
+        _, y, mean, rstd = _wide_forward(a, None, weight, bias, eps)
+        ctx.save_for_backward(a, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        a, weight, mean, rstd = ctx.saved_tensors
+        return _wide_backward(dy.contiguous(), None, a, weight, mean, rstd), None, None, None
+
+
+class WideAddLayerNormFunction(torch.autograd.Function):
+    """(s, y) = (a + b, LN(a + b)) for the pre-norm residual block; the backward takes the gradients of BOTH outputs and
+    returns dLN(dy) + ds for a and for b (the same tensor) -- one pass per direction where add + layer_norm are five."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, eps):
+        s, y, mean, rstd = _wide_forward(a.contiguous(), b.contiguous(), weight, bias, eps)
+        ctx.save_for_backward(s, weight, mean, rstd)
+        return s, y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ds, dy):
+        s, weight, mean, rstd = ctx.saved_tensors
+        if dy is None:                             # only the sum was used downstream
+            return ds, ds, None, None, None
+        dx = _wide_backward(dy.contiguous(), None if ds is None else ds.contiguous(), s, weight, mean, rstd)
+        return dx, dx, None, None, None
+
+
+def residual_pre_norm(x, branch, norm: torch.nn.LayerNorm):
+    """(x + branch, norm(x + branch)) -- the step between two sub-blocks of a pre-norm transformer block (reference
+    models/swin/swin_transformer.py:386-401: `x = shortcut + drop_path(x)` followed by the next `norm(x)`).  `branch` None:
+    (x, norm(x)).  One fused pass per direction on the GPU when the width is supported, the plain ops otherwise."""
+    if wide_supported(x, norm):
+        if branch is None:
+            return x, WideLayerNormFunction.apply(x, norm.weight, norm.bias, norm.eps)
+        if branch.shape == x.shape and branch.dtype == x.dtype:
+            return WideAddLayerNormFunction.apply(x, branch, norm.weight, norm.bias, norm.eps)
+    s = x if branch is None else x + branch
+    return s, norm(s)
+
+
 # ---- GroupNorm(32, 256) of the token-major feature pyramid (csrc/groupnorm_tokens.hip, include/rlipv2_groupnorm.h) ----
 level_group_norm_enabled = True
 

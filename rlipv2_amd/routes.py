@@ -15,6 +15,8 @@ Routes:
                              1283-1300, 1346-1401)
   one_launch_box_head        decoder.py: sigmoid(delta + inverse_sigmoid(ref)) of the prediction heads (hoi.py:2122-2138) as one
                              launch of csrc/decoder_glue.hip with sigmoid's own backward
+  fused_wide_layer_norm      norm.py / swin.py: the Swin blocks' residual add + LayerNorm (models/swin/swin_transformer.py:386-401) as
+                             one pass per direction at the Swin widths (csrc/layernorm_wide.hip); no effect on the R50 configurations
 """
 from __future__ import annotations
 
@@ -25,6 +27,7 @@ import torch
 GPU_ONLY_ROUTES = {
     "residual_gradient_in_gemm": ("rlipv2_amd.linear", "residual_gradient_in_gemm"),
     "one_launch_box_head": ("rlipv2_amd.decoder", "one_launch_box_head"),
+    "fused_wide_layer_norm": ("rlipv2_amd.norm", "fused_wide_layer_norm"),
 }
 
 # tolerances (tests/test_zz_round4_gpu.py::test_gradient_links_change_nothing_in_the_train_step_bf16): loss within 1e-3

@@ -24,6 +24,7 @@ from torch import nn
 
 from .blocks import NestedTensor, PositionEmbeddingSine
 from .linear import token_linear
+from .norm import residual_pre_norm
 
 
 class DropPath(nn.Module):
@@ -142,11 +143,11 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio), drop)
 
-    def forward(self, x, mask):
-        """x [B, H, W, C]"""
-        B, H, W, C = x.shape
+    def attention(self, y, mask):
+        """the attention branch on the NORMALISED input y [B, H, W, C] (pad, shift, window partition, attention, reverse),
+        drop-path applied: what is added to the residual stream"""
+        B, H, W, C = y.shape
         ws = self.ws
-        y = self.norm1(x)
         pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
         if pad_r or pad_b:
             y = F.pad(y, (0, 0, 0, pad_r, 0, pad_b))
@@ -160,8 +161,21 @@ class SwinTransformerBlock(nn.Module):
             y = torch.roll(y, shifts=(self.shift, self.shift), dims=(1, 2))
         if pad_r or pad_b:
             y = y[:, :H, :W]
-        x = x + self.drop_path(y)
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        return self.drop_path(y)
+
+    def branches(self, x, pending, mask):
+        """One block on the residual stream `x + pending` (`pending`: the previous block's MLP branch, not yet added; None for
+        the first block).  Returns (x, pending'): the stream after this block's attention branch and this block's MLP branch,
+        again not yet added -- so that every residual add runs together with the LayerNorm that reads its result
+        (norm.residual_pre_norm: one pass on the GPU at the Swin widths, `add` + `layer_norm` otherwise; same values)."""
+        x, y = residual_pre_norm(x, pending, self.norm1)
+        x, y = residual_pre_norm(x, self.attention(y, mask), self.norm2)
+        return x, self.drop_path(self.mlp(y))
+
+    def forward(self, x, mask):
+        """x [B, H, W, C] (reference SwinTransformerBlock.forward, models/swin/swin_transformer.py:355-403)"""
+        x, pending = self.branches(x, None, mask)
+        return x + pending
 
 
 class PatchMerging(nn.Module):
@@ -191,7 +205,8 @@ class BasicLayer(nn.Module):
         self.downsample = PatchMerging(dim) if downsample else None
         self._masks = {}
 
-    def forward(self, x):
+    def forward(self, x, out_norm=None):
+        """-> (stage output, input of the next stage, out_norm(stage output) or None)"""
         B, H, W, C = x.shape
         ws = self.ws
         Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
@@ -199,9 +214,15 @@ class BasicLayer(nn.Module):
         if key not in self._masks:
             self._masks[key] = shift_mask(Hp, Wp, ws, self.shift, x.device)
         mask = self._masks[key]
+        pending = None
         for blk in self.blocks:
-            x = blk(x, mask)
-        return x, (self.downsample(x) if self.downsample is not None else x)
+            x, pending = blk.branches(x, pending, mask)
+        # the last block's MLP branch is added together with the stage's output norm when there is one
+        if out_norm is not None:
+            x, normed = residual_pre_norm(x, pending, out_norm)
+        else:
+            x, normed = (x if pending is None else x + pending), None
+        return x, (self.downsample(x) if self.downsample is not None else x), normed
 
 
 class PatchEmbed(nn.Module):
@@ -262,9 +283,9 @@ class SwinTransformer(nn.Module):
         x = self.pos_drop(x)
         outs = {}
         for i, layer in enumerate(self.layers):
-            x_out, x = layer(x)
+            _, x, normed = layer(x, getattr(self, f"norm{i}") if i in self.out_indices else None)
             if i in self.out_indices:
-                outs[f"layer{i}"] = getattr(self, f"norm{i}")(x_out).permute(0, 3, 1, 2)
+                outs[f"layer{i}"] = normed.permute(0, 3, 1, 2)
         return outs
 
 

@@ -96,6 +96,53 @@ def test_fused_adamw_against_torch(lib, max_norm, grad_scale):
         torch.testing.assert_close(m2[i], st["exp_avg_sq"], rtol=2e-5, atol=1e-6 * float(st["exp_avg_sq"].abs().max()))
 
 
+@pytest.mark.parametrize("C,rows,form", [(192, 333, "pre_norm"), (384, 70, "pre_norm"), (768, 41, "plain"), (1536, 19, "pre_norm"),
+                                         (96, 130, "post_norm"), (128, 67, "pre_norm"), (512, 9, "plain"), (1024, 13, "pre_norm")])
+def test_wide_layernorm_forward_and_backward_against_torch(lib, C, rows, form):
+    """csrc/layernorm_wide.hip (round 5, never run on hardware) at every supported width.  pre_norm: s = a + b rounded to bf16
+    and written out, y = LN(s), backward dx = LN'(dy) + ds (the Swin block, models/swin/swin_transformer.py:386-401);
+    plain: y = LN(a); post_norm: y = LN(a + b) with the sum kept in float32.  Against float32 PyTorch on the same operands."""
+    eps = 1e-5
+    lg = ctypes.c_long
+    lib.layernorm_wide_supported.argtypes = [lg, ci]
+    assert lib.layernorm_wide_supported(rows, C) == 1 and lib.layernorm_wide_supported(rows, 256) == 0
+    torch.manual_seed(C + rows)
+    a = torch.randn(rows, C).to(torch.bfloat16)
+    b = None if form == "plain" else (0.5 * torch.randn(rows, C)).to(torch.bfloat16)
+    gamma = (1.0 + 0.1 * torch.randn(C)).to(torch.bfloat16)
+    beta = (0.1 * torch.randn(C)).to(torch.bfloat16)
+    dy = torch.randn(rows, C).to(torch.bfloat16)
+    ds = torch.randn(rows, C).to(torch.bfloat16) if form == "pre_norm" else None
+    y, s_out = torch.empty_like(a), (torch.empty_like(a) if form == "pre_norm" else None)
+    mean, rstd = torch.empty(rows), torch.empty(rows)
+    lib.layernorm_wide_forward_bf16.argtypes = [vp, vp, vp, vp, lg, ci, ctypes.c_float, vp, vp, vp, vp, vp]
+    assert lib.layernorm_wide_forward_bf16(ptr(a), ptr(b) if b is not None else None, ptr(gamma), ptr(beta), rows, C, eps, ptr(y),
+                                           ptr(s_out) if s_out is not None else None, ptr(mean), ptr(rstd), None) == 0
+    if form == "pre_norm":
+        assert torch.equal(s_out, (a.float() + b.float()).to(torch.bfloat16))        # the sum the next block reads, bit for bit
+        x = s_out.float().requires_grad_(True)                                       # statistics are taken from the rounded sum
+    else:
+        x = (a.float() + (b.float() if b is not None else 0)).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x, (C,), gamma.float(), beta.float(), eps)
+    torch.testing.assert_close(y.float(), ref.detach(), rtol=2.0 ** -7, atol=2.0 ** -7)        # one bfloat16 rounding
+    torch.testing.assert_close(mean, x.detach().mean(1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd, (x.detach().var(1, unbiased=False) + eps).rsqrt(), rtol=1e-5, atol=1e-6)
+    ref.backward(dy.float())
+    want = x.grad + (ds.float() if ds is not None else 0)
+    dx = torch.empty_like(a)
+    x_saved = s_out if form == "pre_norm" else (a if form == "plain" else (a.float() + b.float()).to(torch.bfloat16))
+    lib.layernorm_wide_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, lg, ci, vp, vp]
+    assert lib.layernorm_wide_backward_bf16(ptr(dy), ptr(ds) if ds is not None else None, ptr(x_saved), ptr(gamma), ptr(mean),
+                                            ptr(rstd), rows, C, ptr(dx), None) == 0
+    tol = 2.0 ** -6 if form != "post_norm" else 2.0 ** -5       # (post_norm: the backward sees the ROUNDED sum as its input)
+    torch.testing.assert_close(dx.float(), want, rtol=tol, atol=tol * float(want.abs().max()))
+    # argument checks: unsupported width, missing operands, a sum output without a second addend, misaligned pointers
+    assert lib.layernorm_wide_forward_bf16(ptr(a), None, ptr(gamma), ptr(beta), rows, 200, eps, ptr(y), None, ptr(mean), ptr(rstd), None) != 0
+    assert lib.layernorm_wide_forward_bf16(ptr(a), None, ptr(gamma), ptr(beta), rows, C, eps, ptr(y), ptr(y), ptr(mean), ptr(rstd), None) != 0
+    assert lib.layernorm_wide_forward_bf16(None, None, ptr(gamma), ptr(beta), rows, C, eps, ptr(y), None, ptr(mean), ptr(rstd), None) != 0
+    assert lib.layernorm_wide_backward_bf16(ptr(dy) + 2, None, ptr(x_saved), ptr(gamma), ptr(mean), ptr(rstd), rows, C, ptr(dx), None) != 0
+
+
 @unchanged_since_gpu_run
 @pytest.mark.parametrize("rows,with_b", [(700, True), (129, False)])
 def test_add_layernorm_forward_and_backward_against_torch(lib, rows, with_b):

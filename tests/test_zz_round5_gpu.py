@@ -37,8 +37,8 @@ def test_host_route_self_check_switches_the_routes_on():
     try:
         before = torch.cuda.get_rng_state(DEV).clone()
         verdict = routes.validate(step, criterion, batch, log=print)
-        assert verdict == {"residual_gradient_in_gemm": "on", "one_launch_box_head": "on"}, verdict
-        assert routes.state() == {"residual_gradient_in_gemm": True, "one_launch_box_head": True}
+        assert verdict == {"residual_gradient_in_gemm": "on", "one_launch_box_head": "on", "fused_wide_layer_norm": "on"}, verdict
+        assert all(routes.state().values())
         assert torch.equal(before, torch.cuda.get_rng_state(DEV))
         assert all(p.grad is None for p in step.parameters())
         # a broken route: the one-launch box head returns boxes shifted by a constant -> its gradients differ -> stays off
@@ -53,7 +53,7 @@ def test_host_route_self_check_switches_the_routes_on():
         finally:
             decoder.BoxHeadFunction.forward = staticmethod(real)
         assert verdict["residual_gradient_in_gemm"] == "on" and verdict["one_launch_box_head"].startswith("off (self-check failed")
-        assert routes.state() == {"residual_gradient_in_gemm": True, "one_launch_box_head": False}
+        assert routes.state() == {"residual_gradient_in_gemm": True, "one_launch_box_head": False, "fused_wide_layer_norm": True}
     finally:
         routes.set_all(False)
 
@@ -99,3 +99,62 @@ def test_two_rank_bench_prints_one_line():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["config"]["parallelism"].startswith("dp2 (")
     assert set(d["config"]["host_routes"]) == set(routes.GPU_ONLY_ROUTES)
     assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
+
+
+@pytest.mark.parametrize("C,form", [(192, "pre_norm"), (384, "pre_norm"), (768, "plain"), (1536, "pre_norm"), (96, "plain")])
+def test_wide_layer_norm_against_torch(C, form):
+    """csrc/layernorm_wide.hip through norm.residual_pre_norm (the Swin blocks' add + LayerNorm, models/swin/swin_transformer.py:
+    386-401) against the plain ops it replaces: the sum bit for bit, y within one bfloat16 rounding, the input gradient of both
+    addends (LN'(dy) + the residual path's gradient) within 2^-6 of float32 PyTorch on the same operands."""
+    from rlipv2_amd import norm
+    torch.manual_seed(C)
+    rows = (3, 1111)
+    ln = torch.nn.LayerNorm(C).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        ln.weight.add_(0.1 * torch.randn(C, device=DEV).to(torch.bfloat16))
+        ln.bias.add_(0.1 * torch.randn(C, device=DEV).to(torch.bfloat16))
+    for p in ln.parameters():
+        p.requires_grad_(False)                                   # (frozen, as in the Swin backbones)
+    a0 = torch.randn(*rows, C, device=DEV).to(torch.bfloat16)
+    b0 = (0.5 * torch.randn(*rows, C, device=DEV)).to(torch.bfloat16) if form == "pre_norm" else None
+    gs, gy = torch.randn(*rows, C, device=DEV).to(torch.bfloat16), torch.randn(*rows, C, device=DEV).to(torch.bfloat16)
+    res = {}
+    for fused in (True, False):
+        norm.fused_wide_layer_norm = fused
+        try:
+            a = a0.clone().requires_grad_(True)
+            b = None if b0 is None else b0.clone().requires_grad_(True)
+            s, y = norm.residual_pre_norm(a, b, ln)
+            if fused:
+                assert "Wide" in type(y.grad_fn).__name__, type(y.grad_fn).__name__
+            ((s.float() * gs.float()).sum() + (y.float() * gy.float()).sum()).backward()
+            res[fused] = [s.detach().float(), y.detach().float(), a.grad.float()] + ([b.grad.float()] if b is not None else [])
+        finally:
+            norm.fused_wide_layer_norm = False
+    assert torch.equal(res[True][0], res[False][0])
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=2.0 ** -7, atol=2.0 ** -7)
+    # float32 reference of the gradient on the same (rounded) sum
+    x = res[False][0].clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x, (C,), ln.weight.float(), ln.bias.float(), ln.eps)
+    ((x * gs.float()).sum() + (ref * gy.float()).sum()).backward()
+    for g in res[True][2:]:
+        torch.testing.assert_close(g, x.grad, rtol=2.0 ** -6, atol=2.0 ** -6 * float(x.grad.abs().max()))
+
+
+def test_swin_step_with_the_fused_norms_matches_the_plain_ops():
+    """routes.validate on a small Swin-L train step (configs 4-5): the fused add + LayerNorm route reproduces the plain step."""
+    from rlipv2_amd import train
+    torch.manual_seed(0)
+    margs = parseda.default_args(num_queries=40, enc_layers=2, dec_layers=2)
+    model, criterion = train.build_training(margs, device=DEV, with_text_encoder=True, backbone_name="swin_large")
+    train.to_bf16(model)
+    model.train()
+    step = train.ParSeDATrainStep(model)
+    batch = train.synthetic_batch(2, 224, 288, n_obj=13, n_verb=7, triplets=3, device=DEV, seed=1)
+    batch[0].tensors = batch[0].tensors.to(torch.bfloat16)
+    train.freeze_parameters_without_gradient(step, criterion, batch)
+    try:
+        verdict = routes.validate(step, criterion, batch, log=print)
+        assert verdict["fused_wide_layer_norm"] == "on", verdict
+    finally:
+        routes.set_all(False)

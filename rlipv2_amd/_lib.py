@@ -37,6 +37,8 @@ EXPORTS = (
     # include/rlipv2_alif.h
     "alif_attention_supported", "alif_attention_padded_tv", "alif_attention_forward_bf16",
     "alif_attention_softmax_backward_bf16",
+    # include/rlipv2_swin.h
+    "window_attention_supported", "window_attention_forward_bf16", "window_attention_backward_bf16",
     # include/rlipv2_elementwise.h
     "add_relu_bf16", "affine_relu_bf16", "affine_relu_backward_bf16",
     # include/rlipv2_groupnorm.h
@@ -151,6 +153,10 @@ def lib() -> ctypes.CDLL:
     L.alif_attention_softmax_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, f32, i, i, i, i, vp, vp, vp, vp]
     L.alif_attention_softmax_backward_bf16.restype = i
     L.alif_attention_supported.restype = L.alif_attention_padded_tv.restype = L.alif_attention_forward_bf16.restype = i
+    L.window_attention_supported.argtypes = [i, i, i, i]
+    L.window_attention_forward_bf16.argtypes = [vp, vp, vp, vp, i, i, i, i, f32, vp, vp]
+    L.window_attention_backward_bf16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, f32, vp, vp]
+    L.window_attention_supported.restype = L.window_attention_forward_bf16.restype = L.window_attention_backward_bf16.restype = i
     L.add_relu_bf16.argtypes = [vp, vp, vp, lg, vp]
     L.add_relu_bf16.restype = i
     L.affine_relu_bf16.argtypes = [vp, vp, vp, vp, lg, i, vp]

@@ -1,0 +1,407 @@
+// window_attention.hip -- the window attention of the Swin backbones (BASELINE configs 4-5; reference
+// models/swin/swin_transformer.py:221-301, WindowAttention.forward) as ONE kernel per direction for gfx950:
+//
+//   S = scale Q K^T + relative-position bias (+ the shift mask of the window)      [N, N], N = window_size^2 <= 64
+//   P = softmax_j(S),   O = P V                                                     head_dim 32
+//
+// As PyTorch ops that is matmul + add + float32 softmax + cast + matmul (and their backward), each a pass over the
+// [B, windows, heads, N, N] attention tensor -- 40 M elements per block at 800 x 1333 in stage 0.  Here a WAVE owns one
+// (window, head) at a time and nothing N x N ever leaves the CU:
+//   * S^T = K Q^T on v_mfma_f32_32x32x16_bf16 with the operand fragments loaded straight from the packed qkv tensor (16
+//     bytes per lane, k-contiguous as the projection leaves them): in the C layout of that instruction a LANE holds one
+//     QUERY (column) and its registers run over the KEYS (rows), so the softmax is 2 x 32 in-lane operations and one
+//     exchange with the other half-wave -- no cross-lane reduction trees;
+//   * the relative-position bias of the wave's head lives in registers for all the windows the wave walks (the table is
+//     handed over transposed and padded to 64 x 64 with -30000 in the padded KEY rows: that is also the padding mask);
+//     the shift mask of the few windows that have one is added from a compact table of distinct masks;
+//   * P goes through the wave's own LDS tile as bfloat16 (a lane writes the row of its query, 8 bytes at a time; the A
+//     fragments of P V are 16-byte reads of that row), V through a transposed LDS tile; O = P V on the same instruction.
+// The backward recomputes S and P from Q and K (8 MFMAs) instead of saving them:
+//   dV = P^T dO,  dP^T = V dO^T,  dS = P o (dP - rowsum(P o dP)),  dQ = scale dS K,  dK = scale dS^T Q
+// with dS leaving through LDS in both orientations.  Written in round 5 without a GPU: checked on the lane-level model
+// of tools/emu/ against float32 PyTorch (tests/test_dense_emulated.py), NOT yet run on hardware; the host side keeps it
+// behind the self-checked route `fused_window_attention` (rlipv2_amd/routes.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rlipv2_msda.h"
+#include "../../include/rlipv2_swin.h"
+#include "once_per_device.h"
+
+#ifndef MSDA_DYNAMIC_LDS
+#define MSDA_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
+#ifndef MSDA_ASM_FENCE
+#define MSDA_ASM_FENCE() asm volatile("" ::: "memory")
+#endif
+// the lanes of ONE wave hand data to each other through LDS: program order is enough on the hardware (a wave's LDS
+// operations complete in order), the compiler must not move memory operations across; a wave barrier in the host model
+#define WATT_WAVE_SYNC() do { MSDA_ASM_FENCE(); __builtin_amdgcn_wave_barrier(); MSDA_ASM_FENCE(); } while (0)
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int HD = 32;                  // head dimension (every Swin preset: C / heads = 32)
+constexpr int NP = 64;                  // tokens per window, padded (window_size <= 8)
+constexpr int WAVES = 4, THREADS = WAVES * 64;
+constexpr int P_STRIDE = NP + 8;        // bf16 per row of an [NP][NP] LDS tile (+ 16 bytes: rows on different banks)
+constexpr int T_STRIDE = NP + 8;        // bf16 per row of a transposed operand tile [HD][NP]
+constexpr int FWD_WAVE_LDS = (NP * P_STRIDE + HD * T_STRIDE) * 2;                   // P | V^T
+constexpr int BWD_WAVE_LDS = (2 * NP * P_STRIDE + 3 * HD * T_STRIDE) * 2;          // X^T (P^T, then dS^T) | dS | K^T | Q^T | dO^T
+constexpr float kPadBias = -30000.f;    // what the padded key rows of the bias table hold
+
+__device__ __forceinline__ float bf(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint32_t rne(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return rne(a) | (rne(b) << 16); }
+
+union Frag {
+    uint4 u;
+    bf16x8 v;
+};
+
+__device__ __forceinline__ Frag load_frag(const uint16_t *p, bool ok)
+{
+    Frag f;
+    f.u = ok ? *reinterpret_cast<const uint4 *>(p) : make_uint4(0u, 0u, 0u, 0u);
+    return f;
+}
+__device__ __forceinline__ Frag lds_frag(const uint16_t *p)
+{
+    Frag f;
+    f.u = *reinterpret_cast<const uint4 *>(p);
+    return f;
+}
+
+// C / D layout of v_mfma_f32_32x32x16: lane -> column (lane & 31), register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+// (alif_attention.hip runs the same instruction with the same layouts on the hardware)
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// the task of a wave: head `head`, windows first, first + step, ... < windows
+struct Task { int head, first, step; bool any; };
+
+__device__ __forceinline__ Task task_of(int heads, int windows)
+{
+    const int g = blockIdx.x * WAVES + (threadIdx.x >> 6);          // global wave index: head fastest
+    const int chunks = (gridDim.x * WAVES) / heads;                  // whole groups of `heads` waves
+    Task t;
+    t.head = g % heads;
+    t.first = g / heads;
+    t.step = chunks;
+    t.any = t.first < chunks && t.first < windows;
+    return t;
+}
+
+// S^T = scale K Q^T + bias^T (+ mask^T): s[jt][it][r] = logit of key jt * 32 + acc_row(r), query it * 32 + (lane & 31)
+// -> softmax over the keys, in place: s becomes P^T.  Returns nothing else: the backward recomputes, nothing is saved.
+__device__ __forceinline__ void logits_and_softmax(const uint16_t *qw, const uint16_t *kw, int row_stride, int N, float scale,
+                                                   const float (&bias)[2][2][16], const float *mask_t, int lane,
+                                                   f32x16 (&s)[2][2])
+{
+    const int li = lane & 31, kg = (lane >> 5) * 8;
+    Frag a[2][2], b[2][2];                                           // [tile][k-step]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int tok = t * 32 + li;
+            a[t][ks] = load_frag(kw + (size_t)tok * row_stride + ks * 16 + kg, tok < N);
+            b[t][ks] = load_frag(qw + (size_t)tok * row_stride + ks * 16 + kg, tok < N);
+        }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[jt][it][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                s[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jt][ks].v, b[it][ks].v, s[jt][it], 0, 0, 0);
+        }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[jt][it][r] * scale + bias[jt][it][r];
+                if (mask_t) v += mask_t[(jt * 32 + acc_row(r, lane)) * NP + it * 32 + li];
+                s[jt][it][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                      // the other half-wave holds the other 32 keys
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(s[jt][it][r] - mx);
+                s[jt][it][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[jt][it][r] *= inv;
+    }
+}
+
+// x^T registers (lane = query column, registers = key rows) -> LDS tile rows[query][key] as bfloat16: the lane's 4
+// consecutive keys of a register group leave as one 8-byte store
+__device__ __forceinline__ void store_rows(uint16_t *tile, const f32x16 (&x)[2][2], int lane)
+{
+    const int li = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int j0 = jt * 32 + 8 * g + 4 * half;
+                *reinterpret_cast<uint2 *>(tile + (it * 32 + li) * P_STRIDE + j0) =
+                    make_uint2(pack2(x[jt][it][4 * g], x[jt][it][4 * g + 1]), pack2(x[jt][it][4 * g + 2], x[jt][it][4 * g + 3]));
+            }
+}
+
+// x^T registers -> LDS tile cols[key][query] as bfloat16 (for a fixed register the 32 lanes of a half-wave write 32
+// consecutive queries)
+__device__ __forceinline__ void store_cols(uint16_t *tile, const f32x16 (&x)[2][2], int lane)
+{
+    const int li = lane & 31;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tile[(jt * 32 + acc_row(r, lane)) * P_STRIDE + it * 32 + li] = (uint16_t)rne(x[jt][it][r]);
+}
+
+// rows [token][32 channels] of one (window, head) in global memory -> transposed LDS tile [channel][token]; lane = token
+__device__ __forceinline__ void stage_transposed(uint16_t *tile, const uint16_t *src, int row_stride, int N, int lane)
+{
+    uint4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        v[c] = lane < N ? *reinterpret_cast<const uint4 *>(src + (size_t)lane * row_stride + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t w[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[(c * 8 + 2 * e) * T_STRIDE + lane] = (uint16_t)(w[e] & 0xffffu);
+            tile[(c * 8 + 2 * e + 1) * T_STRIDE + lane] = (uint16_t)(w[e] >> 16);
+        }
+    }
+}
+
+// out[rows of A][32 channels] = A [NP x NP, LDS rows] x B^T [32 x NP, transposed LDS tile]: two row tiles of 32
+__device__ __forceinline__ void product_rows(const uint16_t *a_tile, const uint16_t *bt_tile, int lane, f32x16 (&o)[2])
+{
+    const int li = lane & 31, kg = (lane >> 5) * 8;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[rt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NP / 16; ++ks) {
+            const Frag a = lds_frag(a_tile + (rt * 32 + li) * P_STRIDE + ks * 16 + kg);
+            const Frag b = lds_frag(bt_tile + li * T_STRIDE + ks * 16 + kg);
+            o[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, o[rt], 0, 0, 0);
+        }
+    }
+}
+
+// o[rt][r]: row rt * 32 + acc_row(r), channel lane & 31 -> global rows of `row_stride` elements, scaled
+__device__ __forceinline__ void store_product(uint16_t *dst, int row_stride, int N, float scale, const f32x16 (&o)[2], int lane)
+{
+    const int li = lane & 31;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = rt * 32 + acc_row(r, lane);
+            if (i < N) dst[(size_t)i * row_stride + li] = (uint16_t)rne(o[rt][r] * scale);
+        }
+}
+
+__device__ __forceinline__ void load_bias(const float *bias_t, int head, int lane, float (&bias)[2][2][16])
+{
+    const int li = lane & 31;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                bias[jt][it][r] = bias_t[((size_t)head * NP + jt * 32 + acc_row(r, lane)) * NP + it * 32 + li];
+}
+
+__global__ __launch_bounds__(THREADS) void window_attention_forward_kernel(
+    const uint16_t *__restrict__ qkv, const float *__restrict__ bias_t, const float *__restrict__ mask_t,
+    const int *__restrict__ mask_id, int windows, int windows_per_image, int heads, int N, float scale,
+    uint16_t *__restrict__ out)
+{
+    MSDA_DYNAMIC_LDS(unsigned char, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t *Pl = reinterpret_cast<uint16_t *>(lds + wave * FWD_WAVE_LDS);
+    uint16_t *Vt = Pl + NP * P_STRIDE;
+    const Task t = task_of(heads, windows);
+    if (!t.any) return;
+    const int C = heads * HD, row_stride = 3 * C;
+    float bias[2][2][16];
+    load_bias(bias_t, t.head, lane, bias);
+    for (int w = t.first; w < windows; w += t.step) {
+        const uint16_t *base = qkv + (size_t)w * N * row_stride + t.head * HD;
+        const int mid = mask_id ? mask_id[w % windows_per_image] : -1;
+        f32x16 s[2][2];
+        logits_and_softmax(base, base + C, row_stride, N, scale, bias, mid >= 0 ? mask_t + (size_t)mid * NP * NP : nullptr, lane, s);
+        WATT_WAVE_SYNC();                                            // the previous window's tiles are no longer read
+        store_rows(Pl, s, lane);
+        stage_transposed(Vt, base + 2 * C, row_stride, N, lane);
+        WATT_WAVE_SYNC();
+        f32x16 o[2];
+        product_rows(Pl, Vt, lane, o);
+        store_product(out + (size_t)w * N * C + t.head * HD, C, N, 1.f, o, lane);
+    }
+}
+
+// d_qkv of one (window, head) from qkv and d_out; see the file header for the formulas
+__global__ __launch_bounds__(THREADS) void window_attention_backward_kernel(
+    const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ d_out, const float *__restrict__ bias_t,
+    const float *__restrict__ mask_t, const int *__restrict__ mask_id, int windows, int windows_per_image, int heads, int N,
+    float scale, uint16_t *__restrict__ d_qkv)
+{
+    MSDA_DYNAMIC_LDS(unsigned char, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, kg = (lane >> 5) * 8;
+    uint16_t *Xt = reinterpret_cast<uint16_t *>(lds + wave * BWD_WAVE_LDS);     // [key][query]: P^T, later dS^T
+    uint16_t *dSl = Xt + NP * P_STRIDE;                                         // [query][key]
+    uint16_t *Kt = dSl + NP * P_STRIDE, *Qt = Kt + HD * T_STRIDE, *dOt = Qt + HD * T_STRIDE;
+    const Task t = task_of(heads, windows);
+    if (!t.any) return;
+    const int C = heads * HD, row_stride = 3 * C;
+    float bias[2][2][16];
+    load_bias(bias_t, t.head, lane, bias);
+    for (int w = t.first; w < windows; w += t.step) {
+        const uint16_t *base = qkv + (size_t)w * N * row_stride + t.head * HD;
+        const uint16_t *dob = d_out + (size_t)w * N * C + t.head * HD;
+        uint16_t *gb = d_qkv + (size_t)w * N * row_stride + t.head * HD;
+        const int mid = mask_id ? mask_id[w % windows_per_image] : -1;
+        f32x16 p[2][2];
+        logits_and_softmax(base, base + C, row_stride, N, scale, bias, mid >= 0 ? mask_t + (size_t)mid * NP * NP : nullptr, lane, p);
+        // dP^T = V dO^T: same layout as P^T (lane = query, registers = keys)
+        f32x16 dp[2][2];
+        {
+            Frag a[2][2], b[2][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int tok = tt * 32 + li;
+                    a[tt][ks] = load_frag(base + 2 * C + (size_t)tok * row_stride + ks * 16 + kg, tok < N);
+                    b[tt][ks] = load_frag(dob + (size_t)tok * C + ks * 16 + kg, tok < N);
+                }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dp[jt][it][r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        dp[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jt][ks].v, b[it][ks].v, dp[jt][it], 0, 0, 0);
+                }
+        }
+        WATT_WAVE_SYNC();                                            // the previous window's tiles are no longer read
+        store_cols(Xt, p, lane);                                     // P^T for dV = P^T dO
+        stage_transposed(dOt, dob, C, N, lane);
+        stage_transposed(Kt, base + C, row_stride, N, lane);
+        stage_transposed(Qt, base, row_stride, N, lane);
+        // dS = P o (dP - sum_j P dP), per query (lane), in place in dp
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            float dot = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dot += p[jt][it][r] * dp[jt][it][r];
+            dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[jt][it][r] = p[jt][it][r] * (dp[jt][it][r] - dot);
+        }
+        store_rows(dSl, dp, lane);
+        WATT_WAVE_SYNC();
+        f32x16 o[2];
+        product_rows(Xt, dOt, lane, o);                              // dV[key][ch] = sum_query P^T[key][query] dO[query][ch]
+        store_product(gb + 2 * C, row_stride, N, 1.f, o, lane);
+        product_rows(dSl, Kt, lane, o);                              // dQ[query][ch] = scale sum_key dS[query][key] K[key][ch]
+        store_product(gb, row_stride, N, scale, o, lane);
+        WATT_WAVE_SYNC();                                            // P^T has been read: its tile takes dS^T
+        store_cols(Xt, dp, lane);
+        WATT_WAVE_SYNC();
+        product_rows(Xt, Qt, lane, o);                               // dK[key][ch] = scale sum_query dS^T[key][query] Q[query][ch]
+        store_product(gb + C, row_stride, N, scale, o, lane);
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int grid_for(int windows, int heads)
+{
+    // enough waves for every CU (256 CUs x 8) in whole groups of `heads` waves; a wave keeps its head's bias in registers
+    int chunks = 4096 / heads;
+    if (chunks < 1) chunks = 1;
+    if (chunks > windows) chunks = windows;
+    return (chunks * heads + WAVES - 1) / WAVES;
+}
+
+}  // namespace
+
+extern "C" int window_attention_supported(int windows, int heads, int tokens, int head_dim)
+{
+    return windows >= 1 && heads >= 1 && heads <= 1024 && tokens >= 1 && tokens <= NP && head_dim == HD &&
+           (long)windows * tokens * heads * HD * 3 < (1L << 31);
+}
+
+extern "C" int window_attention_forward_bf16(const void *qkv, const float *bias_t, const float *mask_t, const int *mask_id,
+                                             int windows, int windows_per_image, int heads, int tokens, float scale, void *out,
+                                             void *stream)
+{
+    if (!window_attention_supported(windows, heads, tokens, HD) || windows_per_image < 1) return MSDA_ERR_BAD_SHAPE;
+    if (!qkv || !bias_t || !out || ((mask_t == nullptr) != (mask_id == nullptr))) return MSDA_ERR_NULL_POINTER;
+    if (!aligned16(qkv) || !aligned16(out)) return MSDA_ERR_ALIGNMENT;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(window_attention_forward_kernel, dim3(grid_for(windows, heads)), dim3(THREADS), WAVES * FWD_WAVE_LDS,
+                       (hipStream_t)stream, (const uint16_t *)qkv, bias_t, mask_t, mask_id, windows, windows_per_image, heads,
+                       tokens, scale, (uint16_t *)out);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}
+
+extern "C" int window_attention_backward_bf16(const void *qkv, const void *d_out, const float *bias_t, const float *mask_t,
+                                              const int *mask_id, int windows, int windows_per_image, int heads, int tokens,
+                                              float scale, void *d_qkv, void *stream)
+{
+    if (!window_attention_supported(windows, heads, tokens, HD) || windows_per_image < 1) return MSDA_ERR_BAD_SHAPE;
+    if (!qkv || !d_out || !bias_t || !d_qkv || ((mask_t == nullptr) != (mask_id == nullptr))) return MSDA_ERR_NULL_POINTER;
+    if (!aligned16(qkv) || !aligned16(d_out) || !aligned16(d_qkv)) return MSDA_ERR_ALIGNMENT;
+    RLIPV2_ONCE_PER_DEVICE(      // more than 64 KB of dynamic LDS has to be asked for
+        (void)hipFuncSetAttribute((const void *)window_attention_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  WAVES * BWD_WAVE_LDS));
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(window_attention_backward_kernel, dim3(grid_for(windows, heads)), dim3(THREADS), WAVES * BWD_WAVE_LDS,
+                       (hipStream_t)stream, (const uint16_t *)qkv, (const uint16_t *)d_out, bias_t, mask_t, mask_id, windows,
+                       windows_per_image, heads, tokens, scale, (uint16_t *)d_qkv);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}

@@ -21,7 +21,7 @@ def _declared_functions(cpu=False):
             continue
         text = open(os.path.join(ROOT, "include", header)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        names += re.findall(r"\b((?:msda|linear|add_layernorm|layernorm_wide|adamw|alif_attention|add_relu|affine_relu|groupnorm_tokens|dab|hoi_assign)_[a-z0-9_]+|add_relu_bf16)\s*\(", text)
+        names += re.findall(r"\b((?:msda|linear|add_layernorm|layernorm_wide|adamw|alif_attention|window_attention|add_relu|affine_relu|groupnorm_tokens|dab|hoi_assign)_[a-z0-9_]+|add_relu_bf16)\s*\(", text)
     return sorted(set(names))
 
 

@@ -392,3 +392,70 @@ def test_mfma_expand_gemm_against_torch(lib, T, N, mask, bias, relu):
     torch.testing.assert_close(c.float(), want, rtol=2.0 ** -7, atol=2.0 ** -8)
     if mask:
         assert bool((c[mk.float() <= 0] == 0).all())
+
+
+def _window_attention_reference(qkv, bias, mask, mask_id, wpi, scale):
+    """WindowAttention's core (reference models/swin/swin_transformer.py:272-297) in float32 on the bf16 operands"""
+    W, N, _, h, d = qkv.shape
+    q, k, v = (qkv[:, :, t].permute(0, 2, 1, 3).float() for t in range(3))           # [W, h, N, d]
+    attn = (q * scale) @ k.transpose(-2, -1) + bias[None]
+    if mask is not None:
+        ids = mask_id[torch.arange(W) % wpi]
+        add = torch.where(ids[:, None, None] >= 0, mask[ids.clamp_min(0)], torch.zeros(()))
+        attn = attn + add[:, None]
+    p = attn.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(W, N, h * d), p
+
+
+def _padded_transposed(t, N, pad_rows):
+    """[..., N, N] (query, key) -> [..., 64, 64] (key, query), `pad_rows` in the key rows >= N, 0 elsewhere"""
+    out = torch.zeros(*t.shape[:-2], 64, 64)
+    out[..., N:, :] = pad_rows
+    out[..., :N, :N] = t.transpose(-2, -1)
+    return out.contiguous()
+
+
+@pytest.mark.parametrize("N,heads,windows,masked", [(49, 6, 5, True), (49, 3, 2, False), (64, 4, 3, True), (16, 12, 4, False)])
+def test_window_attention_against_torch(lib, N, heads, windows, masked):
+    """csrc/window_attention.hip (round 5, never run on hardware) on the lane-level model: forward and backward of the Swin
+    window attention against float32 PyTorch on the same bf16 operands.  N = 49 (window 7) exercises the padded keys /
+    queries, `masked` the shift masks through the compact table, heads not a multiple of the 4 waves of a workgroup the
+    wave-to-task mapping."""
+    torch.manual_seed(N + heads)
+    d, wpi = 32, max(1, windows - 1)
+    scale = d ** -0.5
+    qkv = (0.8 * torch.randn(windows, N, 3, heads, d)).to(torch.bfloat16)
+    bias = 0.5 * torch.randn(heads, N, N)
+    mask = mask_id = None
+    if masked:
+        region = torch.randint(0, 3, (2, N))
+        mask = torch.where(region[:, :, None] != region[:, None, :], torch.tensor(-100.0), torch.tensor(0.0))   # 2 distinct masks
+        mask_id = torch.tensor(([-1, 0, 1, -1, 1] * wpi)[:wpi], dtype=torch.int32)
+    bias_t = _padded_transposed(bias, N, -30000.0)
+    mask_t = _padded_transposed(mask, N, 0.0) if masked else None
+    out = torch.zeros(windows, N, heads * d, dtype=torch.bfloat16)
+    lib.window_attention_supported.argtypes = [ci] * 4
+    assert lib.window_attention_supported(windows, heads, N, d) == 1 and lib.window_attention_supported(windows, heads, 65, d) == 0
+    lib.window_attention_forward_bf16.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, vp, vp]
+    assert lib.window_attention_forward_bf16(ptr(qkv), ptr(bias_t), ptr(mask_t) if masked else None, ptr(mask_id) if masked else None,
+                                             windows, wpi, heads, N, scale, ptr(out), None) == 0
+    q32 = qkv.float().requires_grad_(True)
+    ref, p = _window_attention_reference(q32, bias, mask, mask_id.long() if masked else None, wpi, scale)
+    # one bfloat16 rounding of the probabilities and of the result
+    torch.testing.assert_close(out.float(), ref.detach(), rtol=2.0 ** -6, atol=2.0 ** -6 * float(ref.abs().max()))
+    d_out = torch.randn(windows, N, heads * d).to(torch.bfloat16)
+    ref.backward(d_out.float())
+    d_qkv = torch.full_like(qkv, float("nan"))
+    lib.window_attention_backward_bf16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, vp, vp]
+    assert lib.window_attention_backward_bf16(ptr(qkv), ptr(d_out), ptr(bias_t), ptr(mask_t) if masked else None,
+                                              ptr(mask_id) if masked else None, windows, wpi, heads, N, scale, ptr(d_qkv), None) == 0
+    assert torch.isfinite(d_qkv.float()).all()                      # every element written
+    want = q32.grad
+    for t, name in enumerate(("dq", "dk", "dv")):
+        got, w = d_qkv[:, :, t].float(), want[:, :, t]
+        err = float((got - w).abs().max()) / float(w.abs().max())
+        assert err < 2.0 ** -5, (name, err)                          # bf16 probabilities / dS in the products, bf16 results
+    # argument checks
+    assert lib.window_attention_forward_bf16(ptr(qkv), None, None, None, windows, wpi, heads, N, scale, ptr(out), None) != 0
+    assert lib.window_attention_forward_bf16(ptr(qkv), ptr(bias_t), ptr(bias_t), None, windows, wpi, heads, N, scale, ptr(out), None) != 0
+    assert lib.window_attention_backward_bf16(ptr(qkv), ptr(d_out), ptr(bias_t), None, None, windows, 0, heads, N, scale, ptr(d_qkv), None) != 0

@@ -11,9 +11,9 @@
 //     bytes per lane, k-contiguous as the projection leaves them): in the C layout of that instruction a LANE holds one
 //     QUERY (column) and its registers run over the KEYS (rows), so the softmax is 2 x 32 in-lane operations and one
 //     exchange with the other half-wave -- no cross-lane reduction trees;
-//   * the relative-position bias of the wave's head lives in registers for all the windows the wave walks (the table is
-//     handed over transposed and padded to 64 x 64 with -30000 in the padded KEY rows: that is also the padding mask);
-//     the shift mask of the few windows that have one is added from a compact table of distinct masks;
+//   * the relative-position bias is handed over transposed and padded to 64 x 64 with -30000 in the padded KEY rows (that
+//     is also the padding mask): for a fixed key the 32 lanes of a half-wave read 32 consecutive floats of a 16 KB table
+//     that stays in the cache; the shift mask of the few windows that have one comes from a compact table of distinct masks;
 //   * P goes through the wave's own LDS tile as bfloat16 (a lane writes the row of its query, 8 bytes at a time; the A
 //     fragments of P V are 16-byte reads of that row), V through a transposed LDS tile; O = P V on the same instruction.
 // The backward recomputes S and P from Q and K (8 MFMAs) instead of saving them:
@@ -26,7 +26,6 @@
 
 #include "../../include/rlipv2_msda.h"
 #include "../../include/rlipv2_swin.h"
-#include "once_per_device.h"
 
 #ifndef MSDA_DYNAMIC_LDS
 #define MSDA_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
@@ -45,14 +44,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int HD = 32;                  // head dimension (every Swin preset: C / heads = 32)
 constexpr int NP = 64;                  // tokens per window, padded (window_size <= 8)
-constexpr int WAVES = 4, THREADS = WAVES * 64;
+constexpr int WAVES = 2, THREADS = WAVES * 64;    // (LDS per wave decides the waves per CU: small workgroups pack best)
 constexpr int P_STRIDE = NP + 8;        // bf16 per row of an [NP][NP] LDS tile (+ 16 bytes: rows on different banks)
 constexpr int T_STRIDE = NP + 8;        // bf16 per row of a transposed operand tile [HD][NP]
 constexpr int FWD_WAVE_LDS = (NP * P_STRIDE + HD * T_STRIDE) * 2;                   // P | V^T
-constexpr int BWD_WAVE_LDS = (2 * NP * P_STRIDE + 3 * HD * T_STRIDE) * 2;          // X^T (P^T, then dS^T) | dS | K^T | Q^T | dO^T
-constexpr float kPadBias = -30000.f;    // what the padded key rows of the bias table hold
+constexpr int BWD_WAVE_LDS = (2 * NP * P_STRIDE + HD * T_STRIDE) * 2;              // X^T (P^T, then dS^T) | dS | dO^T, then K^T, then Q^T
 
-__device__ __forceinline__ float bf(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ uint32_t rne(float f)
 {
     const uint32_t u = __float_as_uint(f);
@@ -98,92 +95,107 @@ __device__ __forceinline__ Task task_of(int heads, int windows)
     return t;
 }
 
-// S^T = scale K Q^T + bias^T (+ mask^T): s[jt][it][r] = logit of key jt * 32 + acc_row(r), query it * 32 + (lane & 31)
-// -> softmax over the keys, in place: s becomes P^T.  Returns nothing else: the backward recomputes, nothing is saved.
-__device__ __forceinline__ void logits_and_softmax(const uint16_t *qw, const uint16_t *kw, int row_stride, int N, float scale,
-                                                   const float (&bias)[2][2][16], const float *mask_t, int lane,
-                                                   f32x16 (&s)[2][2])
+// operand fragments of one 32-token tile of a [token][row_stride] matrix: [k-step] (16 channels each), zero for tokens >= N
+__device__ __forceinline__ void load_tile_frags(const uint16_t *src, int row_stride, int N, int tile, int lane, Frag (&f)[2])
 {
-    const int li = lane & 31, kg = (lane >> 5) * 8;
-    Frag a[2][2], b[2][2];                                           // [tile][k-step]
+    const int tok = tile * 32 + (lane & 31), kg = (lane >> 5) * 8;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int ks = 0; ks < 2; ++ks) f[ks] = load_frag(src + (size_t)tok * row_stride + ks * 16 + kg, tok < N);
+}
+
+// x^T[jt][r] = sum over the 32 channels of  rows[key jt * 32 + acc_row(r)] . cols[this tile's query lane & 31]
+__device__ __forceinline__ void product_keys_by_queries(const Frag (&rows)[2][2], const Frag (&cols)[2], f32x16 (&x)[2])
+{
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int tok = t * 32 + li;
-            a[t][ks] = load_frag(kw + (size_t)tok * row_stride + ks * 16 + kg, tok < N);
-            b[t][ks] = load_frag(qw + (size_t)tok * row_stride + ks * 16 + kg, tok < N);
-        }
+    for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+        for (int r = 0; r < 16; ++r) x[jt][r] = 0.f;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[jt][it][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                s[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jt][ks].v, b[it][ks].v, s[jt][it], 0, 0, 0);
-        }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[jt][it][r] * scale + bias[jt][it][r];
-                if (mask_t) v += mask_t[(jt * 32 + acc_row(r, lane)) * NP + it * 32 + li];
-                s[jt][it][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                      // the other half-wave holds the other 32 keys
-        float sum = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __expf(s[jt][it][r] - mx);
-                s[jt][it][r] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[jt][it][r] *= inv;
+        for (int ks = 0; ks < 2; ++ks) x[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rows[jt][ks].v, cols[ks].v, x[jt], 0, 0, 0);
     }
 }
 
-// x^T registers (lane = query column, registers = key rows) -> LDS tile rows[query][key] as bfloat16: the lane's 4
+// logits of one query tile (s[jt][r]: key jt * 32 + acc_row(r), query it * 32 + (lane & 31)), in place:
+// s <- softmax over the keys of  scale s + bias^T (+ mask^T).  The bias of the wave's head is read from the (cache-resident)
+// table for every window: holding it in 64 registers halved the waves a SIMD can keep.
+__device__ __forceinline__ void softmax_keys(f32x16 (&s)[2], float scale, const float *bias_h, const float *mask_w, int it, int lane)
+{
+    const int q = it * 32 + (lane & 31);
+    float add[2][16];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[jt][r] = bias_h[(jt * 32 + acc_row(r, lane)) * NP + q];
+    if (mask_w) {                                                    // (wave-uniform)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) add[jt][r] += mask_w[(jt * 32 + acc_row(r, lane)) * NP + q];
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[jt][r] = s[jt][r] * scale + add[jt][r];
+            mx = fmaxf(mx, s[jt][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                          // the other half-wave holds the other 32 keys
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[jt][r] = __expf(s[jt][r] - mx);
+            sum += s[jt][r];
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[jt][r] *= inv;
+}
+
+// x^T registers of query tile `it` (lane = query, registers = keys) -> LDS tile rows[query][key] as bfloat16: the lane's 4
 // consecutive keys of a register group leave as one 8-byte store
-__device__ __forceinline__ void store_rows(uint16_t *tile, const f32x16 (&x)[2][2], int lane)
+__device__ __forceinline__ void store_rows(uint16_t *tile, const f32x16 (&x)[2], int it, int lane)
 {
     const int li = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int j0 = jt * 32 + 8 * g + 4 * half;
-                *reinterpret_cast<uint2 *>(tile + (it * 32 + li) * P_STRIDE + j0) =
-                    make_uint2(pack2(x[jt][it][4 * g], x[jt][it][4 * g + 1]), pack2(x[jt][it][4 * g + 2], x[jt][it][4 * g + 3]));
-            }
+        for (int g = 0; g < 4; ++g) {
+            const int j0 = jt * 32 + 8 * g + 4 * half;
+            *reinterpret_cast<uint2 *>(tile + (it * 32 + li) * P_STRIDE + j0) =
+                make_uint2(pack2(x[jt][4 * g], x[jt][4 * g + 1]), pack2(x[jt][4 * g + 2], x[jt][4 * g + 3]));
+        }
 }
 
-// x^T registers -> LDS tile cols[key][query] as bfloat16 (for a fixed register the 32 lanes of a half-wave write 32
-// consecutive queries)
-__device__ __forceinline__ void store_cols(uint16_t *tile, const f32x16 (&x)[2][2], int lane)
+// x^T registers of query tile `it` -> LDS tile cols[key][query] as bfloat16 (for a fixed register the 32 lanes of a
+// half-wave write 32 consecutive queries)
+__device__ __forceinline__ void store_cols(uint16_t *tile, const f32x16 (&x)[2], int it, int lane)
 {
     const int li = lane & 31;
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int r = 0; r < 16; ++r) tile[(jt * 32 + acc_row(r, lane)) * P_STRIDE + it * 32 + li] = (uint16_t)rne(x[jt][r]);
+}
+
+// LDS tile rows[a][b] -> LDS tile cols[b][a]; lane = row a
+__device__ __forceinline__ void transpose_tile(uint16_t *dst, const uint16_t *src, int lane)
+{
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                tile[(jt * 32 + acc_row(r, lane)) * P_STRIDE + it * 32 + li] = (uint16_t)rne(x[jt][it][r]);
+    for (int c = 0; c < NP / 8; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + lane * P_STRIDE + c * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dst[(c * 8 + 2 * e) * P_STRIDE + lane] = (uint16_t)(w[e] & 0xffffu);
+            dst[(c * 8 + 2 * e + 1) * P_STRIDE + lane] = (uint16_t)(w[e] >> 16);
+        }
+    }
 }
 
 // rows [token][32 channels] of one (window, head) in global memory -> transposed LDS tile [channel][token]; lane = token
@@ -204,46 +216,26 @@ __device__ __forceinline__ void stage_transposed(uint16_t *tile, const uint16_t 
     }
 }
 
-// out[rows of A][32 channels] = A [NP x NP, LDS rows] x B^T [32 x NP, transposed LDS tile]: two row tiles of 32
-__device__ __forceinline__ void product_rows(const uint16_t *a_tile, const uint16_t *bt_tile, int lane, f32x16 (&o)[2])
+// row tile `rt` of  A [NP x NP, LDS rows] x B^T [32 x NP, transposed LDS tile]  -> global rows of `row_stride` elements,
+// scaled: o[r] = row rt * 32 + acc_row(r), channel lane & 31
+__device__ __forceinline__ void product_tile_store(const uint16_t *a_tile, const uint16_t *bt_tile, int rt, uint16_t *dst,
+                                                   int row_stride, int N, float scale, int lane)
 {
     const int li = lane & 31, kg = (lane >> 5) * 8;
+    f32x16 o;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[rt][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < NP / 16; ++ks) {
-            const Frag a = lds_frag(a_tile + (rt * 32 + li) * P_STRIDE + ks * 16 + kg);
-            const Frag b = lds_frag(bt_tile + li * T_STRIDE + ks * 16 + kg);
-            o[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, o[rt], 0, 0, 0);
-        }
+    for (int ks = 0; ks < NP / 16; ++ks) {
+        const Frag a = lds_frag(a_tile + (rt * 32 + li) * P_STRIDE + ks * 16 + kg);
+        const Frag b = lds_frag(bt_tile + li * T_STRIDE + ks * 16 + kg);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, o, 0, 0, 0);
     }
-}
-
-// o[rt][r]: row rt * 32 + acc_row(r), channel lane & 31 -> global rows of `row_stride` elements, scaled
-__device__ __forceinline__ void store_product(uint16_t *dst, int row_stride, int N, float scale, const f32x16 (&o)[2], int lane)
-{
-    const int li = lane & 31;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = rt * 32 + acc_row(r, lane);
-            if (i < N) dst[(size_t)i * row_stride + li] = (uint16_t)rne(o[rt][r] * scale);
-        }
-}
-
-__device__ __forceinline__ void load_bias(const float *bias_t, int head, int lane, float (&bias)[2][2][16])
-{
-    const int li = lane & 31;
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                bias[jt][it][r] = bias_t[((size_t)head * NP + jt * 32 + acc_row(r, lane)) * NP + it * 32 + li];
+    for (int r = 0; r < 16; ++r) {
+        const int i = rt * 32 + acc_row(r, lane);
+        if (i < N) dst[(size_t)i * row_stride + li] = (uint16_t)rne(o[r] * scale);
+    }
 }
 
 __global__ __launch_bounds__(THREADS) void window_attention_forward_kernel(
@@ -258,20 +250,27 @@ __global__ __launch_bounds__(THREADS) void window_attention_forward_kernel(
     const Task t = task_of(heads, windows);
     if (!t.any) return;
     const int C = heads * HD, row_stride = 3 * C;
-    float bias[2][2][16];
-    load_bias(bias_t, t.head, lane, bias);
+    const float *bias_h = bias_t + (size_t)t.head * NP * NP;
     for (int w = t.first; w < windows; w += t.step) {
         const uint16_t *base = qkv + (size_t)w * N * row_stride + t.head * HD;
         const int mid = mask_id ? mask_id[w % windows_per_image] : -1;
-        f32x16 s[2][2];
-        logits_and_softmax(base, base + C, row_stride, N, scale, bias, mid >= 0 ? mask_t + (size_t)mid * NP * NP : nullptr, lane, s);
+        const float *mask_w = mid >= 0 ? mask_t + (size_t)mid * NP * NP : nullptr;
+        Frag kf[2][2];
+        load_tile_frags(base + C, row_stride, N, 0, lane, kf[0]);
+        load_tile_frags(base + C, row_stride, N, 1, lane, kf[1]);
         WATT_WAVE_SYNC();                                            // the previous window's tiles are no longer read
-        store_rows(Pl, s, lane);
         stage_transposed(Vt, base + 2 * C, row_stride, N, lane);
-        WATT_WAVE_SYNC();
-        f32x16 o[2];
-        product_rows(Pl, Vt, lane, o);
-        store_product(out + (size_t)w * N * C + t.head * HD, C, N, 1.f, o, lane);
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) {                             // one tile of 32 queries at a time (register budget)
+            Frag qf[2];
+            load_tile_frags(base, row_stride, N, it, lane, qf);
+            f32x16 s[2];
+            product_keys_by_queries(kf, qf, s);
+            softmax_keys(s, scale, bias_h, mask_w, it, lane);
+            store_rows(Pl, s, it, lane);
+            WATT_WAVE_SYNC();
+            product_tile_store(Pl, Vt, it, out + (size_t)w * N * C + t.head * HD, C, N, 1.f, lane);
+        }
     }
 }
 
@@ -283,76 +282,66 @@ __global__ __launch_bounds__(THREADS) void window_attention_backward_kernel(
 {
     MSDA_DYNAMIC_LDS(unsigned char, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 31, kg = (lane >> 5) * 8;
     uint16_t *Xt = reinterpret_cast<uint16_t *>(lds + wave * BWD_WAVE_LDS);     // [key][query]: P^T, later dS^T
     uint16_t *dSl = Xt + NP * P_STRIDE;                                         // [query][key]
-    uint16_t *Kt = dSl + NP * P_STRIDE, *Qt = Kt + HD * T_STRIDE, *dOt = Qt + HD * T_STRIDE;
+    uint16_t *Tt = dSl + NP * P_STRIDE;                                         // [channel][token]: dO^T, then K^T, then Q^T
     const Task t = task_of(heads, windows);
     if (!t.any) return;
     const int C = heads * HD, row_stride = 3 * C;
-    float bias[2][2][16];
-    load_bias(bias_t, t.head, lane, bias);
+    const float *bias_h = bias_t + (size_t)t.head * NP * NP;
     for (int w = t.first; w < windows; w += t.step) {
         const uint16_t *base = qkv + (size_t)w * N * row_stride + t.head * HD;
         const uint16_t *dob = d_out + (size_t)w * N * C + t.head * HD;
         uint16_t *gb = d_qkv + (size_t)w * N * row_stride + t.head * HD;
         const int mid = mask_id ? mask_id[w % windows_per_image] : -1;
-        f32x16 p[2][2];
-        logits_and_softmax(base, base + C, row_stride, N, scale, bias, mid >= 0 ? mask_t + (size_t)mid * NP * NP : nullptr, lane, p);
-        // dP^T = V dO^T: same layout as P^T (lane = query, registers = keys)
-        f32x16 dp[2][2];
-        {
-            Frag a[2][2], b[2][2];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int tok = tt * 32 + li;
-                    a[tt][ks] = load_frag(base + 2 * C + (size_t)tok * row_stride + ks * 16 + kg, tok < N);
-                    b[tt][ks] = load_frag(dob + (size_t)tok * C + ks * 16 + kg, tok < N);
-                }
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dp[jt][it][r] = 0.f;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-                        dp[jt][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[jt][ks].v, b[it][ks].v, dp[jt][it], 0, 0, 0);
-                }
-        }
+        const float *mask_w = mid >= 0 ? mask_t + (size_t)mid * NP * NP : nullptr;
+        Frag kf[2][2], vf[2][2];
+        load_tile_frags(base + C, row_stride, N, 0, lane, kf[0]);
+        load_tile_frags(base + C, row_stride, N, 1, lane, kf[1]);
+        load_tile_frags(base + 2 * C, row_stride, N, 0, lane, vf[0]);
+        load_tile_frags(base + 2 * C, row_stride, N, 1, lane, vf[1]);
         WATT_WAVE_SYNC();                                            // the previous window's tiles are no longer read
-        store_cols(Xt, p, lane);                                     // P^T for dV = P^T dO
-        stage_transposed(dOt, dob, C, N, lane);
-        stage_transposed(Kt, base + C, row_stride, N, lane);
-        stage_transposed(Qt, base, row_stride, N, lane);
-        // dS = P o (dP - sum_j P dP), per query (lane), in place in dp
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        stage_transposed(Tt, dob, C, N, lane);
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) {                             // one tile of 32 queries at a time (register budget)
+            Frag qf[2], gf[2];
+            load_tile_frags(base, row_stride, N, it, lane, qf);
+            load_tile_frags(dob, C, N, it, lane, gf);
+            f32x16 p[2], dp[2];
+            product_keys_by_queries(kf, qf, p);
+            softmax_keys(p, scale, bias_h, mask_w, it, lane);
+            product_keys_by_queries(vf, gf, dp);                     // dP^T = V dO^T: same layout as P^T
+            // dS = P o (dP - sum over the keys of P dP), per query (lane), in place in dp
             float dot = 0.f;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dot += p[jt][it][r] * dp[jt][it][r];
+                for (int r = 0; r < 16; ++r) dot += p[jt][r] * dp[jt][r];
             dot += __shfl_xor(dot, 32, 64);
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[jt][it][r] = p[jt][it][r] * (dp[jt][it][r] - dot);
+                for (int r = 0; r < 16; ++r) dp[jt][r] = p[jt][r] * (dp[jt][r] - dot);
+            store_cols(Xt, p, it, lane);                             // P^T for dV = P^T dO
+            store_rows(dSl, dp, it, lane);
         }
-        store_rows(dSl, dp, lane);
         WATT_WAVE_SYNC();
-        f32x16 o[2];
-        product_rows(Xt, dOt, lane, o);                              // dV[key][ch] = sum_query P^T[key][query] dO[query][ch]
-        store_product(gb + 2 * C, row_stride, N, 1.f, o, lane);
-        product_rows(dSl, Kt, lane, o);                              // dQ[query][ch] = scale sum_key dS[query][key] K[key][ch]
-        store_product(gb, row_stride, N, scale, o, lane);
-        WATT_WAVE_SYNC();                                            // P^T has been read: its tile takes dS^T
-        store_cols(Xt, dp, lane);
+#pragma unroll 1
+        for (int rt = 0; rt < 2; ++rt)                               // dV[key][ch] = sum_query P^T[key][query] dO[query][ch]
+            product_tile_store(Xt, Tt, rt, gb + 2 * C, row_stride, N, 1.f, lane);
         WATT_WAVE_SYNC();
-        product_rows(Xt, Qt, lane, o);                               // dK[key][ch] = scale sum_query dS^T[key][query] Q[query][ch]
-        store_product(gb + C, row_stride, N, scale, o, lane);
+        stage_transposed(Tt, base + C, row_stride, N, lane);
+        transpose_tile(Xt, dSl, lane);                               // P^T has been read: its tile takes dS^T
+        WATT_WAVE_SYNC();
+#pragma unroll 1
+        for (int rt = 0; rt < 2; ++rt)                               // dQ[query][ch] = scale sum_key dS[query][key] K[key][ch]
+            product_tile_store(dSl, Tt, rt, gb, row_stride, N, scale, lane);
+        WATT_WAVE_SYNC();
+        stage_transposed(Tt, base, row_stride, N, lane);
+        WATT_WAVE_SYNC();
+#pragma unroll 1
+        for (int rt = 0; rt < 2; ++rt)                               // dK[key][ch] = scale sum_query dS^T[key][query] Q[query][ch]
+            product_tile_store(Xt, Tt, rt, gb + C, row_stride, N, scale, lane);
     }
 }
 
@@ -396,9 +385,7 @@ extern "C" int window_attention_backward_bf16(const void *qkv, const void *d_out
     if (!window_attention_supported(windows, heads, tokens, HD) || windows_per_image < 1) return MSDA_ERR_BAD_SHAPE;
     if (!qkv || !d_out || !bias_t || !d_qkv || ((mask_t == nullptr) != (mask_id == nullptr))) return MSDA_ERR_NULL_POINTER;
     if (!aligned16(qkv) || !aligned16(d_out) || !aligned16(d_qkv)) return MSDA_ERR_ALIGNMENT;
-    RLIPV2_ONCE_PER_DEVICE(      // more than 64 KB of dynamic LDS has to be asked for
-        (void)hipFuncSetAttribute((const void *)window_attention_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  WAVES * BWD_WAVE_LDS));
+    static_assert(WAVES * BWD_WAVE_LDS <= 64 * 1024 && WAVES * FWD_WAVE_LDS <= 64 * 1024, "dynamic LDS within the default limit");
     (void)hipGetLastError();
     hipLaunchKernelGGL(window_attention_backward_kernel, dim3(grid_for(windows, heads)), dim3(THREADS), WAVES * BWD_WAVE_LDS,
                        (hipStream_t)stream, (const uint16_t *)qkv, (const uint16_t *)d_out, bias_t, mask_t, mask_id, windows,

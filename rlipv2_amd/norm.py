@@ -115,16 +115,25 @@ def add_layer_norm(a, b, norm: torch.nn.LayerNorm):
 fused_wide_layer_norm = False
 
 
+def _on_device(t) -> bool:
+    """the kernels take device pointers (the lane-level model of tools/emu/ replaces this in tests/test_swin_fused_emulated.py)"""
+    return t.is_cuda
+
+
 def wide_supported(x, norm) -> bool:
     """the fused route can take `norm(x)`: CUDA bfloat16, a supported width, frozen affine parameters (the reference freezes
     every norm of its Swin backbones, models/swin/backbone.py:66-69; trainable ones keep PyTorch's op and its dgamma / dbeta)"""
     w, b = norm.weight, norm.bias
-    if not (fused_wide_layer_norm and enabled and x.is_cuda and x.dtype == torch.bfloat16 and w is not None and b is not None
+    if not (fused_wide_layer_norm and enabled and _on_device(x) and x.dtype == torch.bfloat16 and w is not None and b is not None
             and w.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and len(norm.normalized_shape) == 1
             and not w.requires_grad and not b.requires_grad and not torch.is_autocast_enabled()):
         return False
     C = x.shape[-1]
     return norm.normalized_shape[0] == C and bool(_lib.lib().layernorm_wide_supported(x.numel() // C, C))
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else None
 
 
 def _wide_forward(a, b, weight, bias, eps):
@@ -137,7 +146,7 @@ def _wide_forward(a, b, weight, bias, eps):
     _check(_lib.lib().layernorm_wide_forward_bf16(a.data_ptr(), None if b is None else b.data_ptr(), weight.data_ptr(),
                                                   bias.data_ptr(), rows, C, float(eps), y.data_ptr(),
                                                   None if b is None else s.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                  torch.cuda.current_stream(a.device).cuda_stream), "layernorm_wide_forward")
+                                                  _stream(a)), "layernorm_wide_forward")
     roofline.add(roofline.tensor_bytes(a, b, weight, bias, y, s, mean, rstd))
     return s, y, mean, rstd
 
@@ -147,8 +156,7 @@ def _wide_backward(dy, ds, x, weight, mean, rstd):
     dx = torch.empty_like(x)
     _check(_lib.lib().layernorm_wide_backward_bf16(dy.data_ptr(), None if ds is None else ds.data_ptr(), x.data_ptr(),
                                                    weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x.numel() // C, C,
-                                                   dx.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
-           "layernorm_wide_backward")
+                                                   dx.data_ptr(), _stream(x)), "layernorm_wide_backward")
     roofline.add(roofline.tensor_bytes(dy, ds, x, weight, mean, rstd, dx))
     return dx
 

@@ -24,6 +24,7 @@ from torch import nn
 
 from .blocks import NestedTensor, PositionEmbeddingSine
 from .linear import token_linear
+from . import norm as _norm
 from .norm import residual_pre_norm
 
 
@@ -80,6 +81,73 @@ def shift_mask(Hp, Wp, ws, shift, device):
     return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
 
 
+# GPU-only route (csrc/window_attention.hip; never run on hardware): OFF until rlipv2_amd/routes.validate() has compared the
+# Swin train step with it against the PyTorch op sequence on the caller's own model and batch.
+fused_window_attention = False
+
+
+def _padded_transposed(t, n, pad_rows):
+    """[..., n, n] (query, key) -> float32 [..., 64, 64] (key, query): `pad_rows` in the key rows >= n, 0 elsewhere -- the
+    layout include/rlipv2_swin.h asks for (a lane of the kernel owns a query and walks the keys)"""
+    out = t.new_zeros(*t.shape[:-2], 64, 64, dtype=torch.float32)
+    out[..., n:, :] = pad_rows
+    out[..., :n, :n] = t.transpose(-2, -1).float()
+    return out.contiguous()
+
+
+def compact_masks(mask):
+    """[nW, N, N] additive shift masks -> (mask_t [K, 64, 64] float32 of the K distinct non-zero masks, mask_id [nW] int32,
+    -1 = no mask): all interior windows of a shifted layout share the zero mask, the right / bottom / corner ones a few more"""
+    nW, n = mask.shape[0], mask.shape[-1]
+    flat = mask.reshape(nW, -1)
+    distinct, inverse = torch.unique(flat, dim=0, return_inverse=True)
+    nonzero = distinct.abs().sum(1) != 0
+    remap = torch.cumsum(nonzero.to(torch.int32), 0) - 1
+    ids = torch.where(nonzero[inverse], remap[inverse], torch.full_like(remap[inverse], -1)).to(torch.int32)
+    kept = distinct[nonzero].view(-1, n, n)
+    if kept.shape[0] == 0:
+        return None, None
+    return _padded_transposed(kept, n, 0.0), ids.contiguous()
+
+
+class WindowAttentionFunction(torch.autograd.Function):
+    """softmax(scale q k^T + bias (+ mask)) v over all windows and heads of a block: one launch per direction on the packed qkv
+    tensor (include/rlipv2_swin.h); the backward recomputes the probabilities, nothing N x N is saved.  The bias table is frozen
+    (the reference freezes it, models/swin/backbone.py:66-69) -- no gradient for it here."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias_t, mask_t, mask_id, heads, scale):
+        from . import _lib
+        Bw, nW, N = qkv.shape[0], qkv.shape[1], qkv.shape[2]
+        qkv = qkv.contiguous()
+        out = torch.empty(Bw, nW, N, heads * 32, dtype=qkv.dtype, device=qkv.device)
+        st = _lib.lib().window_attention_forward_bf16(
+            qkv.data_ptr(), bias_t.data_ptr(), None if mask_t is None else mask_t.data_ptr(),
+            None if mask_id is None else mask_id.data_ptr(), Bw * nW, nW, heads, N, float(scale), out.data_ptr(),
+            _norm._stream(qkv))
+        if st:
+            raise RuntimeError("window_attention_forward: " + _lib.strerror(st))
+        ctx.save_for_backward(qkv, bias_t, mask_t, mask_id)
+        ctx.heads, ctx.scale = heads, float(scale)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        from . import _lib
+        qkv, bias_t, mask_t, mask_id = ctx.saved_tensors
+        Bw, nW, N = qkv.shape[0], qkv.shape[1], qkv.shape[2]
+        d_out = d_out.contiguous()
+        d_qkv = torch.empty_like(qkv)
+        st = _lib.lib().window_attention_backward_bf16(
+            qkv.data_ptr(), d_out.data_ptr(), bias_t.data_ptr(), None if mask_t is None else mask_t.data_ptr(),
+            None if mask_id is None else mask_id.data_ptr(), Bw * nW, nW, ctx.heads, N, ctx.scale, d_qkv.data_ptr(),
+            _norm._stream(qkv))
+        if st:
+            raise RuntimeError("window_attention_backward: " + _lib.strerror(st))
+        return d_qkv, None, None, None, None, None
+
+
 class WindowAttention(nn.Module):
     def __init__(self, dim, window_size, num_heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
@@ -107,11 +175,41 @@ class WindowAttention(nn.Module):
             self._bias_key = key
         return self._bias
 
+    def fused_supported(self, x):
+        t = self.relative_position_bias_table
+        return (fused_window_attention and _norm._on_device(x) and x.dtype == torch.bfloat16 and not t.requires_grad
+                and self.dim // self.num_heads == 32 and self.ws * self.ws <= 64 and not torch.is_autocast_enabled()
+                and not (self.training and self.attn_drop > 0) and self.qkv.weight.dtype == torch.bfloat16)
+
+    def bias_table_t(self):
+        """the frozen relative-position bias as the kernel reads it: float32 [heads, 64, 64], transposed, -30000 in the padded
+        key rows (include/rlipv2_swin.h); cached like `bias` (frozen tables only)"""
+        t = self.relative_position_bias_table
+        key = (t._version, t.data_ptr(), "t")
+        if getattr(self, "_bias_t_key", None) != key:
+            with torch.no_grad():
+                n = self.ws * self.ws
+                b = t[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1)
+                self._bias_t = _padded_transposed(b, n, -30000.0)
+            self._bias_t_key = key
+        return self._bias_t
+
     def forward(self, x, mask):
         """x [B, nW, N, C]; mask None or [nW, N, N] -> [B, nW, N, C]"""
         B, nW, N, C = x.shape
         h = self.num_heads
-        qkv = token_linear(x, self.qkv.weight, self.qkv.bias).view(B, nW, N, 3, h, C // h).permute(3, 0, 1, 4, 2, 5)
+        packed = token_linear(x, self.qkv.weight, self.qkv.bias)
+        if self.fused_supported(x):
+            # one kernel per direction on the packed projection (csrc/window_attention.hip); `mask` arrives with its compact
+            # table attached by BasicLayer (mask.compact = (mask_t, mask_id))
+            # (compact == (None, None): every window's mask is zero; a mask without the attribute keeps the op sequence)
+            compact = (None, None) if mask is None else getattr(mask, "compact", None)
+            if compact is not None:
+                mask_t, mask_id = compact
+                out = WindowAttentionFunction.apply(packed.view(B, nW, N, 3, h, C // h), self.bias_table_t(), mask_t, mask_id, h,
+                                                    (C // h) ** -0.5)
+                return self.proj_drop(token_linear(out, self.proj.weight, self.proj.bias))
+        qkv = packed.view(B, nW, N, 3, h, C // h).permute(3, 0, 1, 4, 2, 5)
         add = self.bias(x.dtype)[None, None]                      # [1, 1, h, N, N]
         if mask is not None:
             add = add + mask.to(x.dtype)[None, :, None]           # [1, nW, h, N, N]
@@ -212,7 +310,9 @@ class BasicLayer(nn.Module):
         Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
         key = (Hp, Wp, str(x.device))
         if key not in self._masks:
-            self._masks[key] = shift_mask(Hp, Wp, ws, self.shift, x.device)
+            m = shift_mask(Hp, Wp, ws, self.shift, x.device)
+            m.compact = compact_masks(m) if ws * ws <= 64 else (None, None)      # (for the fused attention kernel)
+            self._masks[key] = m
         mask = self._masks[key]
         pending = None
         for blk in self.blocks:

@@ -106,7 +106,8 @@ def test_route_verdicts():
 
 def test_routes_are_off_in_the_package_and_stay_off_without_a_gpu():
     from rlipv2_amd import train
-    assert routes.state() == {"residual_gradient_in_gemm": False, "one_launch_box_head": False, "fused_wide_layer_norm": False}
+    assert routes.state() == {"residual_gradient_in_gemm": False, "one_launch_box_head": False, "fused_wide_layer_norm": False,
+                              "fused_window_attention": False}
     samples, text, targets = train.synthetic_batch(1, 32, 32, n_obj=3, n_verb=2, triplets=1, device="cpu")
     verdict = routes.validate(None, None, (samples, text, targets))
     assert all(v.startswith("off (not applicable") for v in verdict.values()) and not any(routes.state().values())

@@ -37,7 +37,7 @@ def test_host_route_self_check_switches_the_routes_on():
     try:
         before = torch.cuda.get_rng_state(DEV).clone()
         verdict = routes.validate(step, criterion, batch, log=print)
-        assert verdict == {"residual_gradient_in_gemm": "on", "one_launch_box_head": "on", "fused_wide_layer_norm": "on"}, verdict
+        assert verdict == {k: "on" for k in routes.GPU_ONLY_ROUTES}, verdict
         assert all(routes.state().values())
         assert torch.equal(before, torch.cuda.get_rng_state(DEV))
         assert all(p.grad is None for p in step.parameters())
@@ -53,7 +53,7 @@ def test_host_route_self_check_switches_the_routes_on():
         finally:
             decoder.BoxHeadFunction.forward = staticmethod(real)
         assert verdict["residual_gradient_in_gemm"] == "on" and verdict["one_launch_box_head"].startswith("off (self-check failed")
-        assert routes.state() == {"residual_gradient_in_gemm": True, "one_launch_box_head": False, "fused_wide_layer_norm": True}
+        assert routes.state() == {k: k != "one_launch_box_head" for k in routes.GPU_ONLY_ROUTES}
     finally:
         routes.set_all(False)
 
@@ -155,6 +155,44 @@ def test_swin_step_with_the_fused_norms_matches_the_plain_ops():
     train.freeze_parameters_without_gradient(step, criterion, batch)
     try:
         verdict = routes.validate(step, criterion, batch, log=print)
-        assert verdict["fused_wide_layer_norm"] == "on", verdict
+        assert verdict["fused_wide_layer_norm"] == "on" and verdict["fused_window_attention"] == "on", verdict
     finally:
         routes.set_all(False)
+
+
+@pytest.mark.parametrize("ws,heads,shift", [(7, 6, True), (7, 12, False), (8, 3, True)])
+def test_window_attention_module_fused_against_the_op_sequence(ws, heads, shift):
+    """swin.WindowAttention with the fused kernel (csrc/window_attention.hip) against its own PyTorch op sequence (matmul + bias +
+    mask + float32 softmax + matmul, reference models/swin/swin_transformer.py:262-301) in bfloat16: output within 2^-6 of the
+    largest value, gradients of the input and of the qkv / proj parameters within 3 %."""
+    from rlipv2_amd import swin
+    torch.manual_seed(ws + heads)
+    C, B = heads * 32, 2
+    Hp, Wp = 3 * ws, 4 * ws
+    attn = swin.WindowAttention(C, ws, heads).to(DEV).to(torch.bfloat16)
+    attn.relative_position_bias_table.requires_grad_(False)        # (frozen, as in the Swin backbones)
+    with torch.no_grad():
+        attn.relative_position_bias_table.add_(0.5 * torch.randn_like(attn.relative_position_bias_table))
+    mask = None
+    if shift:
+        mask = swin.shift_mask(Hp, Wp, ws, ws // 2, DEV)
+        mask.compact = swin.compact_masks(mask)
+    nW = (Hp // ws) * (Wp // ws)
+    x0 = torch.randn(B, nW, ws * ws, C, device=DEV).to(torch.bfloat16)
+    gy = torch.randn(B, nW, ws * ws, C, device=DEV).to(torch.bfloat16)
+    res = {}
+    for fused in (True, False):
+        swin.fused_window_attention = fused
+        try:
+            for p in attn.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = attn(x, mask)
+            y.backward(gy)
+            res[fused] = [y.detach().float(), x.grad.float()] + [p.grad.float() for p in attn.parameters() if p.grad is not None]
+        finally:
+            swin.fused_window_attention = False
+    scale = float(res[False][0].abs().max())
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2.0 ** -6 * scale
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert float((a - b).norm()) <= 3e-2 * float(b.norm()), (float((a - b).norm()), float(b.norm()))

@@ -166,6 +166,8 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
     def fake(args, env, timeout):
         if args[0] == "--fwd":
             return {"model": {"quad_us": 150.0, "cell_us": 110.0}}
+        if args[0] == "--swin":
+            return {"window_attention_module_fwd_bwd": {"ops_us": 900.0, "fused_us": 300.0}}
         k = int(args[1])
         if k == 3:
             return {"error": "timed out after 75 s (child killed)"}
@@ -178,7 +180,7 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
     names = [n for n, _ in X.ARMS]
     assert arms[names[0]]["b0"]["equal_bits"] and arms[names[1]]["fused"]["equal_bits"]
     assert not arms[names[2]]["b0"]["equal_bits"] and "error" in arms[names[3]]
-    assert rep["encoder_forward_cell"]["model"]["cell_us"] == 110.0
+    assert rep["encoder_forward_cell"]["model"]["cell_us"] == 110.0 and "swin_routes" in rep
     assert "digest" not in json.dumps(rep)
     # a real child that produces nothing (here: no GPU) is an error entry, not an exception
     monkeypatch.undo()

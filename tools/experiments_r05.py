@@ -10,6 +10,8 @@ Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_
              mode 3 without the swap                                  (reference work: ms_deform_im2col_cuda.cuh:87-159, 301-403)
   patch multi   patch_dest_multi_kernel (mask-word prefetch not in a branch)
   fwd cell   cell_forward_kernel (explicit variant "cell" of the product library) against the product forward (.cuh:237-299)
+  swin       the two Swin routes of round 5 (csrc/window_attention.hip, csrc/layernorm_wide.hip; models/swin/swin_transformer.py:
+             262-301, 386-401) at the Swin-L stage-0 shapes against the PyTorch op sequences they replace
 Every backward arm must reproduce the default's three gradients BIT FOR BIT (64-bit digests of the raw bits, computed on the
 device) on the encoder shape (N = 4, 800x1333 pyramid, bf16, model-like locations), B0 signature and fused geometry route;
 time = HIP events around 20 calls of the whole backward.
@@ -90,6 +92,68 @@ def child_forward():
     print("RESULT " + json.dumps(out), flush=True)
 
 
+def child_swin():
+    """the two Swin routes of round 5 at the stage-0 shapes of Swin-L on 800 x 1333 (batch 2: 2 x 1 392 windows of 49 tokens, 6 heads,
+    192 channels): module forward + backward, fused kernel against the PyTorch op sequence -- agreement and HIP-event times"""
+    import torch
+    from rlipv2_amd import norm, swin
+    from tools.patch_check import timed
+    out = {}
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    C, heads, ws, B, Hp, Wp = 192, 6, 7, 2, 203, 336
+    attn = swin.WindowAttention(C, ws, heads).to(dev).to(torch.bfloat16)
+    attn.relative_position_bias_table.requires_grad_(False)
+    mask = swin.shift_mask(Hp, Wp, ws, ws // 2, dev)
+    mask.compact = swin.compact_masks(mask)
+    nW = (Hp // ws) * (Wp // ws)
+    x0 = torch.randn(B, nW, ws * ws, C, device=dev).to(torch.bfloat16)
+    gy = torch.randn_like(x0)
+    res, t = {}, {}
+
+    def attn_step():
+        x = x0.clone().requires_grad_(True)
+        y = attn(x, mask)
+        y.backward(gy)
+        return y.detach().float(), x.grad.float()
+    for fused in (False, True):
+        swin.fused_window_attention = fused
+        try:
+            res[fused] = attn_step()
+            torch.cuda.synchronize()
+            t[fused] = round(timed(attn_step, iters=10), 1)
+        finally:
+            swin.fused_window_attention = False
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))                                     # noqa: E731
+    out["window_attention_module_fwd_bwd"] = {"ops_us": t[False], "fused_us": t[True], "rel_l2_out": rel(res[True][0], res[False][0]),
+                                              "rel_l2_dx": rel(res[True][1], res[False][1]),
+                                              "finite": bool(torch.isfinite(res[True][0]).all() and torch.isfinite(res[True][1]).all())}
+    ln = torch.nn.LayerNorm(C).to(dev).to(torch.bfloat16)
+    for p in ln.parameters():
+        p.requires_grad_(False)
+    a0 = torch.randn(B, 200, 334, C, device=dev).to(torch.bfloat16)
+    b0 = torch.randn_like(a0)
+    g1, g2 = torch.randn_like(a0), torch.randn_like(a0)
+
+    def ln_step():
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        s_, y = norm.residual_pre_norm(a, b, ln)
+        torch.autograd.backward([s_, y], [g1, g2])
+        return y.detach().float(), a.grad.float()
+    for fused in (False, True):
+        norm.fused_wide_layer_norm = fused
+        try:
+            res[fused] = ln_step()
+            torch.cuda.synchronize()
+            t[fused] = round(timed(ln_step, iters=10), 1)
+        finally:
+            norm.fused_wide_layer_norm = False
+    out["residual_add_layer_norm_fwd_bwd"] = {"ops_us": t[False], "fused_us": t[True], "rel_l2_y": rel(res[True][0], res[False][0]),
+                                              "rel_l2_dx": rel(res[True][1], res[False][1]),
+                                              "note": "both timings include two clones of the 51 MB inputs"}
+    print("RESULT " + json.dumps(out), flush=True)
+
+
 def run_child(args, env, timeout):
     t0 = time.time()
     try:
@@ -133,6 +197,8 @@ def main(per_child_timeout=75, budget_s=200):
         report["encoder_backward_arms"] = {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
     if time.time() - t0 <= budget_s:
         report["encoder_forward_cell"] = run_child(["--fwd"], base_env, per_child_timeout)
+    if time.time() - t0 <= budget_s + 30:
+        report["swin_routes"] = run_child(["--swin"], base_env, per_child_timeout)
     report["wall_s"] = round(time.time() - t0, 1)
     return report
 
@@ -142,6 +208,8 @@ if __name__ == "__main__":
         child_backward(int(sys.argv[2]))
     elif len(sys.argv) > 1 and sys.argv[1] == "--fwd":
         child_forward()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--swin":
+        child_swin()
     else:
         rep = main()
         for name, v in rep.get("encoder_backward_arms", {}).items():

@@ -28,6 +28,12 @@ fused_geometry = True
 # fold that geometry into the sampling kernels themselves (msda.FusedMSDeformAttnFunction) when the reference points
 # need no gradient
 fused_sampling = True
+# Cross-attention with FEW queries (the decoders: 150 / 300 queries into 88 892 memory tokens): sample the UNPROJECTED memory and
+# project the few sampled rows, instead of projecting every memory token in every decoder layer (MSDeformAttn._sampled_projection).
+# OFF: the formulation is exact (CPU tests against the standard one), what it costs on the GPU depends on kernels that have not
+# been timed; rlipv2_amd/routes.validate switches it on for a step it reproduces.
+sample_then_project = False
+SAMPLE_THEN_PROJECT_MAX_FRACTION = 0.25       # taken when queries x heads <= this fraction of the memory tokens
 
 
 class _AdjacentCat(torch.autograd.Function):
@@ -177,10 +183,14 @@ class MSDeformAttn(nn.Module):
         #  or attached to the image memory by linear.shared_input for the decoders' value projections)
         if value_grad_link is None:
             value_grad_link = getattr(input_flatten, "value_grad_link", None)
-        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, grad_link=value_grad_link)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], 0.0)
-        value = value.view(N, Len_in, M, self.d_model // M)
+        stp = (sample_then_project and value_grad_link is None and L == 4 and P == 4
+               and Len_q * M <= SAMPLE_THEN_PROJECT_MAX_FRACTION * Len_in and reference_points.shape[-1] in (2, 4))
+        value = None
+        if not stp:
+            value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, grad_link=value_grad_link)
+            if input_padding_mask is not None:
+                value = value.masked_fill(input_padding_mask[..., None], 0.0)
+            value = value.view(N, Len_in, M, self.d_model // M)
 
         n_off = M * L * P * 2
         # (the two projections' parameters share one buffer: "concatenating" them is free, see adjacent_cat)
@@ -193,6 +203,10 @@ class MSDeformAttn(nn.Module):
             qproj, reference_points = MSDeformAttn.trace(self, qproj, reference_points)
         if (qproj.is_cuda and fused_geometry and L == 4 and P == 4 and reference_points.shape[-1] in (2, 4)
                 and qproj.dtype in (torch.float32, torch.bfloat16)):
+            if stp:
+                locations, weights = msda.SamplingGeometryFunction.apply(qproj, reference_points, input_spatial_shapes, M, L, P)
+                return self._sampled_projection(input_flatten, input_padding_mask, input_spatial_shapes,
+                                                input_level_start_index, locations, weights)
             if (fused_sampling and msda_function is msda.MSDeformAttnFunction and qproj.dtype == value.dtype
                     and not reference_points.requires_grad
                     and msda.fused_supported(value, input_spatial_shapes, reference_points, Len_q, L, P,
@@ -227,8 +241,41 @@ class MSDeformAttn(nn.Module):
         else:
             raise ValueError(
                 'Last dim of reference_points must be 2 or 4, but get {} instead.'.format(reference_points.shape[-1]))
-        if value.dtype == torch.bfloat16:
+        if input_flatten.dtype == torch.bfloat16:
             locations = locations.float()
+        if stp:
+            return self._sampled_projection(input_flatten, input_padding_mask, input_spatial_shapes, input_level_start_index,
+                                            locations.contiguous(), weights.contiguous())
         output = msda_function.apply(value, input_spatial_shapes, input_level_start_index,
                                      locations.contiguous(), weights.contiguous(), self.im2col_step)
         return self.output_proj(output)
+
+    def _sampled_projection(self, src, padding_mask, shapes, starts, locations, weights):
+        """The cross-attention of ms_deform_attn.py:98-118 with sampling and value projection exchanged (both are linear):
+
+            out[q, h] = sum_s a_s bilinear(value_h)(loc_s),   value_h = keep (W_h src + b_h)          (keep = 1 - padding mask)
+                      = W_h z[q, h] + b_h z1[q, h],   z[q, h] = sum_s a_s bilinear(keep src)(loc_s)  (all 256 channels),
+                                                      z1[q, h] = sum_s a_s bilinear(keep)(loc_s)      (zero padding, masked pixels)
+
+        z and z1 are the SAME op called with one "head" of 256 (1) channels and the (query, head) pairs as its queries --
+        `locations.view(N, Lq * M, 1, L, P, 2)` is a view, `src` is the value tensor as it is.  Per decoder layer that replaces
+        the [88 892, 256] x [256, 256] value projection (forward, input gradient, weight gradient over all tokens, a 45 MB
+        zero-fill) by M products [N * Lq, 256] x [256, 32]; the memory's gradient becomes a scatter of 256-channel rows."""
+        N, S, C = src.shape
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        Lq = locations.shape[1]
+        D = C // M
+        if padding_mask is not None:
+            keep = (~padding_mask).to(src.dtype)[..., None]
+            src = src * keep
+        else:
+            keep = self.__dict__.get("_ones")
+            if keep is None or keep.shape[:2] != (N, S) or keep.dtype != src.dtype or keep.device != src.device:
+                keep = self.__dict__["_ones"] = torch.ones(N, S, 1, dtype=src.dtype, device=src.device)
+        loc1 = locations.reshape(N, Lq * M, 1, L, P, 2)
+        aw1 = weights.reshape(N, Lq * M, 1, L, P)
+        z = msda_function.apply(src.reshape(N, S, 1, C), shapes, starts, loc1, aw1, self.im2col_step)          # [N, Lq M, C]
+        z1 = msda_function.apply(keep.reshape(N, S, 1, 1), shapes, starts, loc1, aw1, self.im2col_step)        # [N, Lq M, 1]
+        w = self.value_proj.weight.view(M, D, C)                                                                # rows h D .. of W
+        out = torch.einsum("nqhc,hdc->nqhd", z.view(N, Lq, M, C), w) + z1.view(N, Lq, M, 1) * self.value_proj.bias.view(M, D)
+        return token_linear(out.reshape(N, Lq, C), self.output_proj.weight, self.output_proj.bias)

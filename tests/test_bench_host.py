@@ -168,6 +168,8 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
             return {"model": {"quad_us": 150.0, "cell_us": 110.0}}
         if args[0] == "--swin":
             return {"window_attention_module_fwd_bwd": {"ops_us": 900.0, "fused_us": 300.0}}
+        if args[0] == "--stp":
+            return {"standard_us": 400.0, "sample_then_project_us": 380.0}
         k = int(args[1])
         if k == 3:
             return {"error": "timed out after 75 s (child killed)"}

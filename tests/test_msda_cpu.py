@@ -132,3 +132,57 @@ def test_edge_cases():
                                     aw.expand(3, -1, -1, -1, -1).contiguous(), 2)
     with pytest.raises(RuntimeError, match="contiguous"):
         msda.ms_deform_attn_forward(value.transpose(1, 3), shapes, starts, loc2, aw, 64)
+
+
+@pytest.mark.parametrize("nd,masked", [(4, True), (4, False), (2, True)])
+def test_sample_then_project_is_the_same_function(nd, masked):
+    """deform_attn.sample_then_project: the few-query cross-attention with sampling and value projection exchanged
+    (MSDeformAttn._sampled_projection; reference arithmetic models/ops/modules/ms_deform_attn.py:98-118) against the standard
+    order, float64 on the product's CPU op: output and the gradients of the query, the memory, the reference points and every
+    parameter agree to rounding -- with a padding mask, with samples outside the image (zero padding: the bias term must carry
+    the same bilinear coverage), 2-d and 4-d reference points."""
+    from rlipv2_amd import deform_attn
+    torch.manual_seed(7 + nd)
+    pyr = [(12, 16), (6, 8), (3, 4), (2, 2)]
+    shapes = torch.tensor(pyr)
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S, N, Lq, C = int(shapes.prod(1).sum()), 2, 5, 64
+    m = deform_attn.MSDeformAttn(C, 4, 8, 4).double()
+    with torch.no_grad():
+        m.sampling_offsets.weight.copy_(0.3 * torch.randn_like(m.sampling_offsets.weight))
+        m.attention_weights.weight.copy_(0.5 * torch.randn_like(m.attention_weights.weight))
+        m.value_proj.bias.copy_(torch.randn_like(m.value_proj.bias))
+    q0, src0 = torch.randn(N, Lq, C, dtype=torch.float64), torch.randn(N, S, C, dtype=torch.float64)
+    ref0 = torch.rand(N, Lq, 4, nd, dtype=torch.float64) * 1.2 - 0.1             # some reference points outside [0, 1]
+    if nd == 4:
+        ref0[..., 2:] = ref0[..., 2:].abs() * 0.5 + 0.05
+    mask = (torch.rand(N, S) < 0.2) if masked else None
+    go = torch.randn(N, Lq, C, dtype=torch.float64)
+    res = {}
+    for stp in (True, False):
+        deform_attn.sample_then_project = stp
+        try:
+            for p in m.parameters():
+                p.grad = None
+            q, src, ref = (t.clone().requires_grad_(True) for t in (q0, src0, ref0))
+            out = m(q, ref, src, shapes, starts, mask)
+            out.backward(go)
+            res[stp] = [out.detach(), q.grad, src.grad, ref.grad] + [p.grad for p in m.parameters()]
+        finally:
+            deform_attn.sample_then_project = False
+    assert Lq * 8 <= deform_attn.SAMPLE_THEN_PROJECT_MAX_FRACTION * S         # (the route was eligible)
+    for a, b in zip(res[True], res[False]):
+        torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-11)
+    # many queries (the encoder's self-attention): the standard order is kept whatever the switch says
+    deform_attn.sample_then_project = True
+    try:
+        big = torch.randn(N, S, C, dtype=torch.float64)
+        refs = torch.rand(N, S, 4, 2, dtype=torch.float64)
+        calls = []
+        orig = deform_attn.MSDeformAttn._sampled_projection
+        deform_attn.MSDeformAttn._sampled_projection = lambda self, *a: calls.append(1) or orig(self, *a)
+        m(big, refs, src0, shapes, starts, None)
+        assert not calls
+    finally:
+        deform_attn.sample_then_project = False
+        deform_attn.MSDeformAttn._sampled_projection = orig

@@ -286,3 +286,36 @@ def test_plain_b0_signature_without_host_shapes(lib):
             close32(gv, g["g_value_f32"])
             close32(ga, g["g_aw_f32"])
             close32(gl[keep], g["g_loc_f32"][keep])
+
+
+@pytest.mark.parametrize("D", [256, 1])
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_one_head_of_many_channels_as_sample_then_project_calls_the_op(lib, D, dt):
+    """deform_attn.sample_then_project (round 5) calls the op with ONE head of 256 channels (the unprojected memory) or of 1
+    channel (the coverage of the value projection's bias) and the (query, head) pairs as queries: M' = 1, D' in {256, 1},
+    Lq' = Lq x 8, with and without host shapes ("auto" must end on a route that takes these dimensions).  Against the oracle."""
+    rng = np.random.default_rng(5 + D)
+    pyr = np.asarray([(9, 12), (5, 6), (3, 3), (2, 2)], dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
+    S, N, Lq = int((pyr[:, 0] * pyr[:, 1]).sum()), 2, 6 * 8
+    ref = rng.uniform(-0.05, 1.05, size=(N, Lq, 2))
+    off = rng.standard_normal((N, Lq, 1, 4, 4, 2)) * 2.0
+    loc = ref[:, :, None, None, None, :] + off / np.stack([pyr[:, 1], pyr[:, 0]], -1)[None, None, None, :, None, :]
+    aw = rng.random((N, Lq, 1, 4, 4))
+    value = rng.standard_normal((N, S, 1, D)).astype(np.float32)
+    go = rng.standard_normal((N, Lq, D)).astype(np.float32)
+    if dt == BF16:
+        value, go = bf16_val(bf16_bits(value)).astype(np.float32), bf16_val(bf16_bits(go)).astype(np.float32)
+    g = dict(value=value, loc=loc.astype(np.float32), aw=(aw / aw.sum((-1, -2), keepdims=True)).astype(np.float32), grad_out=go,
+             shapes=pyr, starts=starts)
+    a = (g["value"].astype(np.float64), pyr, starts, g["loc"].astype(np.float64), g["aw"].astype(np.float64))
+    ref_out = O.forward(*a)
+    ref_gv, ref_gl, ref_ga = O.backward(*a, g["grad_out"].astype(np.float64))
+    keep = ~kink_samples(g)
+    for host_shapes in (True, False):
+        out, gv, gl, ga = lib.run("auto", "auto", dt, g, host_shapes=host_shapes)
+        tol = dict(rtol=2.0 ** -7, atol_rel=2.0 ** -7) if dt == BF16 else {}
+        close32(out, ref_out, **tol)
+        close32(gv, ref_gv, **tol)
+        close32(ga, ref_ga)
+        close32(gl[keep], ref_gl[keep])

@@ -67,6 +67,8 @@ def test_graphed_step_with_the_routes_on_matches_the_eager_plain_step():
     for mod in model.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
+        elif isinstance(getattr(mod, "dropout", None), float):      # (the ALIF attention core keeps its rate as a float, Q6)
+            mod.dropout = 0.0
     params = [p for p in step.parameters() if p.requires_grad]
     try:
         routes.set_all(False)

@@ -229,6 +229,20 @@ int msda_abi_version(void);
 const char *msda_variant_name(int variant);
 int msda_pick_variant(int backward, int dtype, int N, int S, int M, int D, int L, int Lq, int P);
 
+/* ---- one head of 256 channels, few queries (csrc/msda_rows.hip; round 5, not yet run on hardware) --------------------------
+ * Backward of msda_forward called with M = 1, D = 256: `value` = an unprojected memory [N, S, 256], the queries = (query, head)
+ * pairs (rlipv2_amd/deform_attn.py: MSDeformAttn._sampled_projection -- the decoders' cross-attention of
+ * models/ops/modules/ms_deform_attn.py:98-118 with sampling and value projection exchanged).  Same gradients as
+ * msda_backward (formulas: ms_deform_im2col_cuda.cuh:87-159) without float atomics: every row of grad_src is written exactly
+ * once (no zero-fill needed), sums in sample order (bit-repeatable).  dtype MSDA_F32 or MSDA_BF16 (src / grad_out / grad_src);
+ * sampling_loc [N, Q, L, P, 2], attn_weight [N, Q, L, P] and their gradients float32.  shapes_host: host copy of the int64
+ * [L, 2] level shapes (the launch plan is built from it); level_start on the device as everywhere. */
+int msda_rows_backward_supported(int dtype, const int64_t *shapes_host, int N, int S, int C, int L, int Q, int P);
+
+int msda_rows_backward(int dtype, const void *src, const int64_t *level_start, const int64_t *shapes_host,
+                       const void *sampling_loc, const void *attn_weight, const void *grad_out, int N, int S, int C, int L, int Q,
+                       int P, void *grad_src, void *grad_sampling_loc, void *grad_attn_weight, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ EXPORTS = (
     "msda_algorithmic_bytes", "msda_strerror", "msda_abi_version", "msda_variant_name", "msda_pick_variant",
     "msda_prepare_forward", "msda_prepare_backward", "msda_backward_workspace_bytes", "msda_backward_ws",
     "msda_backward_plan_info", "msda_forward_hs", "msda_fused_forward_hs",
-    "msda_fused_supported", "msda_fused_forward", "msda_fused_backward_ws",
+    "msda_fused_supported", "msda_fused_forward", "msda_fused_backward_ws", "msda_rows_backward_supported", "msda_rows_backward",
     # include/rlipv2_linear.h
     "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
     "linear_expand_supported", "linear_expand_bf16",
@@ -102,6 +102,9 @@ def lib() -> ctypes.CDLL:
     L.msda_fused_forward.argtypes = [i, vp, vp, vp, vp, vp, i, *dims, vp, vp, vp, vp]
     L.msda_fused_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, i, vp, *dims, vp, vp, vp, ctypes.c_size_t, vp]
     L.msda_fused_supported.restype = L.msda_fused_forward.restype = L.msda_fused_backward_ws.restype = i
+    L.msda_rows_backward_supported.argtypes = [i, vp, i, i, i, i, i, i]
+    L.msda_rows_backward.argtypes = [i, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp, vp, vp, vp]
+    L.msda_rows_backward_supported.restype = L.msda_rows_backward.restype = i
     L.msda_check_im2col_step.argtypes = [i, i]
     L.msda_check_im2col_step.restype = i
     L.msda_algorithmic_bytes.argtypes = [i, i, *dims]

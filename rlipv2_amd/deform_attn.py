@@ -274,7 +274,9 @@ class MSDeformAttn(nn.Module):
                 keep = self.__dict__["_ones"] = torch.ones(N, S, 1, dtype=src.dtype, device=src.device)
         loc1 = locations.reshape(N, Lq * M, 1, L, P, 2)
         aw1 = weights.reshape(N, Lq * M, 1, L, P)
-        z = msda_function.apply(src.reshape(N, S, 1, C), shapes, starts, loc1, aw1, self.im2col_step)          # [N, Lq M, C]
+        # (the memory's rows: on the GPU the backward of this call has its own kernels, csrc/msda_rows.hip)
+        rows_function = msda.SampleRowsFunction if (msda_function is msda.MSDeformAttnFunction and src.is_cuda) else msda_function
+        z = rows_function.apply(src.reshape(N, S, 1, C), shapes, starts, loc1, aw1, self.im2col_step)          # [N, Lq M, C]
         z1 = msda_function.apply(keep.reshape(N, S, 1, 1), shapes, starts, loc1, aw1, self.im2col_step)        # [N, Lq M, 1]
         w = self.value_proj.weight.view(M, D, C)                                                                # rows h D .. of W
         out = torch.einsum("nqhc,hdc->nqhd", z.view(N, Lq, M, C), w) + z1.view(N, Lq, M, 1) * self.value_proj.bias.view(M, D)

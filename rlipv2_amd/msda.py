@@ -270,6 +270,51 @@ class MSDeformAttnFunction(Function):
         return g_value, None, None, g_loc, g_aw, None
 
 
+class SampleRowsFunction(Function):
+    """The op with ONE head of 256 channels and the (query, head) pairs as queries (deform_attn.MSDeformAttn._sampled_projection:
+    `value` = the unprojected memory [N, S, 1, 256], sampling_locations [N, Q, 1, L, P, 2], attention_weights [N, Q, 1, L, P]).
+    Forward: the library's forward as it is.  Backward: csrc/msda_rows.hip when it takes the call (CUDA, 256 channels, float32 /
+    bfloat16, host copy of the level shapes) -- every row of the memory's gradient written once, no float atomics, sums in
+    sample order -- and the library's general backward otherwise.  Same signature and gradients as MSDeformAttnFunction."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                        attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        ctx.host_shapes = host_shapes(value_spatial_shapes) if value.is_cuda else None
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, loc, aw = ctx.saved_tensors
+        hs = ctx.host_shapes
+        N, S, M, D = value.shape
+        nL, Q, P = shapes.shape[0], loc.shape[1], loc.shape[4]
+        L = _lib.lib() if value.is_cuda else None
+        arr = (ctypes.c_int64 * len(hs))(*hs) if hs is not None else None
+        if (L is None or arr is None or M != 1 or value.dtype not in (torch.float32, torch.bfloat16) or loc.dtype != torch.float32
+                or aw.dtype != torch.float32 or not L.msda_rows_backward_supported(_DTYPES[value.dtype], arr, N, S, D, nL, Q, P)):
+            g_value, g_loc, g_aw = ms_deform_attn_backward(value, shapes, starts, loc, aw, grad_output.contiguous(),
+                                                           ctx.im2col_step, host=hs)
+            return g_value, None, None, g_loc, g_aw, None
+        go = grad_output.contiguous()
+        go = go if go.dtype == value.dtype else go.to(value.dtype)
+        g_value = torch.empty_like(value)                             # every row is written by the kernel
+        g_loc, g_aw = torch.empty_like(loc), torch.empty_like(aw)
+        with torch.cuda.device(value.device):
+            st = L.msda_rows_backward(_DTYPES[value.dtype], value.data_ptr(), starts.data_ptr(), arr, loc.data_ptr(), aw.data_ptr(),
+                                      go.data_ptr(), N, S, D, nL, Q, P, g_value.data_ptr(), g_loc.data_ptr(), g_aw.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+        if st:
+            _raise(st)
+        roofline.add(roofline.tensor_bytes(loc, aw, go, g_value, g_loc, g_aw))
+        last_variant["bwd"] = "rows"
+        return g_value, None, None, g_loc, g_aw, None
+
+
 def fused_supported(value, spatial_shapes, reference_points, Lq, L, P, need_backward):
     """Can the fused geometry + sampling kernels (msda_fused_forward / msda_fused_backward_ws) take this call?"""
     if not value.is_cuda or value.dtype not in (torch.float32, torch.bfloat16) or value.dim() != 4:

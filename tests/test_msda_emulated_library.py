@@ -319,3 +319,53 @@ def test_one_head_of_many_channels_as_sample_then_project_calls_the_op(lib, D, d
         close32(gv, ref_gv, **tol)
         close32(ga, ref_ga)
         close32(gl[keep], ref_gl[keep])
+
+
+@pytest.mark.parametrize("dt,pyr,Q", [(F32, [(9, 12), (5, 6), (3, 3), (2, 2)], 24), (BF16, [(40, 52), (16, 33), (5, 7), (3, 3)], 8)])
+def test_rows_backward_against_the_oracle(lib, dt, pyr, Q):
+    """csrc/msda_rows.hip (round 5, never run on hardware): backward of the op with ONE head of 256 channels -- the memory's
+    gradient by the ownership scatter (pixel ranges of 16 ... 128 pixels per workgroup: the second pyramid has levels with the 64- and the 32-pixel
+    range, several ranges per level and partial last ranges), location / weight gradients by the dots kernel --
+    against the oracle on the same operands; bit-repeatable; every row of grad_src written (no zero-fill by the caller)."""
+    L = lib.L
+    rng = np.random.default_rng(len(pyr) + Q + dt)
+    pyr = np.asarray(pyr, dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
+    S, N, C, P = int((pyr[:, 0] * pyr[:, 1]).sum()), 2, 256, 4
+    ref = rng.uniform(-0.05, 1.05, size=(N, Q, 2))
+    ref[:, : Q // 4] = ref[:, :1]                                        # a cluster of queries on one spot (long per-pixel sums)
+    off = rng.standard_normal((N, Q, 1, 4, P, 2)) * 2.0
+    loc = (ref[:, :, None, None, None, :] + off / np.stack([pyr[:, 1], pyr[:, 0]], -1)[None, None, None, :, None, :]).astype(np.float32)
+    aw = rng.random((N, Q, 1, 4, P))
+    aw = (aw / aw.sum((-1, -2), keepdims=True)).astype(np.float32)
+    src = rng.standard_normal((N, S, 1, C)).astype(np.float32)
+    dz = rng.standard_normal((N, Q, C)).astype(np.float32)
+    if dt == BF16:
+        src, dz = bf16_val(bf16_bits(src)).astype(np.float32), bf16_val(bf16_bits(dz)).astype(np.float32)
+    a = (src.astype(np.float64), pyr, starts, loc.astype(np.float64), aw.astype(np.float64))
+    ref_gv, ref_gl, ref_ga = O.backward(*a, dz.astype(np.float64))
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    L.msda_rows_backward_supported.argtypes = [i, vp, i, i, i, i, i, i]
+    L.msda_rows_backward.argtypes = [i, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp, vp, vp, vp]
+    p = lambda x: x.ctypes.data                                                  # noqa: E731
+    assert L.msda_rows_backward_supported(dt, p(pyr), N, S, C, 4, Q, P) == 1
+    assert L.msda_rows_backward_supported(dt, p(pyr), N, S, 128, 4, Q, P) == 0 and L.msda_rows_backward_supported(dt, p(pyr), N, S + 1, C, 4, Q, P) == 0
+    enc = (lambda x: np.ascontiguousarray(bf16_bits(x))) if dt == BF16 else (lambda x: np.ascontiguousarray(x, dtype=np.float32))
+    src_d, dz_d = enc(src), enc(dz)
+    runs = []
+    for _ in range(2):
+        g_src = np.full(src_d.shape, 0x7fc0 if dt == BF16 else np.nan, dtype=src_d.dtype)       # NaN: an unwritten row would show
+        g_loc, g_aw = np.full(loc.shape, np.nan, dtype=np.float32), np.full(aw.shape, np.nan, dtype=np.float32)
+        assert L.msda_rows_backward(dt, p(src_d), p(starts), p(pyr), p(loc), p(aw), p(dz_d), N, S, C, 4, Q, P, p(g_src), p(g_loc),
+                                    p(g_aw), None) == 0
+        runs.append((g_src.copy(), g_loc.copy(), g_aw.copy()))
+    for x, y in zip(*runs):
+        np.testing.assert_array_equal(x, y)                              # bit-repeatable
+    g_src = bf16_val(runs[0][0]).astype(np.float64) if dt == BF16 else runs[0][0].astype(np.float64)
+    assert np.isfinite(g_src).all()
+    tol = dict(rtol=2.0 ** -7, atol_rel=2.0 ** -7) if dt == BF16 else {}
+    close32(g_src, ref_gv, **tol)
+    g = dict(loc=loc, shapes=pyr)
+    keep = ~kink_samples(g)
+    close32(runs[0][2].astype(np.float64), ref_ga)
+    close32(runs[0][1].astype(np.float64)[keep], ref_gl[keep])

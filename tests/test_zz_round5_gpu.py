@@ -198,3 +198,81 @@ def test_window_attention_module_fused_against_the_op_sequence(ws, heads, shift)
     assert float((res[True][0] - res[False][0]).abs().max()) <= 2.0 ** -6 * scale
     for a, b in zip(res[True][1:], res[False][1:]):
         assert float((a - b).norm()) <= 3e-2 * float(b.norm()), (float((a - b).norm()), float(b.norm()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rows_backward_against_the_general_backward(dtype):
+    """csrc/msda_rows.hip (msda.SampleRowsFunction: the op with one head of 256 channels, the decoders' sample-then-project route)
+    against the library's general backward on the same call, bench shapes (N = 4, 800 x 1333 pyramid, 2 400 query-heads):
+    the memory's gradient within one bfloat16 rounding / 1e-4, location / weight gradients at the float32 bar away from the
+    floor() kinks; bit-repeatable; every row written (the output buffer starts as NaN)."""
+    from rlipv2_amd import msda
+    from tools.msda_inputs import PYRAMID_800x1333, level_tensors
+    torch.manual_seed(3)
+    shapes, starts = level_tensors(PYRAMID_800x1333, DEV)
+    msda.attach_host_shapes(shapes, PYRAMID_800x1333)
+    S, N, Q = int(shapes.prod(1).sum()), 4, 2400
+    src = torch.randn(N, S, 1, 256, device=DEV).to(dtype)
+    c = torch.rand(N, Q, 1, 1, 1, 2, device=DEV) * 1.1 - 0.05
+    loc = (c + 0.05 * torch.randn(N, Q, 1, 4, 4, 2, device=DEV)).contiguous()
+    aw = torch.softmax(torch.randn(N, Q, 1, 16, device=DEV), -1).view(N, Q, 1, 4, 4).contiguous()
+    dz = torch.randn(N, Q, 256, device=DEV).to(dtype)
+    res = []
+    for fn in (msda.SampleRowsFunction, msda.SampleRowsFunction, msda.MSDeformAttnFunction):
+        v, l, a = src.clone().requires_grad_(True), loc.clone().requires_grad_(True), aw.clone().requires_grad_(True)
+        out = fn.apply(v, shapes, starts, l, a, 64)
+        out.backward(dz)
+        res.append((out.detach().float(), v.grad.float(), l.grad, a.grad))
+    assert msda.last_variant.get("bwd") != "rows"                         # (the last call was the general one ...)
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)                                            # ... and the two rows calls agree bit for bit
+    assert torch.isfinite(res[0][1]).all()
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-4
+    ref = res[2]
+    assert torch.equal(res[0][0], ref[0])
+    assert float((res[0][1] - ref[1]).abs().max()) <= tol * float(ref[1].abs().max())
+    assert float((res[0][3] - ref[3]).abs().max()) <= 1e-4 * float(ref[3].abs().max())
+    g = {"loc": loc.cpu().numpy(), "shapes": shapes.cpu().numpy()}
+    from conftest import kink_samples
+    keep = torch.from_numpy(~kink_samples(g)).to(DEV)
+    assert float((res[0][2] - ref[2])[keep].abs().max()) <= 1e-4 * float(ref[2].abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sample_then_project_module_on_the_gpu(dtype):
+    """MSDeformAttn with deform_attn.sample_then_project (generic forward with M' = 1, D' = 256 + the rows backward) against the
+    standard order at a decoder-like shape: float32 within 1e-4, bfloat16 within 3e-2 of the standard route (which rounds the
+    projected values to bfloat16 before sampling; here the rounding happens after)."""
+    from rlipv2_amd import deform_attn, msda
+    torch.manual_seed(1)
+    pyr = [(50, 67), (25, 34), (13, 17), (7, 9)]
+    shapes = torch.tensor(pyr, device=DEV)
+    msda.attach_host_shapes(shapes, pyr)
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S, N, Lq, C = int(shapes.prod(1).sum()), 2, 60, 256
+    m = deform_attn.MSDeformAttn(C, 4, 8, 4).to(DEV).to(dtype)
+    with torch.no_grad():
+        m.sampling_offsets.weight.copy_((0.05 * torch.randn(m.sampling_offsets.weight.shape, device=DEV)).to(dtype))
+        m.value_proj.bias.copy_(torch.randn(C, device=DEV).to(dtype))
+    q0, src0 = torch.randn(N, Lq, C, device=DEV).to(dtype), torch.randn(N, S, C, device=DEV).to(dtype)
+    ref = torch.cat([torch.rand(N, Lq, 1, 2, device=DEV) * 1.1 - 0.05, torch.rand(N, Lq, 1, 2, device=DEV) * 0.4 + 0.05], -1)
+    ref = ref.expand(N, Lq, 4, 4).contiguous()
+    mask = torch.rand(N, S, device=DEV) < 0.1
+    go = torch.randn(N, Lq, C, device=DEV).to(dtype)
+    res = {}
+    for stp in (True, False):
+        deform_attn.sample_then_project = stp
+        try:
+            for p in m.parameters():
+                p.grad = None
+            q, src = q0.clone().requires_grad_(True), src0.clone().requires_grad_(True)
+            out = m(q, ref, src, shapes, starts, mask)
+            out.backward(go)
+            res[stp] = [out.detach().float(), q.grad.float(), src.grad.float()] + [p.grad.float() for p in m.parameters()]
+            if stp:
+                assert msda.last_variant.get("bwd") in ("rows", "generic"), msda.last_variant
+        finally:
+            deform_attn.sample_then_project = False
+    tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).norm()) <= tol * float(b.norm()) + 1e-6, (float((a - b).norm()), float(b.norm()))

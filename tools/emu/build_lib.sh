@@ -14,7 +14,7 @@ FLAGS="-x c++ -std=c++20 -O1 -fPIC -pthread -DMSDA_EMU -I$HERE/stub -I$ROOT/incl
 # host allocator's red zones; run python with LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so))
 if [ "${EMU_SANITIZE:-0}" = "1" ]; then FLAGS="$FLAGS -g -fno-omit-frame-pointer -fsanitize=address,undefined -shared-libasan"; SAN="-fsanitize=address,undefined -shared-libasan"; fi
 pids=()
-for f in msda_api msda_generic msda_quad msda_dest msda_patch msda_sparse msda_prep msda_window; do
+for f in msda_api msda_generic msda_quad msda_dest msda_patch msda_sparse msda_rows msda_prep msda_window; do
     $CXX $FLAGS -c $ROOT/rlipv2_amd/csrc/$f.hip -o $TMP/$f.o &
     pids+=($!)
 done

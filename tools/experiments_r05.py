@@ -157,7 +157,8 @@ def child_swin():
 def child_stp():
     """the decoders' cross-attention at the bench shape (N = 4, 300 queries, 88 892 memory tokens, bf16), forward + backward of one
     MSDeformAttn call: the standard order (project all memory tokens, then sample) against deform_attn.sample_then_project
-    (sample the unprojected memory on the generic kernels with M' = 1, D' = 256, then project the 2 400 sampled rows per image)"""
+    (sample the unprojected memory -- generic forward with M' = 1, D' = 256, csrc/msda_rows.hip backward --, then project the
+    2 400 sampled rows per image)"""
     import torch
     from rlipv2_amd import deform_attn
     from rlipv2_amd.msda import attach_host_shapes
@@ -198,8 +199,8 @@ def child_stp():
     print("RESULT " + json.dumps({"standard_us": t[False], "sample_then_project_us": t[True],
                                   "rel_l2_out": rel(res[True][0], res[False][0]), "rel_l2_d_src": rel(res[True][1], res[False][1]),
                                   "rel_l2_d_value_proj_weight": rel(res[True][2], res[False][2]),
-                                  "note": "both timings include a clone of the 45 MB memory; the sample-then-project backward runs "
-                                          "the generic kernel's float atomics (no few-query scatter kernel for 256-channel rows yet)"}),
+                                  "note": "both timings include a clone of the 45 MB memory; sample-then-project = generic forward "
+                                          "(M' = 1, D' = 256) + csrc/msda_rows.hip backward (ownership scatter, no atomics)"}),
           flush=True)
 
 

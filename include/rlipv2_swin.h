@@ -7,9 +7,9 @@
  * for one call over all windows and heads of a block.  attn_drop must be 0 (it is in every RLIPv2 Swin preset).
  *
  *   qkv      [windows, N, 3, heads, 32] bf16 -- the packed projection exactly as `self.qkv(x)` leaves it (:272-273)
- *   bias_t   [heads, 64, 64] float32: bias_t[h][j][i] = relative_position_bias[h][i][j] for i, j < N (TRANSPOSED), padded
- *            to 64 x 64: -30000 in the rows j >= N (padded keys never receive weight), 0 elsewhere
- *   mask_t   [K, 64, 64] float32, transposed and zero-padded like bias_t: the K distinct shift masks of the stage (:517-533);
+ *   bias_t   [heads, 64, 64] float32: bias_t[h][i][j] = relative_position_bias[h][i][j] for query i, key j < N, padded to
+ *            64 x 64: -30000 in the columns j >= N (padded keys never receive weight), 0 elsewhere
+ *   mask_t   [K, 64, 64] float32, zero-padded like bias_t: the K distinct shift masks of the stage (:517-533);
  *            mask_id [windows_per_image] int32: index into mask_t, -1 = the window has no mask.  Both NULL: no masks
  *   out      [windows, N, heads * 32] bf16 -- the layout `(attn @ v).transpose(1, 2).reshape(B_, N, C)` produces (:297)
  *   d_out    like out;  d_qkv like qkv (every element written)

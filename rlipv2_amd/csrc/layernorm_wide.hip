@@ -25,14 +25,13 @@ constexpr int MAX_BLOCKS = 2048;
 __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// two floats -> packed bfloat16 pair, round to nearest even (one v_cvt_pk_bf16_f32)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
-    auto rne = [](float f) -> uint32_t {
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    };
-    return rne(a) | (rne(b) << 16);
+    const f32x2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
 
 __device__ __forceinline__ void unpack8(const uint4 &v, float *f)

@@ -11,9 +11,9 @@
 //     bytes per lane, k-contiguous as the projection leaves them): in the C layout of that instruction a LANE holds one
 //     QUERY (column) and its registers run over the KEYS (rows), so the softmax is 2 x 32 in-lane operations and one
 //     exchange with the other half-wave -- no cross-lane reduction trees;
-//   * the relative-position bias is handed over transposed and padded to 64 x 64 with -30000 in the padded KEY rows (that
-//     is also the padding mask): for a fixed key the 32 lanes of a half-wave read 32 consecutive floats of a 16 KB table
-//     that stays in the cache; the shift mask of the few windows that have one comes from a compact table of distinct masks;
+//   * the relative-position bias is handed over padded to [64 queries][64 keys] with -30000 in the padded KEY columns (that
+//     is also the padding mask): a lane reads its query's row, 4 consecutive keys per 16-byte load, from a 16 KB table that
+//     stays in the cache; the shift mask of the few windows that have one comes from a compact table of distinct masks;
 //   * P goes through the wave's own LDS tile as bfloat16 (a lane writes the row of its query, 8 bytes at a time; the A
 //     fragments of P V are 16-byte reads of that row), V through a transposed LDS tile; O = P V on the same instruction.
 // The backward recomputes S and P from Q and K (8 MFMAs) instead of saving them:
@@ -50,13 +50,15 @@ constexpr int T_STRIDE = NP + 8;        // bf16 per row of a transposed operand 
 constexpr int FWD_WAVE_LDS = (NP * P_STRIDE + HD * T_STRIDE) * 2;                   // P | V^T
 constexpr int BWD_WAVE_LDS = (2 * NP * P_STRIDE + HD * T_STRIDE) * 2;              // X^T (P^T, then dS^T) | dS | dO^T, then K^T, then Q^T
 
-__device__ __forceinline__ uint32_t rne(float f)
+// two floats -> packed bfloat16 pair, round to nearest even: ONE v_cvt_pk_bf16_f32 on gfx950 (the bit-twiddling form is 8
+// VALU instructions per value, and the probabilities alone are 64 values per lane and window)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t pack2(float a, float b)
 {
-    const uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    const f32x2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return rne(a) | (rne(b) << 16); }
 
 union Frag {
     uint4 u;
@@ -116,21 +118,31 @@ __device__ __forceinline__ void product_keys_by_queries(const Frag (&rows)[2][2]
 }
 
 // logits of one query tile (s[jt][r]: key jt * 32 + acc_row(r), query it * 32 + (lane & 31)), in place:
-// s <- softmax over the keys of  scale s + bias^T (+ mask^T).  The bias of the wave's head is read from the (cache-resident)
+// s <- softmax over the keys of  scale s + bias (+ mask).  The bias of the wave's head is read from the (cache-resident)
 // table for every window: holding it in 64 registers halved the waves a SIMD can keep.
 __device__ __forceinline__ void softmax_keys(f32x16 (&s)[2], float scale, const float *bias_h, const float *mask_w, int it, int lane)
 {
-    const int q = it * 32 + (lane & 31);
+    // the lane's query row of the padded [64 queries][64 keys] table: registers 4 g .. 4 g + 3 of key tile jt are the 4
+    // consecutive keys jt * 32 + 8 g + 4 (lane >> 5) + 0..3 -- one 16-byte load each
+    const int q = it * 32 + (lane & 31), half = lane >> 5;
     float add[2][16];
+    const float4 *brow = reinterpret_cast<const float4 *>(bias_h + q * NP);
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) add[jt][r] = bias_h[(jt * 32 + acc_row(r, lane)) * NP + q];
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = brow[jt * 8 + 2 * g + half];
+            add[jt][4 * g] = b.x; add[jt][4 * g + 1] = b.y; add[jt][4 * g + 2] = b.z; add[jt][4 * g + 3] = b.w;
+        }
     if (mask_w) {                                                    // (wave-uniform)
+        const float4 *mrow = reinterpret_cast<const float4 *>(mask_w + q * NP);
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) add[jt][r] += mask_w[(jt * 32 + acc_row(r, lane)) * NP + q];
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = mrow[jt * 8 + 2 * g + half];
+                add[jt][4 * g] += b.x; add[jt][4 * g + 1] += b.y; add[jt][4 * g + 2] += b.z; add[jt][4 * g + 3] += b.w;
+            }
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -180,7 +192,7 @@ __device__ __forceinline__ void store_cols(uint16_t *tile, const f32x16 (&x)[2],
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile[(jt * 32 + acc_row(r, lane)) * P_STRIDE + it * 32 + li] = (uint16_t)rne(x[jt][r]);
+        for (int r = 0; r < 16; ++r) tile[(jt * 32 + acc_row(r, lane)) * P_STRIDE + it * 32 + li] = (uint16_t)(pack2(x[jt][r], 0.f) & 0xffffu);
 }
 
 // LDS tile rows[a][b] -> LDS tile cols[b][a]; lane = row a
@@ -234,7 +246,7 @@ __device__ __forceinline__ void product_tile_store(const uint16_t *a_tile, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = rt * 32 + acc_row(r, lane);
-        if (i < N) dst[(size_t)i * row_stride + li] = (uint16_t)rne(o[r] * scale);
+        if (i < N) dst[(size_t)i * row_stride + li] = (uint16_t)(pack2(o[r] * scale, 0.f) & 0xffffu);
     }
 }
 

@@ -86,12 +86,12 @@ def shift_mask(Hp, Wp, ws, shift, device):
 fused_window_attention = False
 
 
-def _padded_transposed(t, n, pad_rows):
-    """[..., n, n] (query, key) -> float32 [..., 64, 64] (key, query): `pad_rows` in the key rows >= n, 0 elsewhere -- the
-    layout include/rlipv2_swin.h asks for (a lane of the kernel owns a query and walks the keys)"""
+def _padded(t, n, pad_keys):
+    """[..., n, n] (query, key) -> float32 [..., 64, 64]: `pad_keys` in the key columns >= n, 0 elsewhere -- the layout
+    include/rlipv2_swin.h asks for (a lane of the kernel owns a query and reads 4 consecutive keys per load)"""
     out = t.new_zeros(*t.shape[:-2], 64, 64, dtype=torch.float32)
-    out[..., n:, :] = pad_rows
-    out[..., :n, :n] = t.transpose(-2, -1).float()
+    out[..., :, n:] = pad_keys
+    out[..., :n, :n] = t.float()
     return out.contiguous()
 
 
@@ -107,7 +107,7 @@ def compact_masks(mask):
     kept = distinct[nonzero].view(-1, n, n)
     if kept.shape[0] == 0:
         return None, None
-    return _padded_transposed(kept, n, 0.0), ids.contiguous()
+    return _padded(kept, n, 0.0), ids.contiguous()
 
 
 class WindowAttentionFunction(torch.autograd.Function):
@@ -182,15 +182,15 @@ class WindowAttention(nn.Module):
                 and not (self.training and self.attn_drop > 0) and self.qkv.weight.dtype == torch.bfloat16)
 
     def bias_table_t(self):
-        """the frozen relative-position bias as the kernel reads it: float32 [heads, 64, 64], transposed, -30000 in the padded
-        key rows (include/rlipv2_swin.h); cached like `bias` (frozen tables only)"""
+        """the frozen relative-position bias as the kernel reads it: float32 [heads, 64 queries, 64 keys], -30000 in the padded
+        key columns (include/rlipv2_swin.h); cached like `bias` (frozen tables only)"""
         t = self.relative_position_bias_table
         key = (t._version, t.data_ptr(), "t")
         if getattr(self, "_bias_t_key", None) != key:
             with torch.no_grad():
                 n = self.ws * self.ws
                 b = t[self.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1)
-                self._bias_t = _padded_transposed(b, n, -30000.0)
+                self._bias_t = _padded(b, n, -30000.0)
             self._bias_t_key = key
         return self._bias_t
 

@@ -407,11 +407,11 @@ def _window_attention_reference(qkv, bias, mask, mask_id, wpi, scale):
     return (p @ v).transpose(1, 2).reshape(W, N, h * d), p
 
 
-def _padded_transposed(t, N, pad_rows):
-    """[..., N, N] (query, key) -> [..., 64, 64] (key, query), `pad_rows` in the key rows >= N, 0 elsewhere"""
+def _padded(t, N, pad_keys):
+    """[..., N, N] (query, key) -> [..., 64, 64], `pad_keys` in the key columns >= N, 0 elsewhere (include/rlipv2_swin.h)"""
     out = torch.zeros(*t.shape[:-2], 64, 64)
-    out[..., N:, :] = pad_rows
-    out[..., :N, :N] = t.transpose(-2, -1)
+    out[..., :, N:] = pad_keys
+    out[..., :N, :N] = t
     return out.contiguous()
 
 
@@ -431,8 +431,8 @@ def test_window_attention_against_torch(lib, N, heads, windows, masked):
         region = torch.randint(0, 3, (2, N))
         mask = torch.where(region[:, :, None] != region[:, None, :], torch.tensor(-100.0), torch.tensor(0.0))   # 2 distinct masks
         mask_id = torch.tensor(([-1, 0, 1, -1, 1] * wpi)[:wpi], dtype=torch.int32)
-    bias_t = _padded_transposed(bias, N, -30000.0)
-    mask_t = _padded_transposed(mask, N, 0.0) if masked else None
+    bias_t = _padded(bias, N, -30000.0)
+    mask_t = _padded(mask, N, 0.0) if masked else None
     out = torch.zeros(windows, N, heads * d, dtype=torch.bfloat16)
     lib.window_attention_supported.argtypes = [ci] * 4
     assert lib.window_attention_supported(windows, heads, N, d) == 1 and lib.window_attention_supported(windows, heads, 65, d) == 0

@@ -7,7 +7,7 @@ on hardware may hang or fault: the parent only ever loses that arm).  Used two w
 
 Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_amd/csrc ablation`; csrc/msda_patch.hip):
   cell 2-4   cell_backward_kernel<., MODE>: geometry once per quad + operand swap | + loads up front, scalar level starts |
-             mode 3 without the swap                                  (reference work: ms_deform_im2col_cuda.cuh:87-159, 301-403)
+             mode 3 without the swap (the last two arms only with --all)                                  (reference work: ms_deform_im2col_cuda.cuh:87-159, 301-403)
   patch multi   patch_dest_multi_kernel (mask-word prefetch not in a branch)
   fwd cell   cell_forward_kernel (explicit variant "cell" of the product library) against the product forward (.cuh:237-299)
   swin       the two Swin routes of round 5 (csrc/window_attention.hip, csrc/layernorm_wide.hip; models/swin/swin_transformer.py:
@@ -27,10 +27,10 @@ sys.path.insert(0, ROOT)
 ABLATION_LIB = os.path.join(ROOT, "tools", "_build", "librlipv2_msda_ablation.so")
 
 ARMS = [("default", {}),
+        ("cell 3 (geometry once per quad + operand swap + loads up front)", {"RLIPV2_CELL_SHARED": "3"}),
         ("cell 2 (geometry once per quad + operand swap)", {"RLIPV2_CELL_SHARED": "2"}),
-        ("cell 3 (2 + loads up front)", {"RLIPV2_CELL_SHARED": "3"}),
-        ("cell 4 (3 without swap)", {"RLIPV2_CELL_SHARED": "4"}),
         ("patch multi", {"RLIPV2_PATCH_MULTI": "1"}),
+        ("cell 4 (3 without swap)", {"RLIPV2_CELL_SHARED": "4"}),
         ("cell 3 + patch multi", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_MULTI": "1"})]
 KEYS = ("RLIPV2_CELL_SHARED", "RLIPV2_PATCH_REPS", "RLIPV2_PATCH_MULTI")
 
@@ -219,20 +219,23 @@ def run_child(args, env, timeout):
     return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
 
 
-def main(per_child_timeout=75, budget_s=200):
-    """parent: one child per arm; stops starting new children when `budget_s` is used up"""
+def main(per_child_timeout=60, budget_s=150):
+    """parent: one child per arm / kernel, most informative first; nothing is started after `budget_s` seconds and no child may
+    run past the deadline (bench.py's default run must stay within minutes)"""
     t0 = time.time()
+    left = lambda: budget_s - (time.time() - t0)                                                              # noqa: E731
     report = {"what": "unmeasured kernel arms, A/B in child processes (tools/experiments_r05.py); evidence only, product path unchanged",
               "shape": "encoder N=4, 800x1333 pyramid, bf16, model-like locations; us = HIP events around 20 whole calls"}
     base_env = {k: v for k, v in os.environ.items() if k not in KEYS and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+
+    def child(args, env=None):
+        if left() < 20:
+            return {"error": "not started: time budget used up"}
+        return run_child(args, env or base_env, int(min(per_child_timeout, left())))
+    arms, base = {}, None
     if os.path.exists(ABLATION_LIB):
-        arms, base = {}, None
-        for k, (name, env) in enumerate(ARMS):
-            if time.time() - t0 > budget_s:
-                arms[name] = {"error": "not started: time budget used up"}
-                continue
-            e = dict(base_env, RLIPV2_LIB_PATH=ABLATION_LIB, **env)
-            out = run_child(["--arm", str(k)], e, per_child_timeout)
+        for k, (name, env) in enumerate(ARMS[:4]):              # (the other arms: `python tools/experiments_r05.py --all`)
+            out = child(["--arm", str(k)], dict(base_env, RLIPV2_LIB_PATH=ABLATION_LIB, **env))
             if "error" not in out:
                 digests = {case: out[case].pop("digest") for case in ("b0", "fused")}
                 if base is None:
@@ -245,12 +248,16 @@ def main(per_child_timeout=75, budget_s=200):
         report["encoder_backward_arms"] = arms
     else:
         report["encoder_backward_arms"] = {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
-    if time.time() - t0 <= budget_s:
-        report["encoder_forward_cell"] = run_child(["--fwd"], base_env, per_child_timeout)
-    if time.time() - t0 <= budget_s + 30:
-        report["swin_routes"] = run_child(["--swin"], base_env, per_child_timeout)
-    if time.time() - t0 <= budget_s + 60:
-        report["decoder_cross_attention_sample_then_project"] = run_child(["--stp"], base_env, per_child_timeout)
+    report["encoder_forward_cell"] = child(["--fwd"])
+    report["decoder_cross_attention_sample_then_project"] = child(["--stp"])
+    report["swin_routes"] = child(["--swin"])
+    if "--all" in sys.argv and base is not None:
+        for k, (name, env) in list(enumerate(ARMS))[4:]:
+            out = run_child(["--arm", str(k)], dict(base_env, RLIPV2_LIB_PATH=ABLATION_LIB, **env), per_child_timeout)
+            if "error" not in out:
+                for case in ("b0", "fused"):
+                    out[case]["equal_bits"] = out[case].pop("digest") == base[case]
+            arms[name] = out
     report["wall_s"] = round(time.time() - t0, 1)
     return report
 

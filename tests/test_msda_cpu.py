@@ -186,3 +186,40 @@ def test_sample_then_project_is_the_same_function(nd, masked):
     finally:
         deform_attn.sample_then_project = False
         deform_attn.MSDeformAttn._sampled_projection = orig
+
+
+def test_full_size_properties_of_the_cpu_arm():
+    """BASELINE config 2's encoder call on ONE image (800 x 1333 pyramid, S = Lq = 22 223, M 8, D 32, L = P = 4) through the CPU
+    twins, checked by properties that need no reference at this size: linearity in `value`, the adjoint identity
+    <grad_out, J v> = <J^T grad_out, v> between forward and the grad_value of backward, partition of unity (value = 1 and
+    in-range samples -> out = sum of the attention weights = 1), and grad_attn_weight = the per-sample bilinear values dotted
+    with grad_out (forward with a one-hot weight)."""
+    torch.manual_seed(0)
+    pyr = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    shapes = torch.tensor(pyr)
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S, M, D = int(shapes.prod(1).sum()), 8, 32
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1)
+                     .flip(-1).reshape(-1, 2) for h, w in pyr])                                  # (x, y) pixel centres
+    off = torch.randn(1, S, M, 4, 4, 2) * 2.0 / torch.tensor([[w, h] for h, w in pyr], dtype=torch.float32)[None, None, None, :, None, :]
+    loc = (ref[None, :, None, None, None, :] + off).contiguous()
+    aw = torch.softmax(torch.randn(1, S, M, 16), -1).view(1, S, M, 4, 4).contiguous()
+    v1, v2 = torch.randn(1, S, M, D), torch.randn(1, S, M, D)
+    go = torch.randn(1, S, M * D)
+    f = lambda v: msda.ms_deform_attn_forward(v, shapes, starts, loc, aw, 64)                      # noqa: E731
+    o1, o2 = f(v1), f(v2)
+    torch.testing.assert_close(f(2.0 * v1 - 0.5 * v2), 2.0 * o1 - 0.5 * o2, rtol=1e-4, atol=1e-4)
+    gv, gl, ga = msda.ms_deform_attn_backward(v1, shapes, starts, loc, aw, go, 64)
+    lhs, rhs = float((go.double() * o2.double()).sum()), float((gv.double() * v2.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    wh = torch.tensor([[w, h] for h, w in pyr], dtype=torch.float32)[None, None, None, :, None, :]
+    px = loc * wh - 0.5                                              # all four corners inside the level: 0 <= px <= size - 1
+    inside = ((px >= 0) & (px <= wh - 1)).all(-1).all(-1).all(-1)                               # [1, S, M]: every sample of the (query, head)
+    ones = f(torch.ones(1, S, M, D)).view(1, S, M, D)
+    assert int(inside.sum()) > S and float((ones[inside] - 1.0).abs().max()) < 1e-5
+    # grad_attn_weight of sample (l, p) = <grad_out, bilinear value at that sample>: forward with the one-hot weight
+    hot = torch.zeros_like(aw)
+    hot[..., 2, 1] = 1.0
+    sampled = msda.ms_deform_attn_forward(v1, shapes, starts, loc, hot, 64).view(1, S, M, D)
+    want = (sampled * go.view(1, S, M, D)).sum(-1)
+    torch.testing.assert_close(ga[..., 2, 1], want, rtol=1e-4, atol=1e-4)

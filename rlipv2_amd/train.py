@@ -921,7 +921,8 @@ def freeze_parameters_without_gradient(step_module, criterion, batch, autocast_d
 
 def build_training(args=None, device="cuda:0", with_text_encoder=True, backbone_name="resnet50"):
     """model + criterion of the train step; `backbone_name`: "resnet50" (BASELINE configs 2-3) or a swin name
-    ("swin_large": configs 4-5)"""
+    ("swin_large": configs 4-5).  The GPU-only host routes are OFF in what this returns: `validate_host_routes` (below)
+    switches on the ones that pass their self-check on the caller's first batch."""
     args = default_args() if args is None else args
     if torch.cuda.is_available() and str(device).startswith("cuda"):
         from .linear import use_tuned_library_gemms
@@ -941,6 +942,15 @@ def build_training(args=None, device="cuda:0", with_text_encoder=True, backbone_
                                          eos_coef=0.1, subject_class=args.subject_class, giou_verb_label=True,
                                          pseudo_verb=args.pseudo_verb).to(device)
     return model, criterion
+
+
+def validate_host_routes(step_module, criterion, batch, autocast_dtype=None, group=None, log=None):
+    """Start-up self-check of the GPU-only routes (rlipv2_amd/routes.py): they are OFF after `build_training`; call this once
+    with the step module, the criterion and one real batch before the first optimiser step (and before any graph capture) to
+    switch on the ones that reproduce the plain step's loss and gradients.  Returns {route: "on" | "off (...)"}; all ranks
+    of a data-parallel run must call it together (one MIN all-reduce).  bench.py does this and reports `config.host_routes`."""
+    from . import routes
+    return routes.validate(step_module, criterion, batch, autocast_dtype=autocast_dtype, group=group, log=log)
 
 
 def build_optimizer(model, lr=1.41e-4, lr_backbone=1.41e-5, text_encoder_lr=1.41e-5, weight_decay=1e-4):

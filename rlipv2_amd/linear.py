@@ -54,25 +54,33 @@ def _workspace(device, nbytes):
     return buf
 
 
+# Feature widths that are multiples of 64 but not of 128 (stage 0 of the Swin backbones: 192 / 576 channels) are not shapes of the
+# weight-gradient kernel (128 x 128 tiles); with this switch the narrow operand is zero-padded to the next multiple of 128 (one
+# extra pass over a [T, 192]-sized tensor) instead of leaving the product to the library GEMM, which runs these token-reducing
+# shapes at 4-9 % of the HBM rate.  OFF: not timed; `bench.py --set linear.pad_wgrad_to_128=1`.
+pad_wgrad_to_128 = False
+PAD_WGRAD_MIN_ROWS = 16384
+
+
+def _padded_width(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
 def supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
     if not (enabled and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
         return False
     rows = x.numel() // x.shape[-1]
-    return rows >= MIN_ROWS and bool(_lib.lib().linear_wgrad_supported(rows, weight.shape[0], weight.shape[1]))
+    M, K = weight.shape[0], weight.shape[1]
+    if rows >= MIN_ROWS and bool(_lib.lib().linear_wgrad_supported(rows, M, K)):
+        return True
+    return (pad_wgrad_to_128 and rows >= PAD_WGRAD_MIN_ROWS and M % 64 == 0 and K % 64 == 0 and M >= 64 and K >= 64
+            and bool(_lib.lib().linear_wgrad_supported(rows, _padded_width(M), _padded_width(K))))
 
 
-def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True, out_dtype=torch.bfloat16):
-    """dW [M, K] = dy[T, M]^T x[T, K] and db [M] = dy.sum(0) (bf16 inputs, float32 accumulation)."""
-    if not (dy.is_cuda and x.is_cuda):
-        raise RuntimeError("Not implemented on the CPU")
-    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
-        raise RuntimeError("linear_wgrad: bfloat16 operands expected")
-    dy = dy.reshape(-1, dy.shape[-1]).contiguous()
-    x = x.reshape(-1, x.shape[-1]).contiguous()
+def _wgrad_call(dy: torch.Tensor, x: torch.Tensor, with_bias: bool, out_dtype):
+    """the kernel on contiguous [T, M] / [T, K] operands of a supported shape"""
     T, M = dy.shape
     K = x.shape[1]
-    if x.shape[0] != T:
-        raise RuntimeError("linear_wgrad: dy and x disagree on the number of rows")
     L = _lib.lib()
     nbytes = L.linear_wgrad_workspace_bytes(T, M, K)
     if nbytes == 0:
@@ -88,6 +96,33 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True, out_
         raise RuntimeError("linear_wgrad: " + _lib.strerror(st))
     roofline.add(roofline.tensor_bytes(dy, x, dw, db), 2 * T * M * K)
     return dw, db
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, with_bias: bool = True, out_dtype=torch.bfloat16):
+    """dW [M, K] = dy[T, M]^T x[T, K] and db [M] = dy.sum(0) (bf16 inputs, float32 accumulation)."""
+    if not (dy.is_cuda and x.is_cuda):
+        raise RuntimeError("Not implemented on the CPU")
+    if dy.dtype != torch.bfloat16 or x.dtype != torch.bfloat16:
+        raise RuntimeError("linear_wgrad: bfloat16 operands expected")
+    dy = dy.reshape(-1, dy.shape[-1]).contiguous()
+    x = x.reshape(-1, x.shape[-1]).contiguous()
+    if x.shape[0] != dy.shape[0]:
+        raise RuntimeError("linear_wgrad: dy and x disagree on the number of rows")
+    return _wgrad_maybe_padded(dy, x, with_bias, out_dtype)
+
+
+def _wgrad_maybe_padded(dy, x, with_bias, out_dtype):
+    M, K = dy.shape[1], x.shape[1]
+    Mp, Kp = (_padded_width(M), _padded_width(K)) if pad_wgrad_to_128 else (M, K)
+    if (Mp, Kp) == (M, K):
+        return _wgrad_call(dy, x, with_bias, out_dtype)
+    # zero columns contribute zero rows / columns of dW (and zero entries of db): the result is the top-left block
+    if Mp != M:
+        dy = F.pad(dy, (0, Mp - M))
+    if Kp != K:
+        x = F.pad(x, (0, Kp - K))
+    dw, db = _wgrad_call(dy, x, with_bias, out_dtype)
+    return dw[:M, :K].contiguous(), (db[:M].contiguous() if db is not None else None)
 
 
 EXPAND_MIN_ROWS = 4096      # below this the library GEMM + elementwise pair is launch-bound anyway

@@ -272,3 +272,35 @@ def test_shared_input_never_mixes_in_place_and_returned_gradients(case):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     finally:
         linear.linear_wgrad = saved
+
+
+def test_weight_gradient_of_64_multiples_by_padding():
+    """linear.pad_wgrad_to_128 (Swin stage 0: 192 / 576 channels): the narrow operand is zero-padded to the kernel's 128-multiples
+    and the result is the top-left block.  Logic on the CPU with a torch stand-in for the kernel call."""
+    calls = []
+
+    def stand_in(dy, x, with_bias, out_dtype):
+        calls.append((tuple(dy.shape), tuple(x.shape)))
+        assert dy.shape[1] % 128 == 0 and x.shape[1] % 128 == 0 and dy.is_contiguous() and x.is_contiguous()
+        return (dy.float().t() @ x.float()).to(out_dtype), (dy.float().sum(0).to(out_dtype) if with_bias else None)
+    saved = linear._wgrad_call
+    linear._wgrad_call = stand_in
+    try:
+        torch.manual_seed(0)
+        for M, K in ((192, 192), (576, 192), (768, 192), (192, 768), (256, 128)):
+            dy, x = torch.randn(300, M).to(torch.bfloat16), torch.randn(300, K).to(torch.bfloat16)
+            want_w, want_b = dy.float().t() @ x.float(), dy.float().sum(0)
+            for flag in (True, False):
+                linear.pad_wgrad_to_128 = flag
+                if not flag and (M % 128 or K % 128):
+                    with pytest.raises(AssertionError):
+                        linear._wgrad_maybe_padded(dy, x, True, torch.float32)
+                    continue
+                dw, db = linear._wgrad_maybe_padded(dy, x, True, torch.float32)
+                assert dw.shape == (M, K) and db.shape == (M,) and dw.is_contiguous()
+                torch.testing.assert_close(dw, want_w, rtol=1e-5, atol=1e-4)
+                torch.testing.assert_close(db, want_b, rtol=1e-5, atol=1e-4)
+        assert ((300, 256), (300, 256)) in calls and ((300, 640), (300, 256)) in calls
+    finally:
+        linear._wgrad_call = saved
+        linear.pad_wgrad_to_128 = False

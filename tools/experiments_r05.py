@@ -151,6 +151,23 @@ def child_swin():
     out["residual_add_layer_norm_fwd_bwd"] = {"ops_us": t[False], "fused_us": t[True], "rel_l2_y": rel(res[True][0], res[False][0]),
                                               "rel_l2_dx": rel(res[True][1], res[False][1]),
                                               "note": "both timings include two clones of the 51 MB inputs"}
+    # weight gradients of stage 0 (192 / 576 channels: 64-multiples the MFMA weight-gradient kernel does not take): the library
+    # GEMM against the kernel on zero-padded operands (linear.pad_wgrad_to_128)
+    from rlipv2_amd import linear
+    T = B * 200 * 334
+    wg = {}
+    for name, M, K in (("qkv 576x192", 576, 192), ("proj 192x192", 192, 192), ("fc1 768x192", 768, 192), ("fc2 192x768", 192, 768)):
+        dy, x = torch.randn(T, M, device=dev).to(torch.bfloat16), torch.randn(T, K, device=dev).to(torch.bfloat16)
+        lib_us = round(timed(lambda: dy.t().mm(x), iters=10), 1)
+        linear.pad_wgrad_to_128 = True
+        try:
+            dw, _ = linear.linear_wgrad(dy, x, with_bias=True, out_dtype=torch.bfloat16)
+            pad_us = round(timed(lambda: linear.linear_wgrad(dy, x, with_bias=True, out_dtype=torch.bfloat16), iters=10), 1)
+        finally:
+            linear.pad_wgrad_to_128 = False
+        wg[name] = {"library_us": lib_us, "padded_kernel_us": pad_us, "rel_l2": rel(dw.float(), dy.t().mm(x).float())}
+        del dy, x
+    out["stage0_weight_gradients"] = wg
     print("RESULT " + json.dumps(out), flush=True)
 
 

@@ -236,45 +236,46 @@ def run_child(args, env, timeout):
     return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
 
 
-def main(per_child_timeout=60, budget_s=150):
+def main(per_child_timeout=45, budget_s=100):
     """parent: one child per arm / kernel, most informative first; nothing is started after `budget_s` seconds and no child may
-    run past the deadline (bench.py's default run must stay within minutes)"""
+    run past the deadline (bench.py's default run must stay within minutes); `--all`: no budget, every arm"""
+    everything = "--all" in sys.argv
+    if everything:
+        per_child_timeout, budget_s = 120, 3600
     t0 = time.time()
     left = lambda: budget_s - (time.time() - t0)                                                              # noqa: E731
     report = {"what": "unmeasured kernel arms, A/B in child processes (tools/experiments_r05.py); evidence only, product path unchanged",
               "shape": "encoder N=4, 800x1333 pyramid, bf16, model-like locations; us = HIP events around 20 whole calls"}
     base_env = {k: v for k, v in os.environ.items() if k not in KEYS and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    have_arms = os.path.exists(ABLATION_LIB)
+    arms, base = {}, [None]
 
     def child(args, env=None):
-        if left() < 20:
+        if left() < 15:
             return {"error": "not started: time budget used up"}
         return run_child(args, env or base_env, int(min(per_child_timeout, left())))
-    arms, base = {}, None
-    if os.path.exists(ABLATION_LIB):
-        for k, (name, env) in enumerate(ARMS[:4]):              # (the other arms: `python tools/experiments_r05.py --all`)
-            out = child(["--arm", str(k)], dict(base_env, RLIPV2_LIB_PATH=ABLATION_LIB, **env))
-            if "error" not in out:
-                digests = {case: out[case].pop("digest") for case in ("b0", "fused")}
-                if base is None:
-                    base = digests
-                for case in ("b0", "fused"):
-                    out[case]["equal_bits"] = digests[case] == base[case]
-            arms[name] = out
-            if k == 0 and "error" in out:
-                break                                          # the default itself failed: nothing to compare with
-        report["encoder_backward_arms"] = arms
-    else:
-        report["encoder_backward_arms"] = {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
+
+    def arm(k):
+        name, env = ARMS[k]
+        if not have_arms or (k > 0 and base[0] is None):
+            return
+        out = child(["--arm", str(k)], dict(base_env, RLIPV2_LIB_PATH=ABLATION_LIB, **env))
+        if "error" not in out:
+            digests = {case: out[case].pop("digest") for case in ("b0", "fused")}
+            if base[0] is None:
+                base[0] = digests
+            for case in ("b0", "fused"):
+                out[case]["equal_bits"] = digests[case] == base[0][case]
+        arms[name] = out
+    # order = value of the evidence: the default pair and the most complete cell arm, the other kernels, then the remaining arms
+    arm(0)
+    arm(1)
+    report["encoder_backward_arms"] = arms if have_arms else {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
     report["encoder_forward_cell"] = child(["--fwd"])
     report["decoder_cross_attention_sample_then_project"] = child(["--stp"])
     report["swin_routes"] = child(["--swin"])
-    if "--all" in sys.argv and base is not None:
-        for k, (name, env) in list(enumerate(ARMS))[4:]:
-            out = run_child(["--arm", str(k)], dict(base_env, RLIPV2_LIB_PATH=ABLATION_LIB, **env), per_child_timeout)
-            if "error" not in out:
-                for case in ("b0", "fused"):
-                    out[case]["equal_bits"] = out[case].pop("digest") == base[case]
-            arms[name] = out
+    for k in range(2, len(ARMS) if everything else 4):
+        arm(k)
     report["wall_s"] = round(time.time() - t0, 1)
     return report
 

@@ -223,3 +223,34 @@ def test_full_size_properties_of_the_cpu_arm():
     sampled = msda.ms_deform_attn_forward(v1, shapes, starts, loc, hot, 64).view(1, S, M, D)
     want = (sampled * go.view(1, S, M, D)).sum(-1)
     torch.testing.assert_close(ga[..., 2, 1], want, rtol=1e-4, atol=1e-4)
+
+
+def test_random_problems_against_the_oracle():
+    """hypothesis-style sweep without the dependency on its shrinker: 40 seeded random problems (1-3 images, 1-5 levels of 1-9 pixels
+    a side, 1-4 heads, 1-9 channels, 0-7 queries, 1-5 points; locations spread far beyond [0, 1], some exactly on pixel centres and on
+    the -1 / size drop boundary) through the CPU twins against the oracle's float64 C restatement."""
+    from oracle import msda_oracle as O
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        N, L, M, D, Lq, P = (int(rng.integers(a, b + 1)) for a, b in ((1, 3), (1, 5), (1, 4), (1, 9), (0, 7), (1, 5)))
+        pyr = rng.integers(1, 10, size=(L, 2)).astype(np.int64)
+        starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
+        S = int((pyr[:, 0] * pyr[:, 1]).sum())
+        loc = rng.uniform(-0.4, 1.4, size=(N, Lq, M, L, P, 2))
+        if Lq:
+            wh = np.stack([pyr[:, 1], pyr[:, 0]], -1)[None, None, None, :, None, :]
+            snap = rng.random(loc.shape) < 0.15                        # exact pixel centres / the drop boundary
+            k = rng.integers(-1, 11, size=loc.shape)
+            loc = np.where(snap, (np.minimum(k, wh) + 0.5) / wh, loc)
+        value = rng.standard_normal((N, S, M, D))
+        aw = rng.random((N, Lq, M, L, P))
+        go = rng.standard_normal((N, Lq, M * D))
+        ref_out = O.forward(value, pyr, starts, loc, aw)
+        ref_gv, ref_gl, ref_ga = O.backward(value, pyr, starts, loc, aw, go)
+        t = [torch.from_numpy(np.ascontiguousarray(a)) for a in (value, pyr, starts, loc, aw)]
+        out = msda.ms_deform_attn_forward(*t, 64)
+        gv, gl, ga = msda.ms_deform_attn_backward(*t, torch.from_numpy(go), 64)
+        np.testing.assert_allclose(out.numpy(), ref_out, rtol=1e-9, atol=1e-11, err_msg=f"case {case}")
+        np.testing.assert_allclose(gv.numpy(), ref_gv, rtol=1e-9, atol=1e-11, err_msg=f"case {case}")
+        np.testing.assert_allclose(ga.numpy(), ref_ga, rtol=1e-9, atol=1e-11, err_msg=f"case {case}")
+        np.testing.assert_allclose(gl.numpy(), ref_gl, rtol=1e-9, atol=1e-10, err_msg=f"case {case}")

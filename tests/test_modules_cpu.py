@@ -894,3 +894,44 @@ def test_ab_switches_of_the_host_restructures_compute_the_same_function(switch):
     finally:
         setattr(mod, switch, True)
         pass
+
+
+def test_training_loop_on_the_cpu_reduces_the_loss():
+    """BASELINE config 1's role taken one step further than plumbing: the reference's optimisation step (AdamW with the three
+    learning-rate groups of main.py:523-539, clip_grad_norm_ 0.1 -- engine.py:170-172) on a small ParSeD v2, one fixed batch of two
+    images (stored backbone features), entirely on the CPU: eight steps drive the weighted loss down.  Runs once on the product's CPU op and once with the
+    checker standing in (the autouse fixture)."""
+    from rlipv2_amd import criterion as MC
+    from rlipv2_amd import parsed, train
+    torch.manual_seed(0)
+    args = parseda.default_args(num_queries=20, enc_layers=4, dec_layers=2, dim_feedforward=128, gating_mechanism="XGating",
+                                pseudo_verb=False)
+    bb = _FeatureBackbone((32, 64, 128))                          # (stored backbone features: the loop is about the transformer)
+    model = parsed.build_parsed(bb, args).train()
+    for m in model.modules():                                       # (deterministic: the hidden dropouts of Q6 off)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        elif isinstance(getattr(m, "dropout", None), float):
+            m.dropout = 0.0
+    samples, _, targets = train.synthetic_batch(2, 64, 96, n_obj=6, n_verb=4, triplets=2, device="cpu", seed=5)
+    gf = torch.Generator().manual_seed(4)
+    bb.features = [(torch.randn(2, c, 64 // s, 96 // s, generator=gf), torch.zeros(2, 64 // s, 96 // s, dtype=torch.bool))
+                   for c, s in ((32, 8), (64, 16), (128, 32))]
+    g = torch.Generator().manual_seed(9)
+    mem = torch.tanh(torch.randn(10, 1, 768, generator=g)).repeat(1, 2, 1)
+    text = (~(mem.sum(-1) > 0), mem, torch.tensor([[6, 4]]))
+    crit = MC.SetCriterionHOI(MC.HungarianMatcherHOI(1, 1, 2.5, 1, subject_class=True), MC.build_weight_dict(2), pseudo_verb=False)
+    opt = train.build_optimizer(model, lr=1e-3, lr_backbone=1e-4, text_encoder_lr=1e-4)
+    feats = samples
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        mc = model(feats, encode_and_save=True, text=text, targets=targets)
+        out = model(feats, encode_and_save=False, memory_cache=mc, text=text, targets=targets)
+        loss = crit.weighted_sum(crit(out, targets))
+        assert torch.isfinite(loss)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.9 * losses[0], losses

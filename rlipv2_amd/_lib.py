@@ -51,7 +51,7 @@ EXPORTS = (
 )
 
 # include/rlipv2_msda_cpu.h (librlipv2_msda_cpu.so: the CPU twins, no HIP)
-CPU_LIB_PATH = os.path.join(_HERE, "librlipv2_msda_cpu.so")
+CPU_LIB_PATH = os.environ.get("RLIPV2_CPU_LIB_PATH") or os.path.join(_HERE, "librlipv2_msda_cpu.so")   # (override: sanitizer builds)
 CPU_EXPORTS = ("msda_forward_cpu", "msda_backward_cpu", "msda_cpu_strerror", "msda_cpu_abi_version")
 
 _lib = None

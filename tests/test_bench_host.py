@@ -129,7 +129,7 @@ def test_package_reads_no_code_path_switch_from_the_environment():
     """~15 environment-variable A/B switches were read inside the product package.  What is left is
     configuration of the libraries underneath (library path, MIOpen / hipBLASLt tuning tables)."""
     import re
-    allowed = {"RLIPV2_LIB_PATH", "RLIPV2_TUNED_MIOPEN", "MIOPEN_USER_DB_PATH", "XDG_CACHE_HOME", "RLIPV2_TUNED_GEMM_TABLE",
+    allowed = {"RLIPV2_LIB_PATH", "RLIPV2_CPU_LIB_PATH", "RLIPV2_TUNED_MIOPEN", "MIOPEN_USER_DB_PATH", "XDG_CACHE_HOME", "RLIPV2_TUNED_GEMM_TABLE",
                "RLIPV2_TUNED_GEMMS"}
     pkg = os.path.join(ROOT, "rlipv2_amd")
     seen = set()

@@ -33,6 +33,25 @@ int window_attention_backward_bf16(const void *qkv, const void *d_out, const flo
                                    const int *mask_id, int windows, int windows_per_image, int heads, int tokens, float scale,
                                    void *d_qkv, void *stream);
 
+/* The same two kernels with pad / cyclic shift / window partition / window reverse folded into their addressing
+ * (models/swin/swin_transformer.py:362-396: F.pad, torch.roll, window_partition before the attention, window_reverse, roll back and
+ * the crop after it -- five copies of the token map per block and direction as PyTorch ops):
+ *   qkv, out, d_out, d_qkv stay in IMAGE order: [B, rows_per_image, 3 * heads * 32] / [B, rows_per_image, heads * 32]
+ *   rowmap   [windows_per_image * N] int32: the row of token t of window w inside its image, or -(slot + 1) for a token that the
+ *            reference creates by zero-padding the normalised map; rows_per_image + pads_per_image == windows_per_image * N
+ *   pad_row  [3 * heads * 32] bf16: q / k / v of a padding token = the projection of a zero input = the qkv bias (NULL: zeros)
+ *   d_pad    [B * pads_per_image, 3 * heads * 32] bf16: the gradient rows of the padding tokens (their sum over all rows is the
+ *            padding's contribution to the bias gradient); may be NULL when there is no padding or no pad_row
+ * Outputs of padding tokens are not written (the reference crops them), their d_out is zero. */
+int window_attention_rows_forward_bf16(const void *qkv, const void *pad_row, const int *rowmap, int rows_per_image, int pads_per_image,
+                                       const float *bias_t, const float *mask_t, const int *mask_id, int windows,
+                                       int windows_per_image, int heads, int tokens, float scale, void *out, void *stream);
+
+int window_attention_rows_backward_bf16(const void *qkv, const void *pad_row, const int *rowmap, int rows_per_image,
+                                        int pads_per_image, const void *d_out, const float *bias_t, const float *mask_t,
+                                        const int *mask_id, int windows, int windows_per_image, int heads, int tokens, float scale,
+                                        void *d_qkv, void *d_pad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ EXPORTS = (
     "alif_attention_softmax_backward_bf16",
     # include/rlipv2_swin.h
     "window_attention_supported", "window_attention_forward_bf16", "window_attention_backward_bf16",
+    "window_attention_rows_forward_bf16", "window_attention_rows_backward_bf16",
     # include/rlipv2_elementwise.h
     "add_relu_bf16", "affine_relu_bf16", "affine_relu_backward_bf16",
     # include/rlipv2_groupnorm.h
@@ -160,6 +161,9 @@ def lib() -> ctypes.CDLL:
     L.window_attention_forward_bf16.argtypes = [vp, vp, vp, vp, i, i, i, i, f32, vp, vp]
     L.window_attention_backward_bf16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, f32, vp, vp]
     L.window_attention_supported.restype = L.window_attention_forward_bf16.restype = L.window_attention_backward_bf16.restype = i
+    L.window_attention_rows_forward_bf16.argtypes = [vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, f32, vp, vp]
+    L.window_attention_rows_backward_bf16.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, i, i, i, i, f32, vp, vp, vp]
+    L.window_attention_rows_forward_bf16.restype = L.window_attention_rows_backward_bf16.restype = i
     L.add_relu_bf16.argtypes = [vp, vp, vp, lg, vp]
     L.add_relu_bf16.restype = i
     L.affine_relu_bf16.argtypes = [vp, vp, vp, vp, lg, i, vp]

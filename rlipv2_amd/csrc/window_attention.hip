@@ -47,8 +47,9 @@ constexpr int NP = 64;                  // tokens per window, padded (window_siz
 constexpr int WAVES = 2, THREADS = WAVES * 64;    // (LDS per wave decides the waves per CU: small workgroups pack best)
 constexpr int P_STRIDE = NP + 8;        // bf16 per row of an [NP][NP] LDS tile (+ 16 bytes: rows on different banks)
 constexpr int T_STRIDE = NP + 8;        // bf16 per row of a transposed operand tile [HD][NP]
-constexpr int FWD_WAVE_LDS = (NP * P_STRIDE + HD * T_STRIDE) * 2;                   // P | V^T
-constexpr int BWD_WAVE_LDS = (2 * NP * P_STRIDE + HD * T_STRIDE) * 2;              // X^T (P^T, then dS^T) | dS | dO^T, then K^T, then Q^T
+constexpr int CODE_BYTES = NP * 4;      // per wave: the row code of each of the window's tokens
+constexpr int FWD_WAVE_LDS = (NP * P_STRIDE + HD * T_STRIDE) * 2 + CODE_BYTES;      // P | V^T | codes
+constexpr int BWD_WAVE_LDS = (2 * NP * P_STRIDE + HD * T_STRIDE) * 2 + CODE_BYTES; // X^T (P^T, then dS^T) | dS | dO^T, then K^T, then Q^T | codes
 
 // two floats -> packed bfloat16 pair, round to nearest even: ONE v_cvt_pk_bf16_f32 on gfx950 (the bit-twiddling form is 8
 // VALU instructions per value, and the probabilities alone are 64 values per lane and window)
@@ -97,12 +98,38 @@ __device__ __forceinline__ Task task_of(int heads, int windows)
     return t;
 }
 
-// operand fragments of one 32-token tile of a [token][row_stride] matrix: [k-step] (16 channels each), zero for tokens >= N
-__device__ __forceinline__ void load_tile_frags(const uint16_t *src, int row_stride, int N, int tile, int lane, Frag (&f)[2])
+// Where the rows of a window's tokens live.  map == nullptr: the tensors are window-major, token t of window w is row w N + t
+// (the layout the reference's window_partition produces).  map != nullptr: the tensors stay in IMAGE order [B, H W, .] and
+// map[(w mod windows_per_image) N + t] is the token's row inside its image, or -(slot + 1) for a token of the zero padding
+// (window_partition after F.pad, models/swin/swin_transformer.py:362-379): its q / k / v are the projection's bias (`pad_row`),
+// its output is dropped and its gradient goes to row `slot` of a small side buffer (it belongs to the bias) -- pad, cyclic
+// shift and window partition / reverse become addressing, no copies.
+struct RowMap { const int *map; int rows_per_image, pads_per_image, windows_per_image; };
+
+// code of token `tok` of window w: >= 0 a row, -1 no such token (tok >= N), <= -2 the pad slot -(code + 2)
+__device__ __forceinline__ int token_code(const RowMap &rm, int w, int N, int tok)
 {
-    const int tok = tile * 32 + (lane & 31), kg = (lane >> 5) * 8;
+    if (tok >= N) return -1;
+    if (!rm.map) return w * N + tok;
+    const int b = w / rm.windows_per_image, wl = w - b * rm.windows_per_image;
+    const int r = rm.map[wl * N + tok];
+    return r >= 0 ? b * rm.rows_per_image + r : -2 - (b * rm.pads_per_image + (-r - 1));
+}
+
+// row of a token in an input matrix: `mat` for real rows, the single row `pad` for padding tokens (nullptr: zeros), nullptr otherwise
+__device__ __forceinline__ const uint16_t *in_row(const uint16_t *mat, const uint16_t *pad, int row_stride, int code)
+{
+    return code >= 0 ? mat + (size_t)code * row_stride : (code <= -2 ? pad : nullptr);
+}
+
+// operand fragments of one 32-token tile: [k-step] (16 channels each), zeros for tokens without a row
+__device__ __forceinline__ void load_tile_frags(const uint16_t *mat, const uint16_t *pad, int row_stride, const int *codes, int tile,
+                                                int lane, Frag (&f)[2])
+{
+    const int kg = (lane >> 5) * 8;
+    const uint16_t *row = in_row(mat, pad, row_stride, codes[tile * 32 + (lane & 31)]);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) f[ks] = load_frag(src + (size_t)tok * row_stride + ks * 16 + kg, tok < N);
+    for (int ks = 0; ks < 2; ++ks) f[ks] = load_frag(row + ks * 16 + kg, row != nullptr);
 }
 
 // x^T[jt][r] = sum over the 32 channels of  rows[key jt * 32 + acc_row(r)] . cols[this tile's query lane & 31]
@@ -210,13 +237,14 @@ __device__ __forceinline__ void transpose_tile(uint16_t *dst, const uint16_t *sr
     }
 }
 
-// rows [token][32 channels] of one (window, head) in global memory -> transposed LDS tile [channel][token]; lane = token
-__device__ __forceinline__ void stage_transposed(uint16_t *tile, const uint16_t *src, int row_stride, int N, int lane)
+// the window's rows [token][32 channels] in global memory -> transposed LDS tile [channel][token]; lane = token
+__device__ __forceinline__ void stage_transposed(uint16_t *tile, const uint16_t *mat, const uint16_t *pad, int row_stride,
+                                                 const int *codes, int lane)
 {
+    const uint16_t *row = in_row(mat, pad, row_stride, codes[lane]);
     uint4 v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        v[c] = lane < N ? *reinterpret_cast<const uint4 *>(src + (size_t)lane * row_stride + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+    for (int c = 0; c < 4; ++c) v[c] = row ? *reinterpret_cast<const uint4 *>(row + c * 8) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const uint32_t w[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
@@ -228,10 +256,10 @@ __device__ __forceinline__ void stage_transposed(uint16_t *tile, const uint16_t 
     }
 }
 
-// row tile `rt` of  A [NP x NP, LDS rows] x B^T [32 x NP, transposed LDS tile]  -> global rows of `row_stride` elements,
-// scaled: o[r] = row rt * 32 + acc_row(r), channel lane & 31
+// row tile `rt` of  A [NP x NP, LDS rows] x B^T [32 x NP, transposed LDS tile]  -> the tokens' rows in `dst` (padding tokens: row
+// `slot` of `dst_pad`, or nowhere), scaled: o[r] = token rt * 32 + acc_row(r), channel lane & 31
 __device__ __forceinline__ void product_tile_store(const uint16_t *a_tile, const uint16_t *bt_tile, int rt, uint16_t *dst,
-                                                   int row_stride, int N, float scale, int lane)
+                                                   uint16_t *dst_pad, int row_stride, const int *codes, float scale, int lane)
 {
     const int li = lane & 31, kg = (lane >> 5) * 8;
     f32x16 o;
@@ -245,80 +273,87 @@ __device__ __forceinline__ void product_tile_store(const uint16_t *a_tile, const
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int i = rt * 32 + acc_row(r, lane);
-        if (i < N) dst[(size_t)i * row_stride + li] = (uint16_t)(pack2(o[r] * scale, 0.f) & 0xffffu);
+        const int code = codes[rt * 32 + acc_row(r, lane)];
+        uint16_t *row = code >= 0 ? dst + (size_t)code * row_stride : (code <= -2 && dst_pad ? dst_pad + (size_t)(-2 - code) * row_stride : nullptr);
+        if (row) row[li] = (uint16_t)(pack2(o[r] * scale, 0.f) & 0xffffu);
     }
 }
 
 __global__ __launch_bounds__(THREADS) void window_attention_forward_kernel(
-    const uint16_t *__restrict__ qkv, const float *__restrict__ bias_t, const float *__restrict__ mask_t,
-    const int *__restrict__ mask_id, int windows, int windows_per_image, int heads, int N, float scale,
+    const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ pad_row, RowMap rm, const float *__restrict__ bias_t,
+    const float *__restrict__ mask_t, const int *__restrict__ mask_id, int windows, int heads, int N, float scale,
     uint16_t *__restrict__ out)
 {
     MSDA_DYNAMIC_LDS(unsigned char, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *Pl = reinterpret_cast<uint16_t *>(lds + wave * FWD_WAVE_LDS);
     uint16_t *Vt = Pl + NP * P_STRIDE;
+    int *codes = reinterpret_cast<int *>(Vt + HD * T_STRIDE);
     const Task t = task_of(heads, windows);
     if (!t.any) return;
     const int C = heads * HD, row_stride = 3 * C;
     const float *bias_h = bias_t + (size_t)t.head * NP * NP;
+    const uint16_t *qh = qkv + t.head * HD, *ph = pad_row ? pad_row + t.head * HD : nullptr;
     for (int w = t.first; w < windows; w += t.step) {
-        const uint16_t *base = qkv + (size_t)w * N * row_stride + t.head * HD;
-        const int mid = mask_id ? mask_id[w % windows_per_image] : -1;
+        const int mid = mask_id ? mask_id[w % rm.windows_per_image] : -1;
         const float *mask_w = mid >= 0 ? mask_t + (size_t)mid * NP * NP : nullptr;
+        WATT_WAVE_SYNC();                                            // the previous window's tiles and codes are no longer read
+        codes[lane] = token_code(rm, w, N, lane);
+        WATT_WAVE_SYNC();
         Frag kf[2][2];
-        load_tile_frags(base + C, row_stride, N, 0, lane, kf[0]);
-        load_tile_frags(base + C, row_stride, N, 1, lane, kf[1]);
-        WATT_WAVE_SYNC();                                            // the previous window's tiles are no longer read
-        stage_transposed(Vt, base + 2 * C, row_stride, N, lane);
+        load_tile_frags(qh + C, ph ? ph + C : nullptr, row_stride, codes, 0, lane, kf[0]);
+        load_tile_frags(qh + C, ph ? ph + C : nullptr, row_stride, codes, 1, lane, kf[1]);
+        stage_transposed(Vt, qh + 2 * C, ph ? ph + 2 * C : nullptr, row_stride, codes, lane);
 #pragma unroll 1
         for (int it = 0; it < 2; ++it) {                             // one tile of 32 queries at a time (register budget)
             Frag qf[2];
-            load_tile_frags(base, row_stride, N, it, lane, qf);
+            load_tile_frags(qh, ph, row_stride, codes, it, lane, qf);
             f32x16 s[2];
             product_keys_by_queries(kf, qf, s);
             softmax_keys(s, scale, bias_h, mask_w, it, lane);
             store_rows(Pl, s, it, lane);
             WATT_WAVE_SYNC();
-            product_tile_store(Pl, Vt, it, out + (size_t)w * N * C + t.head * HD, C, N, 1.f, lane);
+            product_tile_store(Pl, Vt, it, out + t.head * HD, nullptr, C, codes, 1.f, lane);
         }
     }
 }
 
 // d_qkv of one (window, head) from qkv and d_out; see the file header for the formulas
 __global__ __launch_bounds__(THREADS) void window_attention_backward_kernel(
-    const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ d_out, const float *__restrict__ bias_t,
-    const float *__restrict__ mask_t, const int *__restrict__ mask_id, int windows, int windows_per_image, int heads, int N,
-    float scale, uint16_t *__restrict__ d_qkv)
+    const uint16_t *__restrict__ qkv, const uint16_t *__restrict__ pad_row, RowMap rm, const uint16_t *__restrict__ d_out,
+    const float *__restrict__ bias_t, const float *__restrict__ mask_t, const int *__restrict__ mask_id, int windows, int heads,
+    int N, float scale, uint16_t *__restrict__ d_qkv, uint16_t *__restrict__ d_pad)
 {
     MSDA_DYNAMIC_LDS(unsigned char, lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *Xt = reinterpret_cast<uint16_t *>(lds + wave * BWD_WAVE_LDS);     // [key][query]: P^T, later dS^T
     uint16_t *dSl = Xt + NP * P_STRIDE;                                         // [query][key]
     uint16_t *Tt = dSl + NP * P_STRIDE;                                         // [channel][token]: dO^T, then K^T, then Q^T
+    int *codes = reinterpret_cast<int *>(Tt + HD * T_STRIDE);
     const Task t = task_of(heads, windows);
     if (!t.any) return;
     const int C = heads * HD, row_stride = 3 * C;
     const float *bias_h = bias_t + (size_t)t.head * NP * NP;
+    const uint16_t *qh = qkv + t.head * HD, *ph = pad_row ? pad_row + t.head * HD : nullptr;
+    const uint16_t *doh = d_out + t.head * HD;
+    uint16_t *gh = d_qkv + t.head * HD, *gp = d_pad ? d_pad + t.head * HD : nullptr;
     for (int w = t.first; w < windows; w += t.step) {
-        const uint16_t *base = qkv + (size_t)w * N * row_stride + t.head * HD;
-        const uint16_t *dob = d_out + (size_t)w * N * C + t.head * HD;
-        uint16_t *gb = d_qkv + (size_t)w * N * row_stride + t.head * HD;
-        const int mid = mask_id ? mask_id[w % windows_per_image] : -1;
+        const int mid = mask_id ? mask_id[w % rm.windows_per_image] : -1;
         const float *mask_w = mid >= 0 ? mask_t + (size_t)mid * NP * NP : nullptr;
+        WATT_WAVE_SYNC();                                            // the previous window's tiles and codes are no longer read
+        codes[lane] = token_code(rm, w, N, lane);
+        WATT_WAVE_SYNC();
         Frag kf[2][2], vf[2][2];
-        load_tile_frags(base + C, row_stride, N, 0, lane, kf[0]);
-        load_tile_frags(base + C, row_stride, N, 1, lane, kf[1]);
-        load_tile_frags(base + 2 * C, row_stride, N, 0, lane, vf[0]);
-        load_tile_frags(base + 2 * C, row_stride, N, 1, lane, vf[1]);
-        WATT_WAVE_SYNC();                                            // the previous window's tiles are no longer read
-        stage_transposed(Tt, dob, C, N, lane);
+        load_tile_frags(qh + C, ph ? ph + C : nullptr, row_stride, codes, 0, lane, kf[0]);
+        load_tile_frags(qh + C, ph ? ph + C : nullptr, row_stride, codes, 1, lane, kf[1]);
+        load_tile_frags(qh + 2 * C, ph ? ph + 2 * C : nullptr, row_stride, codes, 0, lane, vf[0]);
+        load_tile_frags(qh + 2 * C, ph ? ph + 2 * C : nullptr, row_stride, codes, 1, lane, vf[1]);
+        stage_transposed(Tt, doh, nullptr, C, codes, lane);          // (the output of a padding token is dropped: zero gradient)
 #pragma unroll 1
         for (int it = 0; it < 2; ++it) {                             // one tile of 32 queries at a time (register budget)
             Frag qf[2], gf[2];
-            load_tile_frags(base, row_stride, N, it, lane, qf);
-            load_tile_frags(dob, C, N, it, lane, gf);
+            load_tile_frags(qh, ph, row_stride, codes, it, lane, qf);
+            load_tile_frags(doh, nullptr, C, codes, it, lane, gf);
             f32x16 p[2], dp[2];
             product_keys_by_queries(kf, qf, p);
             softmax_keys(p, scale, bias_h, mask_w, it, lane);
@@ -340,20 +375,20 @@ __global__ __launch_bounds__(THREADS) void window_attention_backward_kernel(
         WATT_WAVE_SYNC();
 #pragma unroll 1
         for (int rt = 0; rt < 2; ++rt)                               // dV[key][ch] = sum_query P^T[key][query] dO[query][ch]
-            product_tile_store(Xt, Tt, rt, gb + 2 * C, row_stride, N, 1.f, lane);
+            product_tile_store(Xt, Tt, rt, gh + 2 * C, gp ? gp + 2 * C : nullptr, row_stride, codes, 1.f, lane);
         WATT_WAVE_SYNC();
-        stage_transposed(Tt, base + C, row_stride, N, lane);
+        stage_transposed(Tt, qh + C, ph ? ph + C : nullptr, row_stride, codes, lane);
         transpose_tile(Xt, dSl, lane);                               // P^T has been read: its tile takes dS^T
         WATT_WAVE_SYNC();
 #pragma unroll 1
         for (int rt = 0; rt < 2; ++rt)                               // dQ[query][ch] = scale sum_key dS[query][key] K[key][ch]
-            product_tile_store(dSl, Tt, rt, gb, row_stride, N, scale, lane);
+            product_tile_store(dSl, Tt, rt, gh, gp, row_stride, codes, scale, lane);
         WATT_WAVE_SYNC();
-        stage_transposed(Tt, base, row_stride, N, lane);
+        stage_transposed(Tt, qh, ph, row_stride, codes, lane);
         WATT_WAVE_SYNC();
 #pragma unroll 1
         for (int rt = 0; rt < 2; ++rt)                               // dK[key][ch] = scale sum_query dS^T[key][query] Q[query][ch]
-            product_tile_store(Xt, Tt, rt, gb + C, row_stride, N, scale, lane);
+            product_tile_store(Xt, Tt, rt, gh + C, gp ? gp + C : nullptr, row_stride, codes, scale, lane);
     }
 }
 
@@ -376,6 +411,36 @@ extern "C" int window_attention_supported(int windows, int heads, int tokens, in
            (long)windows * tokens * heads * HD * 3 < (1L << 31);
 }
 
+namespace {
+int launch_forward(const void *qkv, const void *pad_row, const RowMap &rm, const float *bias_t, const float *mask_t, const int *mask_id,
+                   int windows, int heads, int tokens, float scale, void *out, void *stream)
+{
+    static_assert(WAVES * BWD_WAVE_LDS <= 64 * 1024 && WAVES * FWD_WAVE_LDS <= 64 * 1024, "dynamic LDS within the default limit");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(window_attention_forward_kernel, dim3(grid_for(windows, heads)), dim3(THREADS), WAVES * FWD_WAVE_LDS,
+                       (hipStream_t)stream, (const uint16_t *)qkv, (const uint16_t *)pad_row, rm, bias_t, mask_t, mask_id, windows, heads,
+                       tokens, scale, (uint16_t *)out);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}
+
+int launch_backward(const void *qkv, const void *pad_row, const RowMap &rm, const void *d_out, const float *bias_t, const float *mask_t,
+                    const int *mask_id, int windows, int heads, int tokens, float scale, void *d_qkv, void *d_pad, void *stream)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(window_attention_backward_kernel, dim3(grid_for(windows, heads)), dim3(THREADS), WAVES * BWD_WAVE_LDS,
+                       (hipStream_t)stream, (const uint16_t *)qkv, (const uint16_t *)pad_row, rm, (const uint16_t *)d_out, bias_t, mask_t,
+                       mask_id, windows, heads, tokens, scale, (uint16_t *)d_qkv, (uint16_t *)d_pad);
+    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+}
+
+bool rows_ok(const int *rowmap, int windows, int windows_per_image, int rows_per_image, int pads_per_image, int tokens)
+{
+    return rowmap && windows_per_image >= 1 && windows % windows_per_image == 0 && rows_per_image >= 1 && pads_per_image >= 0 &&
+           (long)(windows / windows_per_image) * rows_per_image < (1L << 30) &&
+           (long)rows_per_image + pads_per_image == (long)windows_per_image * tokens;
+}
+}  // namespace
+
 extern "C" int window_attention_forward_bf16(const void *qkv, const float *bias_t, const float *mask_t, const int *mask_id,
                                              int windows, int windows_per_image, int heads, int tokens, float scale, void *out,
                                              void *stream)
@@ -383,11 +448,8 @@ extern "C" int window_attention_forward_bf16(const void *qkv, const float *bias_
     if (!window_attention_supported(windows, heads, tokens, HD) || windows_per_image < 1) return MSDA_ERR_BAD_SHAPE;
     if (!qkv || !bias_t || !out || ((mask_t == nullptr) != (mask_id == nullptr))) return MSDA_ERR_NULL_POINTER;
     if (!aligned16(qkv) || !aligned16(out)) return MSDA_ERR_ALIGNMENT;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(window_attention_forward_kernel, dim3(grid_for(windows, heads)), dim3(THREADS), WAVES * FWD_WAVE_LDS,
-                       (hipStream_t)stream, (const uint16_t *)qkv, bias_t, mask_t, mask_id, windows, windows_per_image, heads,
-                       tokens, scale, (uint16_t *)out);
-    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+    const RowMap rm = {nullptr, 0, 0, windows_per_image};
+    return launch_forward(qkv, nullptr, rm, bias_t, mask_t, mask_id, windows, heads, tokens, scale, out, stream);
 }
 
 extern "C" int window_attention_backward_bf16(const void *qkv, const void *d_out, const float *bias_t, const float *mask_t,
@@ -397,10 +459,35 @@ extern "C" int window_attention_backward_bf16(const void *qkv, const void *d_out
     if (!window_attention_supported(windows, heads, tokens, HD) || windows_per_image < 1) return MSDA_ERR_BAD_SHAPE;
     if (!qkv || !d_out || !bias_t || !d_qkv || ((mask_t == nullptr) != (mask_id == nullptr))) return MSDA_ERR_NULL_POINTER;
     if (!aligned16(qkv) || !aligned16(d_out) || !aligned16(d_qkv)) return MSDA_ERR_ALIGNMENT;
-    static_assert(WAVES * BWD_WAVE_LDS <= 64 * 1024 && WAVES * FWD_WAVE_LDS <= 64 * 1024, "dynamic LDS within the default limit");
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(window_attention_backward_kernel, dim3(grid_for(windows, heads)), dim3(THREADS), WAVES * BWD_WAVE_LDS,
-                       (hipStream_t)stream, (const uint16_t *)qkv, (const uint16_t *)d_out, bias_t, mask_t, mask_id, windows,
-                       windows_per_image, heads, tokens, scale, (uint16_t *)d_qkv);
-    return hipGetLastError() == hipSuccess ? MSDA_OK : MSDA_ERR_LAUNCH;
+    const RowMap rm = {nullptr, 0, 0, windows_per_image};
+    return launch_backward(qkv, nullptr, rm, d_out, bias_t, mask_t, mask_id, windows, heads, tokens, scale, d_qkv, nullptr, stream);
+}
+
+extern "C" int window_attention_rows_forward_bf16(const void *qkv, const void *pad_row, const int *rowmap, int rows_per_image,
+                                                  int pads_per_image, const float *bias_t, const float *mask_t, const int *mask_id,
+                                                  int windows, int windows_per_image, int heads, int tokens, float scale, void *out,
+                                                  void *stream)
+{
+    if (!window_attention_supported(windows, heads, tokens, HD) ||
+        !rows_ok(rowmap, windows, windows_per_image, rows_per_image, pads_per_image, tokens))
+        return MSDA_ERR_BAD_SHAPE;
+    if (!qkv || !bias_t || !out || ((mask_t == nullptr) != (mask_id == nullptr))) return MSDA_ERR_NULL_POINTER;
+    if (!aligned16(qkv) || !aligned16(out) || !aligned16(pad_row)) return MSDA_ERR_ALIGNMENT;
+    const RowMap rm = {rowmap, rows_per_image, pads_per_image, windows_per_image};
+    return launch_forward(qkv, pad_row, rm, bias_t, mask_t, mask_id, windows, heads, tokens, scale, out, stream);
+}
+
+extern "C" int window_attention_rows_backward_bf16(const void *qkv, const void *pad_row, const int *rowmap, int rows_per_image,
+                                                   int pads_per_image, const void *d_out, const float *bias_t, const float *mask_t,
+                                                   const int *mask_id, int windows, int windows_per_image, int heads, int tokens,
+                                                   float scale, void *d_qkv, void *d_pad, void *stream)
+{
+    if (!window_attention_supported(windows, heads, tokens, HD) ||
+        !rows_ok(rowmap, windows, windows_per_image, rows_per_image, pads_per_image, tokens))
+        return MSDA_ERR_BAD_SHAPE;
+    if (!qkv || !d_out || !bias_t || !d_qkv || ((mask_t == nullptr) != (mask_id == nullptr))) return MSDA_ERR_NULL_POINTER;
+    if (pads_per_image > 0 && pad_row && !d_pad) return MSDA_ERR_NULL_POINTER;
+    if (!aligned16(qkv) || !aligned16(d_out) || !aligned16(d_qkv) || !aligned16(pad_row) || !aligned16(d_pad)) return MSDA_ERR_ALIGNMENT;
+    const RowMap rm = {rowmap, rows_per_image, pads_per_image, windows_per_image};
+    return launch_backward(qkv, pad_row, rm, d_out, bias_t, mask_t, mask_id, windows, heads, tokens, scale, d_qkv, d_pad, stream);
 }

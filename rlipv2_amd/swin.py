@@ -148,6 +148,68 @@ class WindowAttentionFunction(torch.autograd.Function):
         return d_qkv, None, None, None, None, None
 
 
+def window_row_map(H, W, ws, shift, device):
+    """(rowmap [nW * ws * ws] int32, pads): the image-order row of every token of every window as the reference's pad -> roll ->
+    window_partition lays them out (models/swin/swin_transformer.py:362-379); padding positions are -(slot + 1)."""
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    real = torch.zeros(Hp, Wp, dtype=torch.bool)
+    real[:H, :W] = True
+    idx = torch.zeros(Hp, Wp, dtype=torch.int64)
+    idx[real] = torch.arange(H * W)
+    pads = int((~real).sum())
+    idx[~real] = -(torch.arange(pads) + 1)
+    if shift:
+        idx = torch.roll(idx, shifts=(-shift, -shift), dims=(0, 1))
+    m = idx.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1).to(torch.int32).contiguous()
+    return m.to(device), pads
+
+
+class WindowAttentionRowsFunction(torch.autograd.Function):
+    """WindowAttentionFunction with pad / cyclic shift / window partition / reverse / crop folded into the kernels' addressing:
+    qkv [B, H W, 3 C] and the result [B, H W, C] stay in image order, `rowmap` names every window token's row, padding tokens read
+    `pad_row` (the qkv bias: the projection of the zero padding) and their gradient rows are summed into its gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, pad_row, rowmap, pads, bias_t, mask_t, mask_id, heads, scale, tokens):
+        from . import _lib
+        B, T = qkv.shape[0], qkv.shape[1]
+        nW = rowmap.numel() // tokens
+        qkv = qkv.contiguous()
+        pr = None if pad_row is None else pad_row.contiguous()
+        out = torch.empty(B, T, heads * 32, dtype=qkv.dtype, device=qkv.device)
+        st = _lib.lib().window_attention_rows_forward_bf16(
+            qkv.data_ptr(), None if pr is None else pr.data_ptr(), rowmap.data_ptr(), T, pads, bias_t.data_ptr(),
+            None if mask_t is None else mask_t.data_ptr(), None if mask_id is None else mask_id.data_ptr(), B * nW, nW, heads,
+            tokens, float(scale), out.data_ptr(), _norm._stream(qkv))
+        if st:
+            raise RuntimeError("window_attention_rows_forward: " + _lib.strerror(st))
+        ctx.save_for_backward(qkv, pr, rowmap, bias_t, mask_t, mask_id)
+        ctx.meta = (pads, heads, float(scale), tokens)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        from . import _lib
+        qkv, pr, rowmap, bias_t, mask_t, mask_id = ctx.saved_tensors
+        pads, heads, scale, tokens = ctx.meta
+        B, T = qkv.shape[0], qkv.shape[1]
+        nW = rowmap.numel() // tokens
+        d_out = d_out.contiguous()
+        d_qkv = torch.empty_like(qkv)
+        d_pad = torch.empty(B * pads, qkv.shape[2], dtype=qkv.dtype, device=qkv.device) if (pads and pr is not None) else None
+        st = _lib.lib().window_attention_rows_backward_bf16(
+            qkv.data_ptr(), None if pr is None else pr.data_ptr(), rowmap.data_ptr(), T, pads, d_out.data_ptr(), bias_t.data_ptr(),
+            None if mask_t is None else mask_t.data_ptr(), None if mask_id is None else mask_id.data_ptr(), B * nW, nW, heads, tokens,
+            scale, d_qkv.data_ptr(), None if d_pad is None else d_pad.data_ptr(), _norm._stream(qkv))
+        if st:
+            raise RuntimeError("window_attention_rows_backward: " + _lib.strerror(st))
+        g_pad = None
+        if pr is not None and ctx.needs_input_grad[1]:
+            g_pad = d_pad.float().sum(0).to(pr.dtype) if d_pad is not None else torch.zeros_like(pr)
+        return d_qkv, g_pad, None, None, None, None, None, None, None, None
+
+
 class WindowAttention(nn.Module):
     def __init__(self, dim, window_size, num_heads, qkv_bias=True, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
@@ -193,6 +255,17 @@ class WindowAttention(nn.Module):
                 self._bias_t = _padded(b, n, -30000.0)
             self._bias_t_key = key
         return self._bias_t
+
+    def forward_image_order(self, y, mask, rows):
+        """y [B, H, W, C] (normalised, image order) -> [B, H, W, C]: the fused kernel with the row map `rows` = (rowmap, pads) of
+        this block's shift (window_row_map): no pad / roll / partition / reverse copies.  Only when `fused_supported`."""
+        B, H, W, C = y.shape
+        h = self.num_heads
+        packed = token_linear(y.reshape(B, H * W, C), self.qkv.weight, self.qkv.bias)
+        mask_t, mask_id = (None, None) if mask is None else mask.compact
+        out = WindowAttentionRowsFunction.apply(packed, self.qkv.bias, rows[0], rows[1], self.bias_table_t(), mask_t, mask_id, h,
+                                                (C // h) ** -0.5, self.ws * self.ws)
+        return self.proj_drop(token_linear(out, self.proj.weight, self.proj.bias)).view(B, H, W, C)
 
     def forward(self, x, mask):
         """x [B, nW, N, C]; mask None or [nW, N, N] -> [B, nW, N, C]"""
@@ -241,11 +314,15 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio), drop)
 
-    def attention(self, y, mask):
+    def attention(self, y, mask, rows=None):
         """the attention branch on the NORMALISED input y [B, H, W, C] (pad, shift, window partition, attention, reverse),
-        drop-path applied: what is added to the residual stream"""
+        drop-path applied: what is added to the residual stream.  `rows`: the stage's row maps ((unshifted), (shifted)) for the
+        fused kernel, which then does all of that by addressing"""
         B, H, W, C = y.shape
         ws = self.ws
+        m = mask if self.shift else None
+        if rows is not None and self.attn.fused_supported(y) and (m is None or getattr(m, "compact", None) is not None):
+            return self.drop_path(self.attn.forward_image_order(y, m, rows[1 if self.shift else 0]))
         pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
         if pad_r or pad_b:
             y = F.pad(y, (0, 0, 0, pad_r, 0, pad_b))
@@ -261,13 +338,13 @@ class SwinTransformerBlock(nn.Module):
             y = y[:, :H, :W]
         return self.drop_path(y)
 
-    def branches(self, x, pending, mask):
+    def branches(self, x, pending, mask, rows=None):
         """One block on the residual stream `x + pending` (`pending`: the previous block's MLP branch, not yet added; None for
         the first block).  Returns (x, pending'): the stream after this block's attention branch and this block's MLP branch,
         again not yet added -- so that every residual add runs together with the LayerNorm that reads its result
         (norm.residual_pre_norm: one pass on the GPU at the Swin widths, `add` + `layer_norm` otherwise; same values)."""
         x, y = residual_pre_norm(x, pending, self.norm1)
-        x, y = residual_pre_norm(x, self.attention(y, mask), self.norm2)
+        x, y = residual_pre_norm(x, self.attention(y, mask, rows), self.norm2)
         return x, self.drop_path(self.mlp(y))
 
     def forward(self, x, mask):
@@ -302,6 +379,7 @@ class BasicLayer(nn.Module):
                                  drop, attn_drop, dp[i]) for i in range(depth)])
         self.downsample = PatchMerging(dim) if downsample else None
         self._masks = {}
+        self._rows = {}
 
     def forward(self, x, out_norm=None):
         """-> (stage output, input of the next stage, out_norm(stage output) or None)"""
@@ -314,9 +392,15 @@ class BasicLayer(nn.Module):
             m.compact = compact_masks(m) if ws * ws <= 64 else (None, None)      # (for the fused attention kernel)
             self._masks[key] = m
         mask = self._masks[key]
+        rows = None
+        if fused_window_attention and ws * ws <= 64:
+            rkey = (H, W, str(x.device))
+            if rkey not in self._rows:
+                self._rows[rkey] = (window_row_map(H, W, ws, 0, x.device), window_row_map(H, W, ws, self.shift, x.device))
+            rows = self._rows[rkey]
         pending = None
         for blk in self.blocks:
-            x, pending = blk.branches(x, pending, mask)
+            x, pending = blk.branches(x, pending, mask, rows)
         # the last block's MLP branch is added together with the stage's output norm when there is one
         if out_norm is not None:
             x, normed = residual_pre_norm(x, pending, out_norm)

@@ -460,3 +460,98 @@ def test_window_attention_against_torch(lib, N, heads, windows, masked):
     assert lib.window_attention_forward_bf16(ptr(qkv), None, None, None, windows, wpi, heads, N, scale, ptr(out), None) != 0
     assert lib.window_attention_forward_bf16(ptr(qkv), ptr(bias_t), ptr(bias_t), None, windows, wpi, heads, N, scale, ptr(out), None) != 0
     assert lib.window_attention_backward_bf16(ptr(qkv), ptr(d_out), ptr(bias_t), None, None, windows, 0, heads, N, scale, ptr(d_qkv), None) != 0
+
+
+def swin_row_map(H, W, ws, shift):
+    """the image-order row of every token of every window as the reference's pad -> roll -> window_partition lays them out
+    (models/swin/swin_transformer.py:362-379); padding positions -> -(slot + 1).  Returns (map [nW * ws * ws] int32, pads)."""
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    idx = torch.full((Hp, Wp), 0, dtype=torch.int64)
+    real = torch.zeros(Hp, Wp, dtype=torch.bool)
+    real[:H, :W] = True
+    idx[real] = torch.arange(H * W)
+    n_pad = int((~real).sum())
+    idx[~real] = -(torch.arange(n_pad) + 1)
+    if shift:
+        idx = torch.roll(idx, shifts=(-shift, -shift), dims=(0, 1))
+    return idx.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1).to(torch.int32).contiguous(), n_pad
+
+
+@pytest.mark.parametrize("H,W,ws,shift,heads", [(10, 17, 7, 3, 3), (8, 8, 4, 0, 2), (9, 6, 4, 2, 5)])
+def test_window_attention_rows_mode_against_torch(lib, H, W, ws, shift, heads):
+    """the window attention kernels with pad / shift / partition / reverse folded into their addressing (row map, image-order
+    tensors, padding tokens = the projection's bias, their gradient rows in a side buffer) against the reference's op sequence
+    (pad the token map, roll, partition, attention, reverse, roll back, crop) in float32 on the same bf16 operands."""
+    torch.manual_seed(H * W + heads)
+    B, d, N = 2, 32, ws * ws
+    C = heads * d
+    scale = d ** -0.5
+    rowmap, n_pad = swin_row_map(H, W, ws, shift)
+    nW = rowmap.numel() // N
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    qkv = (0.8 * torch.randn(B, H * W, 3 * C)).to(torch.bfloat16)
+    pad_row = (0.5 * torch.randn(3 * C)).to(torch.bfloat16)
+    bias = 0.5 * torch.randn(heads, N, N)
+    mask = None
+    if shift:
+        img = torch.zeros(Hp, Wp)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[hs, wsl] = cnt
+                cnt += 1
+        win = img.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, N)
+        mask = torch.where(win[:, None, :] - win[:, :, None] != 0, torch.tensor(-100.0), torch.tensor(0.0))      # [nW, N, N]
+    # reference: the op sequence in float32
+    q32 = qkv.float().requires_grad_(True)
+    p32 = pad_row.float().requires_grad_(True)
+    full = p32.expand(B, Hp, Wp, 3 * C).clone()
+    full[:, :H, :W] = q32.view(B, H, W, 3 * C)
+    if shift:
+        full = torch.roll(full, shifts=(-shift, -shift), dims=(1, 2))
+    win_t = full.view(B, Hp // ws, ws, Wp // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(B * nW, N, 3, heads, d)
+    q, k, v = (win_t[:, :, t].permute(0, 2, 1, 3) for t in range(3))
+    attn = (q * scale) @ k.transpose(-2, -1) + bias[None]
+    if mask is not None:
+        attn = (attn.view(B, nW, heads, N, N) + mask[None, :, None]).view(-1, heads, N, N)
+    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    ref = o[:, :H, :W].reshape(B, H * W, C)
+    # kernel
+    bias_t = _padded(bias, N, -30000.0)
+    mask_t = mask_id = None
+    if mask is not None:
+        distinct, inv = torch.unique(mask.reshape(nW, -1), dim=0, return_inverse=True)
+        nz = distinct.abs().sum(1) != 0
+        remap = torch.cumsum(nz.int(), 0) - 1
+        mask_id = torch.where(nz[inv], remap[inv], torch.full_like(remap[inv], -1)).to(torch.int32).contiguous()
+        mask_t = _padded(distinct[nz].view(-1, N, N), N, 0.0)
+    out = torch.full((B, H * W, C), float("nan")).to(torch.bfloat16)
+    lg = ctypes.c_long
+    del lg
+    lib.window_attention_rows_forward_bf16.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, vp, vp]
+    lib.window_attention_rows_backward_bf16.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, vp, vp, vp]
+    mp = lambda t: ptr(t) if t is not None else None                                                     # noqa: E731
+    assert lib.window_attention_rows_forward_bf16(ptr(qkv), ptr(pad_row), ptr(rowmap), H * W, n_pad, ptr(bias_t), mp(mask_t), mp(mask_id),
+                                                  B * nW, nW, heads, N, scale, ptr(out), None) == 0
+    assert torch.isfinite(out.float()).all()                        # every real token's row written
+    torch.testing.assert_close(out.float(), ref.detach(), rtol=2.0 ** -6, atol=2.0 ** -6 * float(ref.abs().max()))
+    d_out = torch.randn(B, H * W, C).to(torch.bfloat16)
+    ref.backward(d_out.float())
+    d_qkv = torch.full_like(qkv, float("nan"))
+    d_pad = torch.full((B * max(n_pad, 1), 3 * C), float("nan")).to(torch.bfloat16)
+    assert lib.window_attention_rows_backward_bf16(ptr(qkv), ptr(pad_row), ptr(rowmap), H * W, n_pad, ptr(d_out), ptr(bias_t), mp(mask_t),
+                                                   mp(mask_id), B * nW, nW, heads, N, scale, ptr(d_qkv), ptr(d_pad), None) == 0
+    assert torch.isfinite(d_qkv.float()).all()
+    err = float((d_qkv.float() - q32.grad).abs().max()) / float(q32.grad.abs().max())
+    assert err < 2.0 ** -5, err
+    if n_pad:
+        got = d_pad.float().sum(0)
+        assert torch.isfinite(got).all()
+        assert float((got - p32.grad).abs().max()) <= 2.0 ** -4 * float(p32.grad.abs().max()) + 1e-3       # (a sum of bf16-rounded rows)
+    # argument checks: the map must cover windows x tokens, the tensors must be aligned
+    assert lib.window_attention_rows_forward_bf16(ptr(qkv), ptr(pad_row), ptr(rowmap), H * W + 1, n_pad, ptr(bias_t), mp(mask_t), mp(mask_id),
+                                                  B * nW, nW, heads, N, scale, ptr(out), None) != 0
+    assert lib.window_attention_rows_forward_bf16(ptr(qkv), ptr(pad_row), None, H * W, n_pad, ptr(bias_t), mp(mask_t), mp(mask_id),
+                                                  B * nW, nW, heads, N, scale, ptr(out), None) != 0

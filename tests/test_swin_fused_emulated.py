@@ -29,6 +29,8 @@ def emu_lib(tmp_path_factory):
     L.window_attention_supported.argtypes = [i, i, i, i]
     L.window_attention_forward_bf16.argtypes = [vp, vp, vp, vp, i, i, i, i, f32, vp, vp]
     L.window_attention_backward_bf16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, f32, vp, vp]
+    L.window_attention_rows_forward_bf16.argtypes = [vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, f32, vp, vp]
+    L.window_attention_rows_backward_bf16.argtypes = [vp, vp, vp, i, i, vp, vp, vp, vp, i, i, i, i, f32, vp, vp, vp]
     L.layernorm_wide_supported.argtypes = [lg, i]
     L.layernorm_wide_forward_bf16.argtypes = [vp, vp, vp, vp, lg, i, f32, vp, vp, vp, vp, vp]
     L.layernorm_wide_backward_bf16.argtypes = [vp, vp, vp, vp, vp, vp, lg, i, vp, vp]
@@ -122,8 +124,10 @@ def test_swin_stage_with_both_routes(on_model):
     fused, kinds = run(True)
     plain, kinds_plain = run(False)
     norm.fused_wide_layer_norm = swin.fused_window_attention = False
-    assert {"WindowAttentionFunctionBackward", "WideAddLayerNormFunctionBackward", "WideLayerNormFunctionBackward"} <= kinds, kinds
-    assert not any("Wide" in k or "WindowAttentionFunction" in k for k in kinds_plain)
+    # (the blocks run the image-order form of the attention kernel: no pad / roll / partition copies around it)
+    assert {"WindowAttentionRowsFunctionBackward", "WideAddLayerNormFunctionBackward", "WideLayerNormFunctionBackward"} <= kinds, kinds
+    assert "RollBackward0" not in kinds                              # (a pad remains: patch merging pads odd maps)
+    assert not any("Wide" in k or "WindowAttention" in k for k in kinds_plain) and "RollBackward0" in kinds_plain
     for a, b in zip(fused[:2], plain[:2]):
         assert float((a - b).abs().max()) <= 2.0 ** -5 * float(b.abs().max())
     for a, b in zip(fused[2:], plain[2:]):

@@ -129,7 +129,7 @@ __device__ __forceinline__ void load_tile_frags(const uint16_t *mat, const uint1
     const int kg = (lane >> 5) * 8;
     const uint16_t *row = in_row(mat, pad, row_stride, codes[tile * 32 + (lane & 31)]);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) f[ks] = load_frag(row + ks * 16 + kg, row != nullptr);
+    for (int ks = 0; ks < 2; ++ks) f[ks] = load_frag(row ? row + ks * 16 + kg : nullptr, row != nullptr);
 }
 
 // x^T[jt][r] = sum over the 32 channels of  rows[key jt * 32 + acc_row(r)] . cols[this tile's query lane & 31]

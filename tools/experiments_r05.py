@@ -93,64 +93,46 @@ def child_forward():
 
 
 def child_swin():
-    """the two Swin routes of round 5 at the stage-0 shapes of Swin-L on 800 x 1333 (batch 2: 2 x 1 392 windows of 49 tokens, 6 heads,
-    192 channels): module forward + backward, fused kernel against the PyTorch op sequence -- agreement and HIP-event times"""
+    """the Swin routes of round 5 at stage 0 of Swin-L on 800 x 1333 (batch 2: [2, 200, 334, 192], 6 heads, window 7): one
+    BasicLayer (two blocks, the second shifted; padded to 203 x 336) forward + backward with fused_window_attention (image-order
+    kernel: pad / shift / partition as addressing) and fused_wide_layer_norm against the PyTorch op sequence -- agreement and
+    HIP-event times; then the stage's weight gradients"""
     import torch
     from rlipv2_amd import norm, swin
     from tools.patch_check import timed
     out = {}
     torch.manual_seed(0)
     dev = "cuda:0"
-    C, heads, ws, B, Hp, Wp = 192, 6, 7, 2, 203, 336
-    attn = swin.WindowAttention(C, ws, heads).to(dev).to(torch.bfloat16)
-    attn.relative_position_bias_table.requires_grad_(False)
-    mask = swin.shift_mask(Hp, Wp, ws, ws // 2, dev)
-    mask.compact = swin.compact_masks(mask)
-    nW = (Hp // ws) * (Wp // ws)
-    x0 = torch.randn(B, nW, ws * ws, C, device=dev).to(torch.bfloat16)
+    C, heads, B = 192, 6, 2
+    layer = swin.BasicLayer(C, 2, heads, window_size=7, downsample=False).to(dev).to(torch.bfloat16)
+    for n, p in layer.named_parameters():
+        if "norm" in n or "relative_position_bias_table" in n:
+            p.requires_grad_(False)                                 # the reference's freezing rule (models/swin/backbone.py:66-69)
+    x0 = torch.randn(B, 200, 334, C, device=dev).to(torch.bfloat16)
     gy = torch.randn_like(x0)
     res, t = {}, {}
 
-    def attn_step():
+    def step():
+        for p in layer.parameters():
+            p.grad = None
         x = x0.clone().requires_grad_(True)
-        y = attn(x, mask)
+        y, _, _ = layer(x)
         y.backward(gy)
         return y.detach().float(), x.grad.float()
     for fused in (False, True):
-        swin.fused_window_attention = fused
+        norm.fused_wide_layer_norm = swin.fused_window_attention = fused
         try:
-            res[fused] = attn_step()
+            res[fused] = step()
             torch.cuda.synchronize()
-            t[fused] = round(timed(attn_step, iters=10), 1)
+            t[fused] = round(timed(step, iters=5), 1)
         finally:
-            swin.fused_window_attention = False
+            norm.fused_wide_layer_norm = swin.fused_window_attention = False
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))                                     # noqa: E731
-    out["window_attention_module_fwd_bwd"] = {"ops_us": t[False], "fused_us": t[True], "rel_l2_out": rel(res[True][0], res[False][0]),
-                                              "rel_l2_dx": rel(res[True][1], res[False][1]),
-                                              "finite": bool(torch.isfinite(res[True][0]).all() and torch.isfinite(res[True][1]).all())}
-    ln = torch.nn.LayerNorm(C).to(dev).to(torch.bfloat16)
-    for p in ln.parameters():
-        p.requires_grad_(False)
-    a0 = torch.randn(B, 200, 334, C, device=dev).to(torch.bfloat16)
-    b0 = torch.randn_like(a0)
-    g1, g2 = torch.randn_like(a0), torch.randn_like(a0)
-
-    def ln_step():
-        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
-        s_, y = norm.residual_pre_norm(a, b, ln)
-        torch.autograd.backward([s_, y], [g1, g2])
-        return y.detach().float(), a.grad.float()
-    for fused in (False, True):
-        norm.fused_wide_layer_norm = fused
-        try:
-            res[fused] = ln_step()
-            torch.cuda.synchronize()
-            t[fused] = round(timed(ln_step, iters=10), 1)
-        finally:
-            norm.fused_wide_layer_norm = False
-    out["residual_add_layer_norm_fwd_bwd"] = {"ops_us": t[False], "fused_us": t[True], "rel_l2_y": rel(res[True][0], res[False][0]),
-                                              "rel_l2_dx": rel(res[True][1], res[False][1]),
-                                              "note": "both timings include two clones of the 51 MB inputs"}
+    out["stage0_two_blocks_fwd_bwd"] = {"ops_us": t[False], "fused_us": t[True], "rel_l2_out": rel(res[True][0], res[False][0]),
+                                        "rel_l2_dx": rel(res[True][1], res[False][1]),
+                                        "finite": bool(torch.isfinite(res[True][0]).all() and torch.isfinite(res[True][1]).all()),
+                                        "note": "both timings include a clone of the 51 MB input"}
+    del layer, res
     # weight gradients of stage 0 (192 / 576 channels: 64-multiples the MFMA weight-gradient kernel does not take): the library
     # GEMM against the kernel on zero-padded operands (linear.pad_wgrad_to_128)
     from rlipv2_amd import linear

@@ -365,7 +365,8 @@ class PatchMerging(nn.Module):
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
-        return token_linear(self.norm(x), self.reduction.weight, None)
+        _, y = residual_pre_norm(x, None, self.norm)                # (the fused LayerNorm at 768 / 1 536 channels when its route is on)
+        return token_linear(y, self.reduction.weight, None)
 
 
 class BasicLayer(nn.Module):

@@ -581,6 +581,7 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
         }
     if experiments is not None:
         line["experiments"] = experiments
+        emit.child_timed_out = "timed out" in json.dumps(experiments)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
     print(json.dumps(line), flush=True)
@@ -766,6 +767,12 @@ def main():
                  experiments=run_experiments(args, world))
         if world > 1:
             dist.destroy_process_group()
+        if getattr(emit, "child_timed_out", False):
+            # a never-run experiment kernel hung in its child process and was killed: the line above is complete; do not let
+            # this process's teardown wait on a device that may be recovering
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         return
     calls = build_msda_step(args.batch, dtype, device, rank)
     stream = torch.cuda.current_stream().cuda_stream

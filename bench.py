@@ -579,11 +579,14 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
                     "FlopCounterMode + the library kernels' own operand accounting): inputs + outputs of every op "
                     "once, in the step's dtypes; frac = max(T_mem, T_mfma) / measured ms_per_step",
         }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
+    # (LAST, after everything of this process that touches the GPU: the arms run in child processes, and one that has never run
+    #  on hardware may leave the device recovering when it is killed)
+    experiments = experiments() if callable(experiments) else experiments
     if experiments is not None:
         line["experiments"] = experiments
         emit.child_timed_out = "timed out" in json.dumps(experiments)
-    if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
     print(json.dumps(line), flush=True)
 
 
@@ -764,7 +767,7 @@ def main():
                              "the timed region (the timed steps replay HIP graphs, whose kernels cannot be bracketed)")
                  if graphed else None, step_roofline=step_roofline, host_routes=host_routes,
                  b0=b0_signature_kernels(args.batch, dtype, device) if args.backbone == "resnet50" else None,
-                 experiments=run_experiments(args, world))
+                 experiments=lambda: run_experiments(args, world))
         if world > 1:
             dist.destroy_process_group()
         if getattr(emit, "child_timed_out", False):

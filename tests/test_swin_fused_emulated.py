@@ -132,3 +132,57 @@ def test_swin_stage_with_both_routes(on_model):
         assert float((a - b).abs().max()) <= 2.0 ** -5 * float(b.abs().max())
     for a, b in zip(fused[2:], plain[2:]):
         assert float((a - b).norm()) <= 4e-2 * float(b.norm()) + 1e-3, (float((a - b).norm()), float(b.norm()))
+
+
+def test_whole_backbone_with_both_routes(on_model):
+    """SwinTransformer at the Swin-T widths (96 / 192 / 384 / 768: every width the LayerNorm kernel is built for that a backbone
+    preset uses below Swin-L's 1536) on an image whose maps need patch, window and merge padding at every stage, drop path off:
+    the three output maps and the gradients of the image and of every trainable parameter, both routes on against both off"""
+    torch.manual_seed(11)
+    m = swin.SwinTransformer(embed_dim=96, depths=(2, 2, 2, 2), num_heads=(3, 6, 12, 24), window_size=7, drop_path_rate=0.0,
+                             out_indices=(1, 2, 3)).to(torch.bfloat16)
+    for n, p in m.named_parameters():
+        if "norm" in n or "relative_position_bias_table" in n:
+            p.requires_grad_(False)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, swin.WindowAttention):
+                mod.relative_position_bias_table.add_((0.3 * torch.randn(mod.relative_position_bias_table.shape)).to(torch.bfloat16))
+    img = torch.randn(1, 3, 70, 90).to(torch.bfloat16)
+    params = [p for p in m.parameters() if p.requires_grad]
+    probes = None
+
+    def run(on):
+        nonlocal probes
+        norm.fused_wide_layer_norm = swin.fused_window_attention = on
+        for p in params:
+            p.grad = None
+        x = img.clone().requires_grad_(True)
+        outs = m(x)
+        if probes is None:
+            probes = {k: torch.randn(v.shape).to(torch.bfloat16) for k, v in outs.items()}
+        loss = sum((v.float() * probes[k].float()).sum() for k, v in outs.items())
+        seen, stack = {}, [loss.grad_fn]
+        while stack:
+            n = stack.pop()
+            if n is not None and id(n) not in seen:
+                seen[id(n)] = n
+                stack.extend(f for f, _ in n.next_functions)
+        names = [type(n).__name__ for n in seen.values()]
+        loss.backward()
+        return ([v.detach().float() for _, v in sorted(outs.items())], [x.grad.float()] + [p.grad.float() for p in params],
+                {k: names.count(k) for k in set(names)})
+    outs_on, grads_on, kinds = run(True)
+    outs_off, grads_off, kinds_off = run(False)
+    norm.fused_wide_layer_norm = swin.fused_window_attention = False
+    assert len(outs_on) == 3
+    # every one of the 8 blocks took the image-order attention kernel and both of its fused residual norms
+    assert kinds.get("WindowAttentionRowsFunctionBackward") == 8 and "RollBackward0" not in kinds, kinds
+    assert kinds.get("WideAddLayerNormFunctionBackward", 0) + kinds.get("WideLayerNormFunctionBackward", 0) >= 16 + 3, kinds
+    assert not any("Wide" in k or "WindowAttention" in k for k in kinds_off)
+    for a, b in zip(outs_on, outs_off):
+        assert float((a - b).norm()) <= 2e-2 * float(b.norm())
+    whole = sum(float((a - b).norm()) ** 2 for a, b in zip(grads_on, grads_off)) ** 0.5
+    assert whole <= 4e-2 * sum(float(b.norm()) ** 2 for b in grads_off) ** 0.5
+    for a, b in zip(grads_on, grads_off):
+        assert float((a - b).norm()) <= 8e-2 * float(b.norm()) + 1e-3, (float((a - b).norm()), float(b.norm()))

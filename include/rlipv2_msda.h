@@ -214,6 +214,41 @@ int msda_fused_backward_ws(int flags, int dtype,
                            void *grad_value, void *grad_qproj,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the "records" route of a bfloat16 encoder call (Lq == S, D = 32, L = P = 4) -------------------------------------------
+ * (csrc/msda_cell_forward.inc with EMIT, csrc/msda_cell_records.inc; round 5, written without a GPU: explicit entry points,
+ *  never picked by the AUTO variants.)  The forward pass (MSDA_VARIANT_CELL's kernel) leaves, in ONE caller-owned buffer of
+ * msda_records_bytes, what the backward pass would otherwise recompute from float32 sampling_loc / attn_weight: a 16-byte
+ * record per sample (window offset of its top-left corner, the two bilinear fractions, the attention weight), the LDS window
+ * table of every (image, head, cell) and the patch masks + group records of the grad_value pass.  The backward pass then runs
+ * no sample geometry and no binning: gradients of the locations / weights (reference ms_deform_im2col_cuda.cuh:87-159) from the
+ * records on v_mfma_f32_4x4x4_16B_bf16, grad_value from the matrix-core patch pass; results are bit-identical to
+ * msda_backward_ws / msda_fused_backward_ws on the same call.
+ *   refdim 0: the op's signature -- sampling_loc / attn_weight are INPUTS of both calls (qproj, ref, grad_qproj NULL);
+ *   refdim 2 / 4: the module's operands (msda_fused_forward) -- sampling_loc / attn_weight are OUTPUTS of the forward and
+ *                 inputs of the backward (the sorting fallback for "far" samples and the softmax backward read them),
+ *                 grad_sampling_loc / grad_attn_weight NULL.
+ * msda_records_bytes: 0 = the route does not take this call.  flags of the backward: MSDA_FLAG_GRAD_VALUE_BF16 (required:
+ * the patch pass writes bfloat16 or float32 rows; pass it for bfloat16 grad_value), MSDA_FLAG_RECORDS_SWAP (operand order of
+ * the 4x4x4 products, an experiment arm).  workspace: msda_backward_workspace_bytes, as for msda_backward_ws. */
+#define MSDA_FLAG_RECORDS_SWAP 0x400
+size_t msda_records_bytes(int dtype, const int64_t *spatial_shapes_host, int N, int S, int M, int D, int L, int Lq, int P);
+int msda_records_forward(int dtype,
+                         const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                         const int64_t *spatial_shapes_host,
+                         const void *qproj, const float *ref, int refdim,
+                         float *sampling_loc, float *attn_weight,
+                         int N, int S, int M, int D, int L, int Lq, int P,
+                         void *out, void *records, size_t records_bytes, void *stream);
+int msda_records_backward(int flags, int dtype,
+                          const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                          const int64_t *spatial_shapes_host,
+                          const float *sampling_loc, const float *attn_weight, const float *ref, int refdim,
+                          const void *grad_out,
+                          int N, int S, int M, int D, int L, int Lq, int P,
+                          void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, void *grad_qproj,
+                          const void *records, size_t records_bytes,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* The reference's batch-chunking precondition (cuda/ms_deform_attn_cuda.cu:50-52). */
 int msda_check_im2col_step(int batch, int im2col_step);
 

@@ -18,7 +18,7 @@ MSDA_F32, MSDA_F64, MSDA_BF16 = 0, 1, 2
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_QUAD, VARIANT_WINDOW, VARIANT_DEST, VARIANT_COARSE, VARIANT_CELL = 0, 1, 2, 3, 4, 5, 6
 VARIANTS = {"auto": VARIANT_AUTO, "generic": VARIANT_GENERIC, "quad": VARIANT_QUAD, "window": VARIANT_WINDOW,
             "dest": VARIANT_DEST, "coarse": VARIANT_COARSE, "cell": VARIANT_CELL}
-FLAG_GRAD_VALUE_ZEROED, FLAG_GRAD_VALUE_BF16 = 0x100, 0x200
+FLAG_GRAD_VALUE_ZEROED, FLAG_GRAD_VALUE_BF16, FLAG_RECORDS_SWAP = 0x100, 0x200, 0x400
 
 EXPORTS = (
     "msda_forward", "msda_backward", "msda_forward_ex", "msda_backward_ex", "msda_check_im2col_step",
@@ -26,6 +26,7 @@ EXPORTS = (
     "msda_prepare_forward", "msda_prepare_backward", "msda_backward_workspace_bytes", "msda_backward_ws",
     "msda_backward_plan_info", "msda_forward_hs", "msda_fused_forward_hs",
     "msda_fused_supported", "msda_fused_forward", "msda_fused_backward_ws", "msda_rows_backward_supported", "msda_rows_backward",
+    "msda_records_bytes", "msda_records_forward", "msda_records_backward",
     # include/rlipv2_linear.h
     "linear_wgrad_workspace_bytes", "linear_wgrad_supported", "linear_wgrad_bf16",
     "linear_expand_supported", "linear_expand_bf16",
@@ -106,6 +107,12 @@ def lib() -> ctypes.CDLL:
     L.msda_rows_backward_supported.argtypes = [i, vp, i, i, i, i, i, i]
     L.msda_rows_backward.argtypes = [i, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp, vp, vp, vp]
     L.msda_rows_backward_supported.restype = L.msda_rows_backward.restype = i
+    L.msda_records_bytes.argtypes = [i, vp, *dims]
+    L.msda_records_bytes.restype = ctypes.c_size_t
+    L.msda_records_forward.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, vp, *dims, vp, vp, ctypes.c_size_t, vp]
+    L.msda_records_backward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, i, vp, *dims, vp, vp, vp, vp, vp, ctypes.c_size_t, vp,
+                                        ctypes.c_size_t, vp]
+    L.msda_records_forward.restype = L.msda_records_backward.restype = i
     L.msda_check_im2col_step.argtypes = [i, i]
     L.msda_check_im2col_step.restype = i
     L.msda_algorithmic_bytes.argtypes = [i, i, *dims]

@@ -394,6 +394,78 @@ int msda_fused_backward_ws(int flags, int dtype, const void *value, const int64_
     return finish_launch();
 }
 
+size_t msda_records_bytes(int dtype, const int64_t *spatial_shapes_host, int N, int S, int M, int D, int L, int Lq, int P)
+{
+    if (validate(dtype, N, S, M, D, L, Lq, P) != MSDA_OK || !spatial_shapes_host) return 0;
+    if ((long)N * S * M * D == 0 || (long)N * Lq * M * L * P == 0) return 0;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = &p;                                   // (cell_forward_supports wants a value pointer; only the shape matters here)
+    if (!dest_shapes_consistent(p, spatial_shapes_host) || !dest_supports(p, spatial_shapes_host)) return 0;
+    return cell_records_bytes(p, spatial_shapes_host);
+}
+
+int msda_records_forward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                         const int64_t *spatial_shapes_host, const void *qproj, const float *ref, int refdim,
+                         float *sampling_loc, float *attn_weight, int N, int S, int M, int D, int L, int Lq, int P, void *out,
+                         void *records, size_t records_bytes, void *stream)
+{
+    const int st = validate(dtype, N, S, M, D, L, Lq, P);
+    if (st != MSDA_OK) return st;
+    if (refdim != 0 && refdim != 2 && refdim != 4) return MSDA_ERR_BAD_VARIANT;
+    const size_t need = msda_records_bytes(dtype, spatial_shapes_host, N, S, M, D, L, Lq, P);
+    if (need == 0) return MSDA_ERR_BAD_VARIANT;
+    if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !out || !records) return MSDA_ERR_NULL_POINTER;
+    if (refdim != 0 && (!qproj || !ref)) return MSDA_ERR_NULL_POINTER;
+    if (records_bytes < need) return MSDA_ERR_BAD_SHAPE;
+    if (!(aligned16(value) && aligned16(sampling_loc) && aligned16(attn_weight) && aligned16(out) && aligned16(records) &&
+          aligned16(qproj) && aligned16(ref)))
+        return MSDA_ERR_ALIGNMENT;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.loc = sampling_loc; p.aw = attn_weight;
+    p.out = out; p.stream = (hipStream_t)stream;
+    Fused f{};
+    f.qproj = qproj; f.ref = ref; f.refdim = refdim; f.loc_save = sampling_loc; f.aw_save = attn_weight;
+    (void)hipGetLastError();
+    launch_cell_forward(p, spatial_shapes_host, refdim ? &f : nullptr, records);
+    return finish_launch();
+}
+
+int msda_records_backward(int flags, int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                          const int64_t *spatial_shapes_host, const float *sampling_loc, const float *attn_weight,
+                          const float *ref, int refdim, const void *grad_out, int N, int S, int M, int D, int L, int Lq, int P,
+                          void *grad_value, void *grad_sampling_loc, void *grad_attn_weight, void *grad_qproj,
+                          const void *records, size_t records_bytes, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int st = validate(dtype, N, S, M, D, L, Lq, P);
+    if (st != MSDA_OK) return st;
+    if (refdim != 0 && refdim != 2 && refdim != 4) return MSDA_ERR_BAD_VARIANT;
+    const size_t need = msda_records_bytes(dtype, spatial_shapes_host, N, S, M, D, L, Lq, P);
+    if (need == 0) return MSDA_ERR_BAD_VARIANT;
+    const bool out_bf16 = (flags & MSDA_FLAG_GRAD_VALUE_BF16) != 0;
+    if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_out || !grad_value || !records ||
+        !workspace)
+        return MSDA_ERR_NULL_POINTER;
+    if (refdim == 0 ? (!grad_sampling_loc || !grad_attn_weight) : (!ref || !grad_qproj)) return MSDA_ERR_NULL_POINTER;
+    Problem p{};
+    p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
+    p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.loc = sampling_loc; p.aw = attn_weight;
+    p.grad_out = grad_out; p.g_value = grad_value; p.g_loc = grad_sampling_loc; p.g_aw = grad_attn_weight;
+    p.stream = (hipStream_t)stream;
+    if (records_bytes < need || workspace_bytes < dest_workspace_bytes(p, spatial_shapes_host)) return MSDA_ERR_BAD_SHAPE;
+    if (!(aligned16(value) && aligned16(sampling_loc) && aligned16(attn_weight) && aligned16(grad_out) && aligned16(grad_value) &&
+          aligned16(grad_sampling_loc) && aligned16(grad_attn_weight) && aligned16(grad_qproj) && aligned16(ref) &&
+          aligned16(records) && aligned16(workspace)))
+        return MSDA_ERR_ALIGNMENT;
+    Fused f{};
+    f.ref = ref; f.refdim = refdim; f.g_qproj = grad_qproj;
+    (void)hipGetLastError();
+    launch_backward_dest(p, refdim ? &f : nullptr, spatial_shapes_host, workspace, out_bf16, records,
+                         (flags & MSDA_FLAG_RECORDS_SWAP) != 0);
+    return finish_launch();
+}
+
 int msda_forward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
                  const void *sampling_loc, const void *attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
                  void *out, void *stream)

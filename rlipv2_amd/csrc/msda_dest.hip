@@ -708,10 +708,11 @@ size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host)
 }
 
 // K1 + grad_value.  out_bf16: grad_value is bfloat16.
-void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shapes_host, void *workspace, bool out_bf16)
+void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shapes_host, void *workspace, bool out_bf16,
+                          const void *records, bool records_swap)
 {
     auto k1 = [&]() { if (f) launch_quad_backward_reduce_fused(p, *f); else launch_quad_backward_reduce(p); };
-    if (sparse_dest_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_SPARSE", 1)) {
+    if (!records && sparse_dest_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_SPARSE", 1)) {
         k1();
         launch_sparse_dest(p, shapes_host, out_bf16);      // few queries: per-(image, head, level) pass, see msda_sparse.hip
         return;
@@ -728,7 +729,11 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
     // word zero and return at once.  Only when the binning met a sample outside its cell's reach (gate != 0: the patch
     // pass has returned without writing) does the sorting pass run.
     const int *gate = nullptr;
-    if (patch_workspace_bytes(p, shapes_host) > 0 && ablation_env("RLIPV2_MSDA_PATCH", 1)) {
+    if (records) {
+        // the "records" route (msda_cell_records.inc): the forward pass has left every sample's geometry, the patch masks and
+        // the group records; nothing is binned here
+        gate = launch_cell_records_backward(p, f, shapes_host, records, out_bf16, records_swap);
+    } else if (patch_workspace_bytes(p, shapes_host) > 0 && ablation_env("RLIPV2_MSDA_PATCH", 1)) {
         int *ctl = counter;
         void *pws = ws + round16(kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl));
         const bool cell = cell_backward_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_CELL", 1);

@@ -77,7 +77,9 @@ bool dest_supports(const Problem &p, const int64_t *shapes_host);
 int dest_shapes_consistent(const Problem &p, const int64_t *shapes_host);
 size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host);
 // the whole backward pass of a call with host shapes: K1 (f != nullptr: with the fused geometry epilogue) + grad_value
-void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shapes_host, void *workspace, bool out_bf16);
+// `records` (optional): the buffer cell_forward_kernel<., EMIT> filled for this call -- the "records" route of msda_patch.hip
+void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shapes_host, void *workspace, bool out_bf16,
+                          const void *records = nullptr, bool records_swap = false);
 // encoder calls (Lq == S) with bfloat16 gradients: wave-autonomous 4x4-pixel patches on the matrix cores (msda_patch.hip).
 // `ctl` = the zeroed control block of launch_dest_scatter (word 60 = "a sample was out of reach, fall back"),
 // `mask_ws` = patch_workspace_bytes of scratch
@@ -89,7 +91,13 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
 bool cell_backward_supports(const Problem &p, const int64_t *shapes_host);
 // forward pass of an encoder call from LDS windows on the matrix cores (explicit variant MSDA_VARIANT_CELL; msda_patch.hip)
 bool cell_forward_supports(const Problem &p, const int64_t *shapes_host);
-void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fused *f);   // f: fused geometry (saves loc / aw)
+void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fused *f, void *records = nullptr);   // f: fused geometry (saves loc / aw)
+// the "records" route (experiment, msda_cell_records.inc): the forward leaves per-sample records + the patch pass's masks and
+// group records in one buffer of cell_records_bytes, the backward pass consumes them (no geometry, no binning)
+bool cell_records_supports(const Problem &p, const int64_t *shapes_host);
+size_t cell_records_bytes(const Problem &p, const int64_t *shapes_host);
+const int *launch_cell_records_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, const void *records,
+                                        bool out_bf16, bool swap);
 // the plan of the cell + patch route as int32 values (include/rlipv2_msda.h: msda_backward_plan_info); 0 = route not taken
 int patch_plan_info(const Problem &p, const int64_t *shapes_host, int32_t *out, int out_len);
 void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, int *ctl, void *mask_ws);

@@ -1356,6 +1356,7 @@ namespace {
 #endif
 #define MSDA_MFMA444(a, b, c) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0)
 #include "msda_cell_forward.inc"
+#include "msda_cell_records.inc"
 #undef MSDA_DEVFN
 #undef MSDA_KERNEL_BOUNDS
 #undef MSDA_LDS_DYNAMIC
@@ -1487,25 +1488,106 @@ bool cell_forward_supports(const Problem &p, const int64_t *shapes_host)
     return true;
 }
 
+// ---- the records buffer: what cell_forward_kernel<., EMIT> leaves for the backward pass (one allocation, saved by the caller)
+//   [control block 256 B | window table 128 B per (image, head, cell) | sample records 256 B per (.., query of the cell)
+//    | patch masks | group records]            (the last two exactly as launch_patch_dest expects them: masks, then records)
+struct RecordsLayout { size_t wtab, srec, masks, total; };
+constexpr size_t kRecCtlBytes = 256;
+static RecordsLayout records_layout(const Problem &p, const PatchPlan &pl)
+{
+    const size_t items = (size_t)p.N * p.M * pl.CY * pl.CX;
+    RecordsLayout r;
+    r.wtab = kRecCtlBytes;
+    r.srec = r.wtab + items * kL * 8 * 4;
+    r.masks = r.srec + items * kCellQ * 256;
+    r.total = r.masks + mask_bytes(p, pl) + rec_bytes(p, pl);
+    return r;
+}
+
+bool cell_records_supports(const Problem &p, const int64_t *shapes_host)
+{
+    PatchPlan pl;
+    if (!cell_forward_supports(p, shapes_host) || !patch_supports(p, shapes_host) || !make_patch_plan(p, shapes_host, pl)) return false;
+    if (pl.bin_lds > kFwdWinBytes || !quad_supports(p)) return false;         // the forward's mask table; buffer addressing of the direct route
+    return (size_t)p.N * p.M * pl.CY * pl.CX * kCellQ * 16 < ((size_t)1 << 31);
+}
+
+size_t cell_records_bytes(const Problem &p, const int64_t *shapes_host)
+{
+    PatchPlan pl;
+    if (!cell_records_supports(p, shapes_host) || !make_patch_plan(p, shapes_host, pl)) return 0;
+    return records_layout(p, pl).total;
+}
+
 // out = forward pass of an encoder call, cell_forward_kernel (explicit variant MSDA_VARIANT_CELL); f != nullptr: the module's
-// operands (projection rows + reference points), f->loc_save / f->aw_save receive the float32 locations / weights
-void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fused *f)
+// operands (projection rows + reference points), f->loc_save / f->aw_save receive the float32 locations / weights.
+// records != nullptr (cell_records_bytes): the kernel also leaves the backward pass's records, masks and group records there
+void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fused *f, void *records)
 {
     PatchPlan pl;
     make_patch_plan(p, shapes_host, pl);
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
-#define MSDA_CELL_FWD(RD, LOC, AW)                                                                                    \
+    unsigned char *rb = reinterpret_cast<unsigned char *>(records);
+    const RecordsLayout rl = records_layout(p, pl);
+    if (rb && hipMemsetAsync(rb, 0, kRecCtlBytes, p.stream) != hipSuccess) return;      // (the error stays recorded)
+    int *rctl = reinterpret_cast<int *>(rb);
+    int *wtab = rb ? reinterpret_cast<int *>(rb + rl.wtab) : nullptr;
+    uint4 *srec = rb ? reinterpret_cast<uint4 *>(rb + rl.srec) : nullptr;
+    uint32_t *masks = rb ? reinterpret_cast<uint32_t *>(rb + rl.masks) : nullptr;
+    float *grecs = rb ? reinterpret_cast<float *>(rb + rl.masks + mask_bytes(p, pl)) : nullptr;
+#define MSDA_CELL_FWD(RD, EMIT, LOC, AW)                                                                              \
     do {                                                                                                              \
-        RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)cell_forward_kernel<RD>,                       \
+        RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)cell_forward_kernel<RD, EMIT>,                 \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));       \
-        hipLaunchKernelGGL((cell_forward_kernel<RD>), grid, block, kFwdLds, p.stream, pl, (const bf16_t *)p.value, p.starts, \
+        hipLaunchKernelGGL((cell_forward_kernel<RD, EMIT>), grid, block, kFwdLds, p.stream, pl, (const bf16_t *)p.value, p.starts, \
                            (float *)(LOC), (float *)(AW), p.N, p.S, p.M, p.Lq, (bf16_t *)p.out,                       \
-                           (const bf16_t *)(f ? f->qproj : nullptr), f ? f->ref : nullptr, p.shapes);                 \
+                           (const bf16_t *)(f ? f->qproj : nullptr), f ? f->ref : nullptr, p.shapes, wtab, srec, masks, grecs, rctl); \
     } while (0)
-    if (!f) MSDA_CELL_FWD(0, const_cast<void *>(p.loc), const_cast<void *>(p.aw));      // (REFDIM 0 only reads them)
-    else if (f->refdim == 2) MSDA_CELL_FWD(2, f->loc_save, f->aw_save);
-    else MSDA_CELL_FWD(4, f->loc_save, f->aw_save);
+    if (!rb) {
+        if (!f) MSDA_CELL_FWD(0, 0, const_cast<void *>(p.loc), const_cast<void *>(p.aw));      // (REFDIM 0 only reads them)
+        else if (f->refdim == 2) MSDA_CELL_FWD(2, 0, f->loc_save, f->aw_save);
+        else MSDA_CELL_FWD(4, 0, f->loc_save, f->aw_save);
+    } else {
+        if (!f) MSDA_CELL_FWD(0, 2, const_cast<void *>(p.loc), const_cast<void *>(p.aw));
+        else if (f->refdim == 2) MSDA_CELL_FWD(2, 2, f->loc_save, f->aw_save);
+        else MSDA_CELL_FWD(4, 2, f->loc_save, f->aw_save);
+    }
 #undef MSDA_CELL_FWD
+}
+
+// The backward pass from the records: cell_records_backward_kernel (grad_sampling_loc / grad_attn_weight, or the projection
+// row's gradient with f) + the matrix-core patch pass on the masks / group records the forward wrote.  `gate` (returned) is the
+// "far sample" word of the records' control block: non-zero -> the patch pass has returned without writing and the caller's
+// sorting pass must produce grad_value.
+const int *launch_cell_records_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, const void *records,
+                                        bool out_bf16, bool swap)
+{
+    PatchPlan pl;
+    make_patch_plan(p, shapes_host, pl);
+    const RecordsLayout rl = records_layout(p, pl);
+    unsigned char *rb = reinterpret_cast<unsigned char *>(const_cast<void *>(records));
+    int *rctl = reinterpret_cast<int *>(rb);
+    const int *wtab = reinterpret_cast<const int *>(rb + rl.wtab);
+    const uint4 *srec = reinterpret_cast<const uint4 *>(rb + rl.srec);
+    const unsigned vbytes = (unsigned)((size_t)p.N * p.S * p.M * kD * 2);
+    const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
+#define MSDA_REC_K(RD, SWAP)                                                                                          \
+    do {                                                                                                              \
+        RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)cell_records_backward_kernel<RD, SWAP>,        \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kFwdWinBytes));  \
+        hipLaunchKernelGGL((cell_records_backward_kernel<RD, SWAP>), grid, block, kFwdWinBytes, p.stream, pl,         \
+                           (const bf16_t *)p.value, p.shapes, p.starts, srec, wtab, (const float *)p.aw,              \
+                           (const bf16_t *)p.grad_out, p.N, p.S, p.M, p.Lq, vbytes, (float *)p.g_loc, (float *)p.g_aw, \
+                           f ? f->ref : nullptr, (bf16_t *)(f ? f->g_qproj : nullptr));                               \
+    } while (0)
+#define MSDA_REC(RD) do { if (swap) MSDA_REC_K(RD, true); else MSDA_REC_K(RD, false); } while (0)
+    if (!f) MSDA_REC(0);
+    else if (f->refdim == 2) MSDA_REC(2);
+    else MSDA_REC(4);
+#undef MSDA_REC
+#undef MSDA_REC_K
+    launch_patch_dest(p, shapes_host, rctl, rb + rl.masks, out_bf16, true);
+    return rctl + kFarWord;
 }
 
 bool cell_backward_supports(const Problem &p, const int64_t *shapes_host)

@@ -1,0 +1,208 @@
+"""The "records" route of the encoder backward (csrc/msda_cell_forward.inc with EMIT, csrc/msda_cell_records.inc; round 5, never
+run on hardware) on the lane-level model of tools/emu/, through the C ABI (msda_records_bytes / msda_records_forward /
+msda_records_backward): the forward pass leaves a 16-byte record per sample, the cells' window tables and the patch pass's masks
+and group records; the backward pass then runs no sample geometry and no binning.
+
+The bar is the verdict's: BIT-EQUAL to the product kernels (msda_backward_ws / msda_fused_backward_ws: cell_backward_kernel +
+patch_dest_kernel, both validated on hardware in round 3) on the same call, both operand orders of the 4x4x4 products; the
+oracle is only the cross-check that the product route itself is right on these inputs."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import msda_oracle as O  # noqa: E402  (tests may use the oracle)
+from test_cell_forward_emulated import CLANG, bf16_bits, bf16_val, make_problem  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang++ (ext_vector_type) as host compiler")
+
+BF16, FLAG_BF16_GV, FLAG_SWAP, CELL = 2, 0x200, 0x400, 6
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("emu_records") / "libmsda_emu.so")
+    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900)
+    L = ctypes.CDLL(so)
+    vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    d = [i] * 7
+    L.msda_records_bytes.argtypes = [i, vp, *d]
+    L.msda_records_bytes.restype = sz
+    L.msda_records_forward.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, vp, *d, vp, vp, sz, vp]
+    L.msda_records_backward.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, i, vp, *d, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+    L.msda_forward_hs.argtypes = [i, i, vp, vp, vp, vp, vp, vp, *d, vp, vp]
+    L.msda_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, *d, vp, vp, vp, vp, sz, vp]
+    L.msda_backward_workspace_bytes.argtypes = [i, vp, *d]
+    L.msda_backward_workspace_bytes.restype = sz
+    L.msda_fused_forward_hs.argtypes = [i, i, vp, vp, vp, vp, vp, vp, i, *d, vp, vp, vp, vp]
+    L.msda_fused_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, i, vp, *d, vp, vp, vp, sz, vp]
+    return L
+
+
+def p(a):
+    return a.ctypes.data if a is not None else None
+
+
+CASES = [
+    ("windows of every level in LDS, 2 x 2 cells, 2 heads", [(20, 27), (10, 14), (5, 7), (3, 4)], 2, (1.5, 1.5, 1.0, 0.7)),
+    ("level 0 too wide for the window budget: the buffer-load route", [(30, 40), (15, 20), (8, 10), (4, 5)], 1, (25.0, 2.0, 1.0, 0.7)),
+    ("ragged pyramid, wide offsets on the coarse levels", [(25, 34), (13, 17), (7, 9), (4, 5)], 1, (2.0, 3.0, 3.0, 3.0)),
+]
+
+
+@pytest.mark.parametrize("name,pyr,M,spread", CASES, ids=[c[0] for c in CASES])
+def test_op_signature_bit_equal_to_the_product_route(lib, name, pyr, M, spread):
+    pyr, starts, S, value, loc, aw = make_problem(pyr, M, spread, seed=7)
+    rng = np.random.default_rng(3)
+    grad_out = bf16_val(bf16_bits(rng.standard_normal((1, S, M * 32)))).astype(np.float32)
+    vb, gob = np.ascontiguousarray(bf16_bits(value)), np.ascontiguousarray(bf16_bits(grad_out))
+    sh, st = np.ascontiguousarray(pyr, dtype=np.int64), np.ascontiguousarray(starts, dtype=np.int64)
+    dims = (1, S, M, 32, 4, S, 4)
+    # the product route: forward (cell kernel, the same sums as the records forward) and backward
+    out_ref = np.zeros((1, S, M * 32), dtype=np.uint16)
+    assert lib.msda_forward_hs(CELL, BF16, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), *dims, p(out_ref), None) == 0
+    ws_bytes = lib.msda_backward_workspace_bytes(BF16, p(sh), *dims)
+    assert ws_bytes > 0
+    gv_ref, gl_ref, ga_ref = np.zeros(vb.shape, dtype=np.uint16), np.full(loc.shape, np.nan, np.float32), np.full(aw.shape, np.nan, np.float32)
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    assert lib.msda_backward_ws(4 | FLAG_BF16_GV, BF16, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), p(gob), *dims, p(gv_ref),
+                                p(gl_ref), p(ga_ref), p(ws), ws_bytes, None) == 0
+    # ... is the oracle's (so "bit-equal to it" means something)
+    a = (value.astype(np.float64), pyr, starts, loc.astype(np.float64), aw.astype(np.float64))
+    o_gv, o_gl, o_ga = O.backward(*a, grad_out.astype(np.float64))
+    assert np.abs(bf16_val(gv_ref) - o_gv).max() <= 2.0 ** -7 * np.abs(o_gv).max()
+    np.testing.assert_allclose(ga_ref, o_ga, rtol=1e-4, atol=1e-5 * float(np.abs(o_ga).max()))
+
+    rec_bytes = lib.msda_records_bytes(BF16, p(sh), *dims)
+    assert rec_bytes > 0
+    records = np.full(rec_bytes + 64, 0xA5, dtype=np.uint8)                     # garbage: whatever is read must have been written
+    out = np.zeros_like(out_ref)
+    assert lib.msda_records_forward(BF16, p(vb), p(sh), p(st), p(sh), None, None, 0, p(loc), p(aw), *dims, p(out), p(records),
+                                    rec_bytes, None) == 0
+    assert np.array_equal(out, out_ref)
+    assert np.all(records[rec_bytes:] == 0xA5)
+    far = int(records[:256].view(np.int32)[60])
+    assert far == 0                                                             # (the patch pass, not the sorting pass, is what runs below)
+    cells = -(-int(pyr[0][0]) // 16) * -(-int(pyr[0][1]) // 16)
+    wtab = records[256:256 + M * cells * 4 * 32].view(np.int32).reshape(M * cells, 4, 8)      # x0, y0, cols, rows, pitch, staged
+    assert np.all(wtab[..., 4] % 4 == 2) and np.all(wtab[..., 4] >= wtab[..., 2])           # pitch = 2 (mod 4), >= cols
+    if "every level in LDS" in name:                                            # which route the levels took
+        assert np.all(wtab[..., 5] == 1), wtab[..., 5]
+    elif "buffer-load" in name:
+        assert np.sum(wtab[..., 5] == 0) >= cells, wtab[..., 5]
+    for flags in (FLAG_BF16_GV, FLAG_BF16_GV | FLAG_SWAP):
+        gv, gl, ga = np.zeros_like(gv_ref), np.full_like(gl_ref, np.nan), np.full_like(ga_ref, np.nan)
+        ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+        assert lib.msda_records_backward(flags, BF16, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), None, 0, p(gob), *dims, p(gv),
+                                         p(gl), p(ga), None, p(records), rec_bytes, p(ws), ws_bytes, None) == 0
+        assert np.array_equal(gl.view(np.uint32), gl_ref.view(np.uint32)), f"grad_sampling_loc differs (flags {flags:#x}, far {far})"
+        assert np.array_equal(ga.view(np.uint32), ga_ref.view(np.uint32)), f"grad_attn_weight differs (flags {flags:#x})"
+        assert np.array_equal(gv, gv_ref), f"grad_value differs (flags {flags:#x}, far {far})"
+
+
+@pytest.mark.parametrize("refdim", [2, 4])
+def test_module_operands_bit_equal_to_the_fused_product_route(lib, refdim):
+    """the train step's form: projection rows + reference points in, saved float32 locations / weights + records out; the
+    backward writes grad_value and the projection rows' gradient"""
+    M, L, P = 2, 4, 4
+    pyr = np.asarray([(20, 27), (10, 14), (5, 7), (3, 4)], dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
+    S = int((pyr[:, 0] * pyr[:, 1]).sum())
+    rng = np.random.default_rng(23 + refdim)
+    refp = []
+    for H, W in pyr:
+        ys, xs = np.meshgrid((np.arange(H) + 0.5) / H, (np.arange(W) + 0.5) / W, indexing="ij")
+        refp.append(np.stack([xs.ravel(), ys.ravel()], -1))
+    refp = np.concatenate(refp, 0)
+    N, Lq = 1, S
+    qproj = rng.standard_normal((N, Lq, M * L * P * 3))
+    qproj[..., :M * L * P * 2] *= 2.0
+    qb = np.ascontiguousarray(bf16_bits(qproj))
+    if refdim == 2:
+        ref = np.ascontiguousarray(np.broadcast_to(refp[None, :, None, :], (N, Lq, L, 2)), dtype=np.float32)
+    else:
+        wh = np.broadcast_to(np.asarray([0.2, 0.15]), (N, Lq, L, 2))
+        ref = np.ascontiguousarray(np.concatenate([np.broadcast_to(refp[None, :, None, :], (N, Lq, L, 2)), wh], -1), dtype=np.float32)
+    vb = np.ascontiguousarray(bf16_bits(rng.standard_normal((N, S, M, 32)) * 0.5))
+    gob = np.ascontiguousarray(bf16_bits(rng.standard_normal((N, Lq, M * 32))))
+    dims = (N, S, M, 32, L, Lq, P)
+    out_ref = np.zeros((N, Lq, M * 32), dtype=np.uint16)
+    loc_ref = np.full((N, Lq, M, L, P, 2), np.nan, dtype=np.float32)
+    aw_ref = np.full((N, Lq, M, L, P), np.nan, dtype=np.float32)
+    assert lib.msda_fused_forward_hs(CELL, BF16, p(vb), p(pyr), p(starts), p(pyr), p(qb), p(ref), refdim, *dims, p(out_ref),
+                                     p(loc_ref), p(aw_ref), None) == 0
+    ws_bytes = lib.msda_backward_workspace_bytes(BF16, p(pyr), *dims)
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    gv_ref, gq_ref = np.zeros(vb.shape, dtype=np.uint16), np.zeros(qb.shape, dtype=np.uint16)
+    assert lib.msda_fused_backward_ws(FLAG_BF16_GV, BF16, p(vb), p(pyr), p(starts), p(pyr), p(loc_ref), p(aw_ref), p(ref), refdim,
+                                      p(gob), *dims, p(gv_ref), p(gq_ref), p(ws), ws_bytes, None) == 0
+
+    rec_bytes = lib.msda_records_bytes(BF16, p(pyr), *dims)
+    assert rec_bytes > 0
+    records = np.full(rec_bytes, 0xA5, dtype=np.uint8)
+    out, loc, aw = np.zeros_like(out_ref), np.full_like(loc_ref, np.nan), np.full_like(aw_ref, np.nan)
+    assert lib.msda_records_forward(BF16, p(vb), p(pyr), p(starts), p(pyr), p(qb), p(ref), refdim, p(loc), p(aw), *dims, p(out),
+                                    p(records), rec_bytes, None) == 0
+    assert np.array_equal(out, out_ref)
+    assert np.array_equal(loc.view(np.uint32), loc_ref.view(np.uint32)) and np.array_equal(aw.view(np.uint32), aw_ref.view(np.uint32))
+    for flags in (FLAG_BF16_GV, FLAG_BF16_GV | FLAG_SWAP):
+        gv, gq = np.zeros_like(gv_ref), np.zeros_like(gq_ref)
+        ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+        assert lib.msda_records_backward(flags, BF16, p(vb), p(pyr), p(starts), p(pyr), p(loc), p(aw), p(ref), refdim, p(gob), *dims,
+                                         p(gv), None, None, p(gq), p(records), rec_bytes, p(ws), ws_bytes, None) == 0
+        assert np.array_equal(gq, gq_ref), f"grad of the projection rows differs (flags {flags:#x})"
+        assert np.array_equal(gv, gv_ref), f"grad_value differs (flags {flags:#x})"
+
+
+def test_far_samples_hand_grad_value_to_the_sorting_pass(lib):
+    """uniform random locations: the forward's binning raises the "far" flag in the records' control block; the backward's
+    patch pass returns at once and the gated sorting pass writes grad_value -- the same bits as the product route, which
+    takes the same detour"""
+    M = 1
+    pyr = np.asarray([(40, 54), (20, 27), (10, 14), (5, 7)], dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
+    S = int((pyr[:, 0] * pyr[:, 1]).sum())
+    rng = np.random.default_rng(31)
+    loc = rng.random((1, S, M, 4, 4, 2)).astype(np.float32)
+    aw = rng.random((1, S, M, 4, 4))
+    aw = (aw / aw.sum((-1, -2), keepdims=True)).astype(np.float32)
+    vb = np.ascontiguousarray(bf16_bits(rng.standard_normal((1, S, M, 32)) * 0.5))
+    gob = np.ascontiguousarray(bf16_bits(rng.standard_normal((1, S, M * 32))))
+    dims = (1, S, M, 32, 4, S, 4)
+    ws_bytes = lib.msda_backward_workspace_bytes(BF16, p(pyr), *dims)
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    gv_ref, gl_ref, ga_ref = np.zeros(vb.shape, dtype=np.uint16), np.full(loc.shape, np.nan, np.float32), np.full(aw.shape, np.nan, np.float32)
+    assert lib.msda_backward_ws(4 | FLAG_BF16_GV, BF16, p(vb), p(pyr), p(starts), p(pyr), p(loc), p(aw), p(gob), *dims, p(gv_ref),
+                                p(gl_ref), p(ga_ref), p(ws), ws_bytes, None) == 0
+    rec_bytes = lib.msda_records_bytes(BF16, p(pyr), *dims)
+    records = np.full(rec_bytes, 0xA5, dtype=np.uint8)
+    out = np.zeros((1, S, M * 32), dtype=np.uint16)
+    assert lib.msda_records_forward(BF16, p(vb), p(pyr), p(starts), p(pyr), None, None, 0, p(loc), p(aw), *dims, p(out), p(records),
+                                    rec_bytes, None) == 0
+    assert int(records[:256].view(np.int32)[60]) != 0                         # the "far" word
+    gv, gl, ga = np.zeros_like(gv_ref), np.full_like(gl_ref, np.nan), np.full_like(ga_ref, np.nan)
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    assert lib.msda_records_backward(FLAG_BF16_GV, BF16, p(vb), p(pyr), p(starts), p(pyr), p(loc), p(aw), None, 0, p(gob), *dims,
+                                     p(gv), p(gl), p(ga), None, p(records), rec_bytes, p(ws), ws_bytes, None) == 0
+    assert np.array_equal(gl.view(np.uint32), gl_ref.view(np.uint32)) and np.array_equal(ga.view(np.uint32), ga_ref.view(np.uint32))
+    # (the sorting pass orders a pixel's records by LDS-atomic arrival inside a wave: lane order on the hardware, thread
+    #  scheduling on the host model -- there the product route itself differs from run to run in a handful of last bits)
+    a, b = bf16_val(gv).astype(np.float64), bf16_val(gv_ref).astype(np.float64)
+    assert np.abs(a - b).max() <= 2.0 ** -7 * np.abs(b).max() and np.mean(gv != gv_ref) < 1e-3
+
+
+def test_unsupported_calls_are_refused(lib):
+    pyr = np.asarray([(20, 27), (10, 14), (5, 7), (3, 4)], dtype=np.int64)
+    S = int((pyr[:, 0] * pyr[:, 1]).sum())
+    assert lib.msda_records_bytes(BF16, p(pyr), 1, S, 2, 32, 4, S, 4) > 0
+    assert lib.msda_records_bytes(0, p(pyr), 1, S, 2, 32, 4, S, 4) == 0          # float32
+    assert lib.msda_records_bytes(BF16, p(pyr), 1, S, 2, 32, 4, 300, 4) == 0     # not an encoder call
+    assert lib.msda_records_bytes(BF16, p(pyr), 1, S, 2, 64, 4, S, 4) == 0       # D != 32
+    assert lib.msda_records_bytes(BF16, None, 1, S, 2, 32, 4, S, 4) == 0         # no host shapes
+    assert lib.msda_records_bytes(BF16, p(pyr), 1, S + 1, 2, 32, 4, S + 1, 4) == 0   # sum(H * W) != S

@@ -20,6 +20,7 @@ ever run the HIP library, and a missing HIP library raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 
@@ -37,8 +38,27 @@ _variant_bwd = _lib.VARIANT_AUTO
 # the train step's encoder forward through cell_forward_kernel (see ms_deform_attn_fused_forward): an experiment that has
 # not run on hardware; a plain attribute that only tools / bench.py --msda-fwd-cell set, never read from the environment
 fused_forward_cell = False
+# The "records" route of the encoder's fused call (csrc/msda_cell_forward.inc EMIT, csrc/msda_cell_records.inc): the forward pass
+# leaves per-sample records, window tables and the patch pass's masks; the backward pass runs no sample geometry and no binning.
+# Bit-identical to the product kernels on the lane-level model (tests/test_records_emulated.py); NEVER run on hardware: a plain
+# attribute that only tools / bench.py's experiments set.  records_swap: the other operand order of the 4x4x4 products.
+records_route = False
+records_swap = False
 # name of the kernel variant the last call of each direction ran (read by bench.py's roofline line)
 last_variant = {}
+
+
+def _on_device(t) -> bool:
+    """(the fused entry points ask here, not t.is_cuda: tests/test_records_emulated.py runs them on the lane-level model of the
+    kernels, where host tensors stand in for device tensors)"""
+    return t.is_cuda
+
+
+@contextlib.contextmanager
+def _launch(t):
+    """device guard of a launch; yields the stream its kernels go to"""
+    with torch.cuda.device(t.device):
+        yield torch.cuda.current_stream().cuda_stream
 
 
 def set_variant(forward: str, backward: str = None) -> None:
@@ -317,7 +337,7 @@ class SampleRowsFunction(Function):
 
 def fused_supported(value, spatial_shapes, reference_points, Lq, L, P, need_backward):
     """Can the fused geometry + sampling kernels (msda_fused_forward / msda_fused_backward_ws) take this call?"""
-    if not value.is_cuda or value.dtype not in (torch.float32, torch.bfloat16) or value.dim() != 4:
+    if not _on_device(value) or value.dtype not in (torch.float32, torch.bfloat16) or value.dim() != 4:
         return False
     hs = host_shapes(spatial_shapes) if need_backward else None
     if need_backward and hs is None:
@@ -338,6 +358,23 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     loc = torch.empty((N, Lq, M, nL, P, 2), dtype=torch.float32, device=value.device) if save else None
     aw = torch.empty((N, Lq, M, nL, P), dtype=torch.float32, device=value.device) if save else None
+    if records_route and save and value.dtype == torch.bfloat16 and host_shapes(spatial_shapes) is not None:
+        hs = host_shapes(spatial_shapes)
+        hs_arr = (ctypes.c_int64 * len(hs))(*hs)
+        rec_bytes = int(L.msda_records_bytes(_DTYPES[value.dtype], hs_arr, N, S, M, D, nL, Lq, P))
+        if rec_bytes:                                      # (0: not a call the route takes -- the decoders, other shapes)
+            records = torch.empty(rec_bytes, dtype=torch.uint8, device=value.device)
+            with _launch(value) as stream:
+                st = L.msda_records_forward(_DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
+                                            level_start_index.data_ptr(), hs_arr, qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
+                                            loc.data_ptr(), aw.data_ptr(), N, S, M, D, nL, Lq, P, out.data_ptr(),
+                                            records.data_ptr(), rec_bytes, stream)
+            if st:
+                _raise(st)
+            roofline.add(roofline.tensor_bytes(value, qproj, ref, out, loc, aw, records))
+            last_variant["fwd"] = "cell+geometry+records"
+            loc.records = records                          # (picked up by FusedMSDeformAttnFunction.forward, saved with loc / aw)
+            return out, loc, aw
     if (fused_forward_cell and save and value.dtype == torch.bfloat16 and Lq == S and nL == 4 and P == 4 and D == 32
             and host_shapes(spatial_shapes) is not None):
         # EXPERIMENT (msda.fused_forward_cell = True; the kernel has not been validated on hardware yet): geometry, the saved float32
@@ -345,21 +382,20 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj
         # (csrc/msda_cell_forward.inc: cell_forward_kernel<refdim>)
         hs = host_shapes(spatial_shapes)
         hs_arr = (ctypes.c_int64 * len(hs))(*hs)
-        with torch.cuda.device(value.device):
+        with _launch(value) as stream:
             st = L.msda_fused_forward_hs(_lib.VARIANT_CELL, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
                                          level_start_index.data_ptr(), hs_arr, qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
-                                         N, S, M, D, nL, Lq, P, out.data_ptr(), loc.data_ptr(), aw.data_ptr(),
-                                         torch.cuda.current_stream().cuda_stream)
+                                         N, S, M, D, nL, Lq, P, out.data_ptr(), loc.data_ptr(), aw.data_ptr(), stream)
         if st:
             _raise(st)
         roofline.add(roofline.tensor_bytes(value, qproj, ref, out, loc, aw))
         last_variant["fwd"] = "cell+geometry"
         return out, loc, aw
-    with torch.cuda.device(value.device):
+    with _launch(value) as stream:
         st = L.msda_fused_forward(_DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
                                   level_start_index.data_ptr(), qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
                                   N, S, M, D, nL, Lq, P, out.data_ptr(), loc.data_ptr() if save else None,
-                                  aw.data_ptr() if save else None, torch.cuda.current_stream().cuda_stream)
+                                  aw.data_ptr() if save else None, stream)
     if st:
         _raise(st)
     roofline.add(roofline.tensor_bytes(value, qproj, ref, out, loc, aw))
@@ -367,8 +403,9 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj
     return out, loc, aw
 
 
-def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, loc, aw, ref, grad_output, host):
-    """-> [grad_value (value's dtype), grad_qproj (value's dtype)]; needs the host copy of the level shapes."""
+def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, loc, aw, ref, grad_output, host, records=None):
+    """-> [grad_value (value's dtype), grad_qproj (value's dtype)]; needs the host copy of the level shapes.
+    records: what ms_deform_attn_fused_forward left on `loc.records` under msda.records_route (the backward then consumes it)."""
     L = _lib.lib()
     N, S, M, D = value.shape
     nL, Lq, P = spatial_shapes.shape[0], loc.shape[1], loc.shape[4]
@@ -381,12 +418,23 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, loc,
     g_qproj = torch.empty((N, Lq, M * nL * P * 3), dtype=value.dtype, device=value.device)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
     flags = _lib.FLAG_GRAD_VALUE_BF16 if value.dtype == torch.bfloat16 else 0
-    with torch.cuda.device(value.device):
+    if records is not None:
+        with _launch(value) as stream:
+            st = L.msda_records_backward(flags | (_lib.FLAG_RECORDS_SWAP if records_swap else 0), _DTYPES[value.dtype],
+                                         value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), hs_arr,
+                                         loc.data_ptr(), aw.data_ptr(), ref.data_ptr(), ref.shape[-1], go.data_ptr(),
+                                         N, S, M, D, nL, Lq, P, g_value.data_ptr(), None, None, g_qproj.data_ptr(),
+                                         records.data_ptr(), records.numel(), ws.data_ptr(), ws_bytes, stream)
+        if st:
+            _raise(st)
+        roofline.add(roofline.tensor_bytes(value, records, aw, ref, go, g_value, g_qproj))
+        last_variant["bwd"] = "records+geometry"
+        return [g_value, g_qproj]
+    with _launch(value) as stream:
         st = L.msda_fused_backward_ws(flags, _DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
                                       level_start_index.data_ptr(), hs_arr, loc.data_ptr(), aw.data_ptr(),
                                       ref.data_ptr(), ref.shape[-1], go.data_ptr(), N, S, M, D, nL, Lq, P,
-                                      g_value.data_ptr(), g_qproj.data_ptr(), ws.data_ptr(), ws_bytes,
-                                      torch.cuda.current_stream().cuda_stream)
+                                      g_value.data_ptr(), g_qproj.data_ptr(), ws.data_ptr(), ws_bytes, stream)
     if st:
         _raise(st)
     roofline.add(roofline.tensor_bytes(value, loc, aw, ref, go, g_value, g_qproj))
@@ -403,7 +451,7 @@ class FusedMSDeformAttnFunction(Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, qproj, reference_points, im2col_step):
-        if not value.is_cuda:
+        if not _on_device(value):
             raise RuntimeError("Not implemented on the CPU")                 # ms_deform_attn.h:54
         for name, t in (("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index)):
             if not t.is_contiguous():
@@ -416,16 +464,18 @@ class FusedMSDeformAttnFunction(Function):
         save = ctx.needs_input_grad[0] or ctx.needs_input_grad[3]
         out, loc, aw = ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj, ref, save)
         if save:
-            ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, aw, ref)
+            records = getattr(loc, "records", None)        # (msda.records_route)
+            ctx.has_records = records is not None
+            ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, aw, ref, *([records] if ctx.has_records else []))
             ctx.host_shapes = host_shapes(spatial_shapes)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, shapes, starts, loc, aw, ref = ctx.saved_tensors
+        value, shapes, starts, loc, aw, ref = ctx.saved_tensors[:6]
         g_value, g_qproj = ms_deform_attn_fused_backward(value, shapes, starts, loc, aw, ref, grad_output.contiguous(),
-                                                         ctx.host_shapes)
+                                                         ctx.host_shapes, ctx.saved_tensors[6] if ctx.has_records else None)
         return g_value, None, None, g_qproj, None, None
 
 

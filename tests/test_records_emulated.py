@@ -206,3 +206,57 @@ def test_unsupported_calls_are_refused(lib):
     assert lib.msda_records_bytes(BF16, p(pyr), 1, S, 2, 64, 4, S, 4) == 0       # D != 32
     assert lib.msda_records_bytes(BF16, None, 1, S, 2, 32, 4, S, 4) == 0         # no host shapes
     assert lib.msda_records_bytes(BF16, p(pyr), 1, S + 1, 2, 32, 4, S + 1, 4) == 0   # sum(H * W) != S
+
+
+def test_autograd_function_with_the_route_on_and_off(lib, monkeypatch):
+    """FusedMSDeformAttnFunction -- the product's Python: the records tensor travels from the forward call to the backward call
+    as a saved tensor -- with msda.records_route on / off (+ records_swap), on the host-model library: the output and both
+    gradients bit for bit.  (tests/test_zz_round5_gpu.py repeats this on the device.)"""
+    import contextlib
+
+    import torch
+
+    from rlipv2_amd import _lib, msda
+
+    i, vp, sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    lib.msda_check_im2col_step.argtypes = [i, i]
+    lib.msda_fused_supported.argtypes = [i, vp, i, *([i] * 7)]
+    lib.msda_fused_forward.argtypes = [i, vp, vp, vp, vp, vp, i, *([i] * 7), vp, vp, vp, vp]
+    monkeypatch.setattr(_lib, "lib", lambda: lib)
+    monkeypatch.setattr(msda, "_on_device", lambda t: True)
+    monkeypatch.setattr(msda, "_launch", lambda t: contextlib.nullcontext(None))
+
+    M, L, P = 2, 4, 4
+    pyr = [(20, 27), (10, 14), (5, 7), (3, 4)]
+    shapes = torch.tensor(pyr, dtype=torch.int64)
+    msda.attach_host_shapes(shapes, pyr)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    g = torch.Generator().manual_seed(5)
+    refp = torch.cat([torch.stack(torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")[::-1], -1).reshape(-1, 2)
+                      for H, W in pyr])
+    ref = refp[None, :, None, :].expand(1, S, L, 2).contiguous()
+    value0 = (0.5 * torch.randn(1, S, M, 32, generator=g)).to(torch.bfloat16)
+    qproj0 = torch.randn(1, S, M * L * P * 3, generator=g)
+    qproj0[..., :M * L * P * 2] *= 2.0
+    qproj0 = qproj0.to(torch.bfloat16)
+    gout = torch.randn(1, S, M * 32, generator=g).to(torch.bfloat16)
+
+    def run(route, swap):
+        monkeypatch.setattr(msda, "records_route", route)
+        monkeypatch.setattr(msda, "records_swap", swap)
+        value, qproj = value0.clone().requires_grad_(True), qproj0.clone().requires_grad_(True)
+        out = msda.FusedMSDeformAttnFunction.apply(value, shapes, starts, qproj, ref, 64)
+        variant_fwd = msda.last_variant["fwd"]
+        out.backward(gout)
+        return out.detach(), value.grad, qproj.grad, variant_fwd, msda.last_variant["bwd"]
+    base = run(False, False)
+    assert base[3] == "quad+geometry" and base[4] == "dest+geometry"
+    for swap in (False, True):
+        got = run(True, swap)
+        assert got[3] == "cell+geometry+records" and got[4] == "records+geometry"
+        # (the two forward kernels sum a query's 16 samples differently: the output agrees to bfloat16 rounding, the gradients
+        #  -- same records, same formulas -- bit for bit)
+        assert float((got[0].float() - base[0].float()).abs().max()) <= 2.0 ** -6 * float(base[0].float().abs().max())
+        assert torch.equal(got[1].view(torch.int16), base[1].view(torch.int16))
+        assert torch.equal(got[2].view(torch.int16), base[2].view(torch.int16))

@@ -684,7 +684,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-experiments", dest="experiments", action="store_false",
                     help="skip the A/B table of the unmeasured kernel arms that a default 1-GPU run appends after its timed region "
-                         "(tools/experiments_r05.py, at most 100 s, child processes)")
+                         "(tools/experiments_r05.py, at most 130 s, child processes)")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE", dest="overrides",
                     help="A/B runs: set a bool / int attribute of a rlipv2_amd module for this run, e.g. --set decoder.fused_glue=0 "
                          "(the switches INTEGRATION.md lists; recorded in config.overrides)")

@@ -20,12 +20,12 @@ def pytest_configure(config):
 # hot path first, then the other kernels, the modules, the newest tests, and the whole-bench contract last
 # (one failure in a late, broad test must not hide the op-level parity results).
 GPU_SUITE_ORDER = ["test_msda_gpu", "test_msda_cell_forward_gpu", "test_norm_gpu", "test_linear_gpu", "test_optim_gpu",
-                   "test_modules_gpu", "test_zz_round4_gpu", "test_zz_round5_gpu", "test_bench_contract"]
+                   "test_modules_gpu", "test_zz_round4_gpu", "test_zz_round5_gpu", "test_bench_contract", "test_zzz_records_gpu"]
 
 
 def gpu_suite_rank(nodeid):
     name = os.path.basename(nodeid.split("::")[0])[:-3]
-    return GPU_SUITE_ORDER.index(name) if name in GPU_SUITE_ORDER else len(GPU_SUITE_ORDER) - 1.5
+    return GPU_SUITE_ORDER.index(name) if name in GPU_SUITE_ORDER else GPU_SUITE_ORDER.index("test_bench_contract") - 0.5
 
 
 def pytest_collection_modifyitems(config, items):

@@ -33,6 +33,7 @@ def test_device_code_equals_the_manifest():
     # (cell_forward_kernel: opt-in experiment; step_scaled_kernel: the optimiser's data-parallel form, grad_scale != 1 -- the
     #  one-GPU step runs round 2's step_kernel; layernorm_wide.hip / window_attention.hip / msda_rows.hip (round 5): behind norm.fused_wide_layer_norm /
     #  swin.fused_window_attention / deform_attn.sample_then_project, OFF until
-    #  routes.validate has compared the Swin step with it against the plain ops on a GPU -- the R50 configurations never reach it)
-    assert all("cell_forward_kernel" in k or "step_scaled_kernel" in k or k.startswith(("layernorm_wide.hip::", "window_attention.hip::", "msda_rows.hip::"))
+    #  routes.validate has compared the Swin step with it against the plain ops on a GPU -- the R50 configurations never reach it;
+    #  cell_records_backward_kernel (round 5): behind msda.records_route, OFF)
+    assert all("cell_forward_kernel" in k or "cell_records_backward_kernel" in k or "step_scaled_kernel" in k or k.startswith(("layernorm_wide.hip::", "window_attention.hip::", "msda_rows.hip::"))
                for k in never), never

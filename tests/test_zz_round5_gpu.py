@@ -276,3 +276,4 @@ def test_sample_then_project_module_on_the_gpu(dtype):
     tol = 3e-2 if dtype == torch.bfloat16 else 1e-4
     for a, b in zip(res[True], res[False]):
         assert float((a - b).norm()) <= tol * float(b.norm()) + 1e-6, (float((a - b).norm()), float(b.norm()))
+

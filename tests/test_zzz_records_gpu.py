@@ -1,0 +1,126 @@
+"""GPU tests of the "records" route of the encoder backward (csrc/msda_cell_forward.inc EMIT, csrc/msda_cell_records.inc): device
+code written in round 5 without a GPU, validated on the lane-level model only (tests/test_records_emulated.py).  An experiment
+behind msda.records_route, OFF in the product -- sorted LAST in the GPU suite (tests/conftest.py: GPU_SUITE_ORDER), after the
+bench contract test, so that a failure here cannot hide any evidence about the product path."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _encoder_call(pyr, N, M, seed, refdim):
+    """a bfloat16 encoder call in the module's operands: value, projection rows, reference points, grad_out"""
+    from rlipv2_amd import msda
+    g = torch.Generator().manual_seed(seed)
+    shapes = torch.tensor(pyr, dtype=torch.int64, device=DEV)
+    msda.attach_host_shapes(shapes, pyr)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    S = sum(h * w for h, w in pyr)
+    refp = torch.cat([torch.stack(torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")[::-1], -1).reshape(-1, 2)
+                      for H, W in pyr])
+    ref = refp[None, :, None, :].expand(N, S, 4, 2)
+    if refdim == 4:
+        ref = torch.cat([ref, torch.tensor([0.2, 0.15]).expand(N, S, 4, 2)], -1)
+    value = (0.5 * torch.randn(N, S, M, 32, generator=g)).to(torch.bfloat16)
+    qproj = torch.randn(N, S, M * 48, generator=g)
+    qproj[..., :M * 32] *= 2.0                                       # offsets of a few pixels
+    gout = torch.randn(N, S, M * 32, generator=g).to(torch.bfloat16)
+    return (value.to(DEV), shapes, starts, qproj.to(torch.bfloat16).to(DEV), ref.contiguous().float().to(DEV), gout.to(DEV))
+
+
+@pytest.mark.parametrize("refdim", [2, 4])
+@pytest.mark.parametrize("pyr,N,M", [([(20, 27), (10, 14), (5, 7), (3, 4)], 1, 2), ([(100, 134), (50, 67), (25, 34), (13, 17)], 2, 8)])
+def test_records_route_matches_the_product_kernels_bit_for_bit(pyr, N, M, refdim):
+    """msda.records_route (cell_forward_kernel with EMIT + cell_records_backward_kernel, never run on hardware before this test)
+    against the product route of the train step through the same autograd function: gradients of value and of the projection
+    rows bit for bit, both operand orders; the output to bfloat16 rounding (the two forward kernels sum in different orders).
+    The bar on the host model was the same (tests/test_records_emulated.py)."""
+    from rlipv2_amd import msda
+    value0, shapes, starts, qproj0, ref, gout = _encoder_call(pyr, N, M, seed=11, refdim=refdim)
+
+    def run(route, swap):
+        msda.records_route, msda.records_swap = route, swap
+        try:
+            value, qproj = value0.clone().requires_grad_(True), qproj0.clone().requires_grad_(True)
+            out = msda.FusedMSDeformAttnFunction.apply(value, shapes, starts, qproj, ref, 64)
+            fwd = msda.last_variant["fwd"]
+            out.backward(gout)
+            torch.cuda.synchronize()
+            return out.detach(), value.grad, qproj.grad, fwd, msda.last_variant["bwd"]
+        finally:
+            msda.records_route = msda.records_swap = False
+    base = run(False, False)
+    assert base[4] == "dest+geometry"
+    for swap in (False, True):
+        got = run(True, swap)
+        assert got[3] == "cell+geometry+records" and got[4] == "records+geometry"
+        assert float((got[0].float() - base[0].float()).abs().max()) <= 2.0 ** -6 * float(base[0].float().abs().max())
+        assert torch.equal(got[1].view(torch.int16), base[1].view(torch.int16)), "grad_value differs"
+        assert torch.equal(got[2].view(torch.int16), base[2].view(torch.int16)), "grad of the projection rows differs"
+    # and twice the same bits (no atomics, fixed summation order)
+    again = run(True, False)
+    assert torch.equal(again[1].view(torch.int16), base[1].view(torch.int16)) and torch.equal(again[0].view(torch.int16), got[0].view(torch.int16))
+
+
+def test_records_route_op_signature_against_the_oracle():
+    """the C ABI of the route with the op's own operands (refdim 0: sampling_loc / attn_weight in, their gradients out) against
+    the oracle, and bit-equal to msda_backward_ws; includes out-of-range, corner and NaN locations"""
+    import ctypes
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import msda_oracle as O
+    from test_cell_forward_emulated import make_problem
+    from rlipv2_amd import _lib
+    L = _lib.lib()
+    pyr, starts, S, value, loc, aw = make_problem([(25, 34), (13, 17), (7, 9), (4, 5)], 2, (2.0, 3.0, 3.0, 3.0), seed=7)
+    M = 2
+    gout = torch.randn(1, S, M * 32, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16)
+    t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a)).to(dt or torch.float32).to(DEV).contiguous()   # noqa: E731
+    v, lo, a_, go = t(value, torch.bfloat16), t(loc), t(aw), gout.to(DEV)
+    sh, st = t(pyr, torch.int64), t(starts, torch.int64)
+    hs = (ctypes.c_int64 * 8)(*[int(x) for x in np.asarray(pyr).reshape(-1)])
+    dims = (1, S, M, 32, 4, S, 4)
+    BF16, FLAG = _lib.MSDA_BF16, _lib.FLAG_GRAD_VALUE_BF16
+    rec_bytes = int(L.msda_records_bytes(BF16, hs, *dims))
+    ws_bytes = int(L.msda_backward_workspace_bytes(BF16, hs, *dims))
+    assert rec_bytes > 0 and ws_bytes > 0
+    records = torch.full((rec_bytes,), 0xA5, dtype=torch.uint8, device=DEV)
+    out = torch.zeros(1, S, M * 32, dtype=torch.bfloat16, device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.msda_records_forward(BF16, v.data_ptr(), sh.data_ptr(), st.data_ptr(), hs, None, None, 0, lo.data_ptr(), a_.data_ptr(),
+                                  *dims, out.data_ptr(), records.data_ptr(), rec_bytes, stream) == 0
+    res = {}
+    for name in ("product", "records", "records_swap"):
+        gv = torch.zeros_like(v)
+        gl, ga = torch.full_like(lo, float("nan")), torch.full_like(a_, float("nan"))
+        ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=DEV)
+        if name == "product":
+            rc = L.msda_backward_ws(_lib.VARIANT_DEST | FLAG, BF16, v.data_ptr(), sh.data_ptr(), st.data_ptr(), hs, lo.data_ptr(),
+                                    a_.data_ptr(), go.data_ptr(), *dims, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), ws.data_ptr(),
+                                    ws_bytes, stream)
+        else:
+            rc = L.msda_records_backward(FLAG | (_lib.FLAG_RECORDS_SWAP if name == "records_swap" else 0), BF16, v.data_ptr(),
+                                         sh.data_ptr(), st.data_ptr(), hs, lo.data_ptr(), a_.data_ptr(), None, 0, go.data_ptr(), *dims,
+                                         gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), None, records.data_ptr(), rec_bytes,
+                                         ws.data_ptr(), ws_bytes, stream)
+        assert rc == 0, (name, rc)
+        torch.cuda.synchronize()
+        res[name] = (gv.cpu(), gl.cpu(), ga.cpu())
+    for name in ("records", "records_swap"):
+        for x, y in zip(res[name], res["product"]):
+            assert torch.equal(x.view(torch.int16 if x.dtype == torch.bfloat16 else torch.int32),
+                               y.view(torch.int16 if y.dtype == torch.bfloat16 else torch.int32)), name
+    a64 = (value.astype(np.float64), pyr, starts, loc.astype(np.float64), aw.astype(np.float64))
+    o_out = O.forward(*a64)
+    o_gv, o_gl, o_ga = O.backward(*a64, gout.float().numpy().astype(np.float64))
+    assert np.abs(out.float().cpu().numpy() - o_out).max() <= 2.0 ** -7 * np.abs(o_out).max()
+    assert np.abs(res["records"][0].float().numpy() - o_gv).max() <= 2.0 ** -7 * np.abs(o_gv).max()
+    np.testing.assert_allclose(res["records"][2].numpy(), o_ga, rtol=1e-4, atol=1e-5 * float(np.abs(o_ga).max()))

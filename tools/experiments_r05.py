@@ -9,6 +9,9 @@ Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_
   cell 2-4   cell_backward_kernel<., MODE>: geometry once per quad + operand swap | + loads up front, scalar level starts |
              mode 3 without the swap (the last two arms only with --all)                                  (reference work: ms_deform_im2col_cuda.cuh:87-159, 301-403)
   patch multi   patch_dest_multi_kernel (mask-word prefetch not in a branch)
+  records    the "records" route (csrc/msda_cell_forward.inc EMIT + csrc/msda_cell_records.inc): the forward leaves per-sample
+             records / window tables / patch masks, the backward runs no geometry and no binning -- fused call, forward and
+             backward times against the product kernels, gradients bit for bit                                  (same lines)
   fwd cell   cell_forward_kernel (explicit variant "cell" of the product library) against the product forward (.cuh:237-299)
   swin       the two Swin routes of round 5 (csrc/window_attention.hip, csrc/layernorm_wide.hip; models/swin/swin_transformer.py:
              262-301, 386-401) at the Swin-L stage-0 shapes against the PyTorch op sequences they replace
@@ -63,6 +66,50 @@ def child_backward(arm):
     res = [t for t in f() if torch.is_tensor(t)]
     out["fused"] = {"digest": [digest(t) for t in res], "finite": all(bool(torch.isfinite(t.float()).all()) for t in res),
                     "us": round(timed(f, iters=20), 1)}
+    print("RESULT " + json.dumps(out), flush=True)
+
+
+def child_records():
+    """the fused encoder call of the train step (N = 4, 800x1333, bf16, model-like projection rows): product route (quad gather
+    forward, cell_backward_kernel + patch_dest_kernel) against msda.records_route, with both operand orders of the 4x4x4 products"""
+    import torch
+    from rlipv2_amd import msda
+    from tools.msda_inputs import PYRAMID_800x1333, make_inputs
+    from tools.patch_check import timed
+    from tools.r03_experiments import fused_problem
+    inp = make_inputs(4, mode="model", dtype=torch.bfloat16, seed=3)
+    msda.attach_host_shapes(inp["shapes"], PYRAMID_800x1333)
+    qproj, ref = fused_problem(4, inp)
+    hs = msda.host_shapes(inp["shapes"])
+    fwd = lambda: msda.ms_deform_attn_fused_forward(inp["value"], inp["shapes"], inp["starts"], qproj, ref, True)   # noqa: E731
+    out, res = {}, {}
+    for name, route, swap, cell in (("product", False, False, False), ("cell_forward", False, False, True),
+                                    ("records", True, False, False), ("records_swap", True, True, False)):
+        msda.records_route, msda.records_swap, msda.fused_forward_cell = route, swap, cell
+        try:
+            o, loc, aw = fwd()
+            records = getattr(loc, "records", None)
+            bwd = lambda: msda.ms_deform_attn_fused_backward(inp["value"], inp["shapes"], inp["starts"], loc, aw, ref,   # noqa: E731
+                                                             inp["grad_out"], hs, records)
+            g = bwd()
+            torch.cuda.synchronize()
+            res[name] = o.float()
+            out[name] = {"fwd_variant": msda.last_variant["fwd"], "bwd_variant": msda.last_variant["bwd"],
+                         "digest": [digest(t) for t in g], "finite": all(bool(torch.isfinite(t.float()).all()) for t in g),
+                         "fwd_us": round(timed(fwd, iters=20), 1)}
+            if name != "cell_forward":
+                out[name]["bwd_us"] = round(timed(bwd, iters=20), 1)
+            if records is not None:
+                out[name]["records_MB"] = round(records.numel() / 1e6, 1)
+                out[name]["far_flag"] = int(records[:256].view(torch.int32)[60])
+            del o, loc, aw, records, g
+        finally:
+            msda.records_route = msda.records_swap = msda.fused_forward_cell = False
+    base = out["product"].pop("digest")
+    scale = float(res["product"].abs().max())
+    for name in ("cell_forward", "records", "records_swap"):
+        out[name]["equal_bits"] = out[name].pop("digest") == base
+        out[name]["out_max_diff_rel_to_max"] = float((res[name] - res["product"]).abs().max()) / scale
     print("RESULT " + json.dumps(out), flush=True)
 
 
@@ -218,7 +265,7 @@ def run_child(args, env, timeout):
     return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
 
 
-def main(per_child_timeout=45, budget_s=100):
+def main(per_child_timeout=45, budget_s=130):
     """parent: one child per arm / kernel, most informative first; nothing is started after `budget_s` seconds and no child may
     run past the deadline (bench.py's default run must stay within minutes); `--all`: no budget, every arm"""
     everything = "--all" in sys.argv
@@ -251,6 +298,7 @@ def main(per_child_timeout=45, budget_s=100):
         arms[name] = out
     # order = value of the evidence: the default pair and the most complete cell arm, the other kernels, then the remaining arms
     arm(0)
+    report["encoder_records_route"] = child(["--records"])
     arm(1)
     report["encoder_backward_arms"] = arms if have_arms else {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
     report["encoder_forward_cell"] = child(["--fwd"])
@@ -265,6 +313,8 @@ def main(per_child_timeout=45, budget_s=100):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--arm":
         child_backward(int(sys.argv[2]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--records":
+        child_records()
     elif len(sys.argv) > 1 and sys.argv[1] == "--fwd":
         child_forward()
     elif len(sys.argv) > 1 and sys.argv[1] == "--swin":

@@ -6,6 +6,7 @@
 #   3. A/B of round 4's host-side restructures (tools/r04_host_ab.py)                           -> host_ab.txt
 #   4. A/B of the kernel arms of round 3 (ablation build; bit-equality demanded)                -> experiments.txt
 #   5. cell_forward_kernel: opt-in tests + timing + a bench line with it                        -> pytest_cell_forward.txt, bench_line_fwd_cell.json
+#      and a bench line with the records route (msda.records_route)                             -> bench_line_records.json
 #   6. kernel stats + HBM-traffic counter passes of the kernels that run (tools/gpu_final_r03.sh, separate --pmc passes)
 #   7. Swin-L (config 4) bench line with its self-checked routes, and with them forced off     -> bench_line_swin*.json
 #   gpurun --timeout 3300 -- 'bash tools/gpu_reopen_r05.sh'
@@ -25,6 +26,10 @@ cat $OUT/experiments.txt
 tail -25 $OUT/pytest_cell_forward.txt
 timeout 600 python bench.py --no-cpu-baseline --no-experiments --msda-fwd-cell > $OUT/bench_line_fwd_cell.json 2> $OUT/bench_fwd_cell_stderr.txt
 tail -c 600 $OUT/bench_line_fwd_cell.json
+# the records route of the encoder forward / backward pair in the whole step (only worth reading if experiments.json above shows
+# its gradients bit-equal): product line above against this one
+timeout 600 python bench.py --no-cpu-baseline --no-experiments --set msda.records_route=1 > $OUT/bench_line_records.json 2> $OUT/bench_records_stderr.txt
+tail -c 600 $OUT/bench_line_records.json
 # brief item 6 decided by one measurement: today's chunk plan against one chunk + direct stores (small-token Linears)
 ( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; for m in 8 100000; do RLIPV2_WGRAD_MINSTEPS=$m timeout 300 python tools/wgrad_plan_ab.py; done > $OUT/wgrad_plan_ab.txt 2>&1 ); cat $OUT/wgrad_plan_ab.txt
 timeout 700 python bench.py --no-cpu-baseline --backbone swin_large --batch 2 > $OUT/bench_line_swin.json 2> $OUT/bench_swin_stderr.txt; tail -c 700 $OUT/bench_line_swin.json

@@ -170,6 +170,8 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
             return {"window_attention_module_fwd_bwd": {"ops_us": 900.0, "fused_us": 300.0}}
         if args[0] == "--stp":
             return {"standard_us": 400.0, "sample_then_project_us": 380.0}
+        if args[0] == "--records":
+            return {"product": {"fwd_us": 190.0, "bwd_us": 540.0}, "records": {"fwd_us": 220.0, "bwd_us": 350.0, "equal_bits": True}}
         k = int(args[1])
         if k == 3:
             return {"error": "timed out after 75 s (child killed)"}
@@ -183,6 +185,7 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
     assert arms[names[0]]["b0"]["equal_bits"] and arms[names[1]]["fused"]["equal_bits"]
     assert not arms[names[2]]["b0"]["equal_bits"] and "error" in arms[names[3]]
     assert rep["encoder_forward_cell"]["model"]["cell_us"] == 110.0 and "swin_routes" in rep
+    assert rep["encoder_records_route"]["records"]["equal_bits"]
     assert "digest" not in json.dumps(rep)
     # a real child that produces nothing (here: no GPU) is an error entry, not an exception
     monkeypatch.undo()

@@ -23,6 +23,7 @@ from test_cell_forward_emulated import CLANG, bf16_bits, bf16_val, make_problem 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang++ (ext_vector_type) as host compiler")
 
 BF16, FLAG_BF16_GV, FLAG_SWAP, CELL = 2, 0x200, 0x400, 6
+FULL = os.environ.get("RLIPV2_TEST_EMU_FULL", "0") == "1"     # the default suite runs one problem per code path (~2.5 min)
 
 
 @pytest.fixture(scope="module")
@@ -52,8 +53,7 @@ def p(a):
 CASES = [
     ("windows of every level in LDS, 2 x 2 cells, 2 heads", [(20, 27), (10, 14), (5, 7), (3, 4)], 2, (1.5, 1.5, 1.0, 0.7)),
     ("level 0 too wide for the window budget: the buffer-load route", [(30, 40), (15, 20), (8, 10), (4, 5)], 1, (25.0, 2.0, 1.0, 0.7)),
-    ("ragged pyramid, wide offsets on the coarse levels", [(25, 34), (13, 17), (7, 9), (4, 5)], 1, (2.0, 3.0, 3.0, 3.0)),
-]
+] + ([("ragged pyramid, wide offsets on the coarse levels", [(25, 34), (13, 17), (7, 9), (4, 5)], 1, (2.0, 3.0, 3.0, 3.0))] if FULL else [])
 
 
 @pytest.mark.parametrize("name,pyr,M,spread", CASES, ids=[c[0] for c in CASES])
@@ -106,7 +106,7 @@ def test_op_signature_bit_equal_to_the_product_route(lib, name, pyr, M, spread):
         assert np.array_equal(gv, gv_ref), f"grad_value differs (flags {flags:#x}, far {far})"
 
 
-@pytest.mark.parametrize("refdim", [2, 4])
+@pytest.mark.parametrize("refdim", [2, 4] if FULL else [2])
 def test_module_operands_bit_equal_to_the_fused_product_route(lib, refdim):
     """the train step's form: projection rows + reference points in, saved float32 locations / weights + records out; the
     backward writes grad_value and the projection rows' gradient"""
@@ -165,7 +165,7 @@ def test_far_samples_hand_grad_value_to_the_sorting_pass(lib):
     patch pass returns at once and the gated sorting pass writes grad_value -- the same bits as the product route, which
     takes the same detour"""
     M = 1
-    pyr = np.asarray([(40, 54), (20, 27), (10, 14), (5, 7)], dtype=np.int64)
+    pyr = np.asarray([(16, 64), (8, 32), (4, 16), (2, 8)], dtype=np.int64)      # 1 x 4 cells: a level-0 patch sees 3 of them
     starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
     S = int((pyr[:, 0] * pyr[:, 1]).sum())
     rng = np.random.default_rng(31)
@@ -260,3 +260,39 @@ def test_autograd_function_with_the_route_on_and_off(lib, monkeypatch):
         assert float((got[0].float() - base[0].float()).abs().max()) <= 2.0 ** -6 * float(base[0].float().abs().max())
         assert torch.equal(got[1].view(torch.int16), base[1].view(torch.int16))
         assert torch.equal(got[2].view(torch.int16), base[2].view(torch.int16))
+
+
+@pytest.mark.parametrize("N,M", [(2, 4), (3, 1)] if FULL else [(2, 4)])
+def test_batches_and_the_xcd_placement(lib, N, M):
+    """N * M = 8 takes the XCD-aware workgroup -> (image, head, cell) mapping (hardware block b runs on XCD b % 8), N * M = 3 the
+    plain one; images beyond the first exercise the per-image offsets of the value rows, the records and the window tables"""
+    pyr = [(16, 28), (8, 14), (4, 7), (2, 4)]            # 1 x 2 cells; 596 queries (<= 512: the product route is the few-query pass)
+    parts = [make_problem(pyr, M, (1.5, 1.5, 1.0, 0.7), seed=40 + n) for n in range(N)]
+    pyr, starts, S = parts[0][0], parts[0][1], parts[0][2]
+    value = np.concatenate([q[3] for q in parts], 0)
+    loc = np.ascontiguousarray(np.concatenate([q[4] for q in parts], 0))
+    aw = np.ascontiguousarray(np.concatenate([q[5] for q in parts], 0))
+    rng = np.random.default_rng(9)
+    vb = np.ascontiguousarray(bf16_bits(value))
+    gob = np.ascontiguousarray(bf16_bits(rng.standard_normal((N, S, M * 32))))
+    sh, st = np.ascontiguousarray(pyr, dtype=np.int64), np.ascontiguousarray(starts, dtype=np.int64)
+    dims = (N, S, M, 32, 4, S, 4)
+    ws_bytes = lib.msda_backward_workspace_bytes(BF16, p(sh), *dims)
+    gv_ref, gl_ref, ga_ref = np.zeros(vb.shape, dtype=np.uint16), np.full(loc.shape, np.nan, np.float32), np.full(aw.shape, np.nan, np.float32)
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    assert lib.msda_backward_ws(4 | FLAG_BF16_GV, BF16, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), p(gob), *dims, p(gv_ref),
+                                p(gl_ref), p(ga_ref), p(ws), ws_bytes, None) == 0
+    rec_bytes = lib.msda_records_bytes(BF16, p(sh), *dims)
+    records = np.full(rec_bytes, 0xA5, dtype=np.uint8)
+    out = np.zeros((N, S, M * 32), dtype=np.uint16)
+    assert lib.msda_records_forward(BF16, p(vb), p(sh), p(st), p(sh), None, None, 0, p(loc), p(aw), *dims, p(out), p(records),
+                                    rec_bytes, None) == 0
+    a64 = (value.astype(np.float64), pyr, starts, loc.astype(np.float64), aw.astype(np.float64))
+    o_out = O.forward(*a64)
+    assert np.abs(bf16_val(out) - o_out).max() <= 2.0 ** -7 * np.abs(o_out).max()
+    gv, gl, ga = np.zeros_like(gv_ref), np.full_like(gl_ref, np.nan), np.full_like(ga_ref, np.nan)
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    assert lib.msda_records_backward(FLAG_BF16_GV | FLAG_SWAP, BF16, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), None, 0, p(gob), *dims,
+                                     p(gv), p(gl), p(ga), None, p(records), rec_bytes, p(ws), ws_bytes, None) == 0
+    assert np.array_equal(gl.view(np.uint32), gl_ref.view(np.uint32)) and np.array_equal(ga.view(np.uint32), ga_ref.view(np.uint32))
+    assert np.array_equal(gv, gv_ref)

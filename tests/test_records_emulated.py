@@ -296,3 +296,48 @@ def test_batches_and_the_xcd_placement(lib, N, M):
                                      p(gv), p(gl), p(ga), None, p(records), rec_bytes, p(ws), ws_bytes, None) == 0
     assert np.array_equal(gl.view(np.uint32), gl_ref.view(np.uint32)) and np.array_equal(ga.view(np.uint32), ga_ref.view(np.uint32))
     assert np.array_equal(gv, gv_ref)
+
+
+@pytest.mark.skipif(not FULL, reason="70 s on the host model; RLIPV2_TEST_EMU_FULL=1 (green when written, round 5)")
+def test_experiments_child_of_the_route_runs_on_the_model(lib, monkeypatch, capsys):
+    """tools/experiments_r05.py --records (the child bench.py's `experiments` leg starts on the first hardware run) with the host
+    model standing in for the device and a small pyramid for the 800 x 1333 one: its own logic -- four configurations, digests,
+    the table it prints -- must not be what fails on the day."""
+    import contextlib
+    import json
+
+    import torch
+
+    from rlipv2_amd import _lib, msda
+    from tools import experiments_r05 as X
+    from tools import msda_inputs, patch_check, r03_experiments
+
+    i, vp = ctypes.c_int, ctypes.c_void_p
+    lib.msda_fused_forward.argtypes = [i, vp, vp, vp, vp, vp, i, *([i] * 7), vp, vp, vp, vp]
+    monkeypatch.setattr(_lib, "lib", lambda: lib)
+    monkeypatch.setattr(msda, "_on_device", lambda t: True)
+    monkeypatch.setattr(msda, "_launch", lambda t: contextlib.nullcontext(None))
+    pyr = [(20, 27), (10, 14), (5, 7), (3, 4)]
+    real_inputs = msda_inputs.make_inputs
+    monkeypatch.setattr(msda_inputs, "make_inputs", lambda N, **kw: real_inputs(1, pyramid=pyr, M=2, device="cpu", **{k: v for k, v in kw.items() if k != "device"}))
+    monkeypatch.setattr(msda_inputs, "PYRAMID_800x1333", pyr)
+
+    def fused_problem(N, inp):
+        S = inp["value"].shape[1]
+        g = torch.Generator().manual_seed(1)
+        ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")[::-1], -1).reshape(-1, 2)
+                         for H, W in pyr])[None, :, None, :].expand(1, S, 4, 2).contiguous()
+        qproj = torch.randn(1, S, 2 * 48, generator=g)
+        qproj[..., :64] *= 2.5
+        return qproj.bfloat16(), ref
+    monkeypatch.setattr(r03_experiments, "fused_problem", fused_problem)
+    monkeypatch.setattr(patch_check, "timed", lambda fn, iters=10: (fn(), 123.0)[1])
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    X.child_records()
+    line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("RESULT ")][-1]
+    out = json.loads(line[7:])
+    assert set(out) == {"product", "cell_forward", "records", "records_swap"}
+    assert out["records"]["equal_bits"] and out["records_swap"]["equal_bits"] and out["cell_forward"]["equal_bits"]
+    assert out["records"]["fwd_variant"] == "cell+geometry+records" and out["records"]["bwd_variant"] == "records+geometry"
+    assert out["product"]["bwd_variant"] == "dest+geometry" and out["records"]["far_flag"] == 0
+    assert out["records"]["out_max_diff_rel_to_max"] <= 2.0 ** -6 and "digest" not in json.dumps(out)

@@ -242,11 +242,11 @@ class KernelTimer:
             code = _lib.MSDA_BF16 if value.dtype == torch.bfloat16 else _lib.MSDA_F32
             if direction == "fwd":       # (value, shapes, starts, qproj, ref, save) -> (out, loc, aw)
                 Lq = rest[0].shape[1]
-                moved = [value, rest[0], rest[1], *[t for t in out if t is not None]]
-            else:                        # (value, shapes, starts, loc, aw, ref, grad_out, host) -> [g_value, g_qproj]
-                Lq = rest[0].shape[1]
-                moved = [value, rest[0], rest[1], rest[2], rest[3], *out]
-            nbytes = sum(t.numel() * t.element_size() for t in moved)
+                moved = [value, rest[0], rest[1], *[t for t in out if t is not None], self.msda._records_out[0]]
+            else:                        # (value, shapes, starts, loc, aw, ref, grad_out, host[, records]) -> [g_value, g_qproj]
+                Lq = rest[3].shape[1]    # (loc / aw are None under msda.records_route: the records buffer replaces them)
+                moved = [value, rest[0], rest[1], rest[2], rest[3], *rest[5:], *out]
+            nbytes = sum(t.numel() * t.element_size() for t in moved if torch.is_tensor(t))
             dims = (N, S, M, D, shapes.shape[0], Lq, 4)
             # grad_value written as bfloat16: 2 bytes per element less than the float32 grad_value of msda_algorithmic_bytes
             saved = N * S * M * D * 2 if (direction == "bwd" and out[0].dtype == torch.bfloat16) else 0

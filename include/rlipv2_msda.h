@@ -225,7 +225,8 @@ int msda_fused_backward_ws(int flags, int dtype,
  * msda_backward_ws / msda_fused_backward_ws on the same call.
  *   refdim 0: the op's signature -- sampling_loc / attn_weight are INPUTS of both calls (qproj, ref, grad_qproj NULL);
  *   refdim 2 / 4: the module's operands (msda_fused_forward) -- sampling_loc / attn_weight are OUTPUTS of the forward and
- *                 inputs of the backward (the sorting fallback for "far" samples and the softmax backward read them),
+ *                 inputs of the backward, or both NULL in both calls: the records then are the whole saved state (the group
+ *                 records hold the same floats; the sorting fallback for "far" samples rebuilds them inside the workspace);
  *                 grad_sampling_loc / grad_attn_weight NULL.
  * msda_records_bytes: 0 = the route does not take this call.  flags of the backward: MSDA_FLAG_GRAD_VALUE_BF16 (required:
  * the patch pass writes bfloat16 or float32 rows; pass it for bfloat16 grad_value), MSDA_FLAG_RECORDS_SWAP (operand order of

@@ -415,8 +415,10 @@ int msda_records_forward(int dtype, const void *value, const int64_t *spatial_sh
     if (refdim != 0 && refdim != 2 && refdim != 4) return MSDA_ERR_BAD_VARIANT;
     const size_t need = msda_records_bytes(dtype, spatial_shapes_host, N, S, M, D, L, Lq, P);
     if (need == 0) return MSDA_ERR_BAD_VARIANT;
-    if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !out || !records) return MSDA_ERR_NULL_POINTER;
+    if (!value || !spatial_shapes || !level_start || !out || !records) return MSDA_ERR_NULL_POINTER;
     if (refdim != 0 && (!qproj || !ref)) return MSDA_ERR_NULL_POINTER;
+    // (module operands: both NULL = the records are the whole saved state, no float32 locations / weights are written)
+    if (refdim == 0 ? (!sampling_loc || !attn_weight) : ((sampling_loc == nullptr) != (attn_weight == nullptr))) return MSDA_ERR_NULL_POINTER;
     if (records_bytes < need) return MSDA_ERR_BAD_SHAPE;
     if (!(aligned16(value) && aligned16(sampling_loc) && aligned16(attn_weight) && aligned16(out) && aligned16(records) &&
           aligned16(qproj) && aligned16(ref)))
@@ -444,10 +446,10 @@ int msda_records_backward(int flags, int dtype, const void *value, const int64_t
     const size_t need = msda_records_bytes(dtype, spatial_shapes_host, N, S, M, D, L, Lq, P);
     if (need == 0) return MSDA_ERR_BAD_VARIANT;
     const bool out_bf16 = (flags & MSDA_FLAG_GRAD_VALUE_BF16) != 0;
-    if (!value || !spatial_shapes || !level_start || !sampling_loc || !attn_weight || !grad_out || !grad_value || !records ||
-        !workspace)
+    if (!value || !spatial_shapes || !level_start || !grad_out || !grad_value || !records || !workspace) return MSDA_ERR_NULL_POINTER;
+    if (refdim == 0 ? (!grad_sampling_loc || !grad_attn_weight || !sampling_loc || !attn_weight) : (!ref || !grad_qproj))
         return MSDA_ERR_NULL_POINTER;
-    if (refdim == 0 ? (!grad_sampling_loc || !grad_attn_weight) : (!ref || !grad_qproj)) return MSDA_ERR_NULL_POINTER;
+    if ((sampling_loc == nullptr) != (attn_weight == nullptr)) return MSDA_ERR_NULL_POINTER;
     Problem p{};
     p.dtype = dtype; p.N = N; p.S = S; p.M = M; p.D = D; p.L = L; p.Lq = Lq; p.P = P;
     p.value = value; p.shapes = spatial_shapes; p.starts = level_start; p.loc = sampling_loc; p.aw = attn_weight;

@@ -708,9 +708,10 @@ size_t dest_workspace_bytes(const Problem &p, const int64_t *shapes_host)
 }
 
 // K1 + grad_value.  out_bf16: grad_value is bfloat16.
-void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shapes_host, void *workspace, bool out_bf16,
+void launch_backward_dest(const Problem &p_in, const Fused *f, const int64_t *shapes_host, void *workspace, bool out_bf16,
                           const void *records, bool records_swap)
 {
+    Problem p = p_in;                                        // (the records route may point loc / aw at rebuilt copies)
     auto k1 = [&]() { if (f) launch_quad_backward_reduce_fused(p, *f); else launch_quad_backward_reduce(p); };
     if (!records && sparse_dest_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_SPARSE", 1)) {
         k1();
@@ -729,13 +730,22 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
     // word zero and return at once.  Only when the binning met a sample outside its cell's reach (gate != 0: the patch
     // pass has returned without writing) does the sorting pass run.
     const int *gate = nullptr;
+    void *pws = ws + round16(kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl));
     if (records) {
         // the "records" route (msda_cell_records.inc): the forward pass has left every sample's geometry, the patch masks and
         // the group records; nothing is binned here
         gate = launch_cell_records_backward(p, f, shapes_host, records, out_bf16, records_swap);
+        if (!p.loc) {
+            // the forward did not save float32 locations / weights: the sorting pass below -- if the gate lets it run at all --
+            // reads copies rebuilt from the group records, in the part of the workspace the binning of the product route uses
+            // (patch_workspace_bytes >= N * Lq * M * 16 samples * 12 bytes: a group record holds exactly these floats)
+            float *loc = reinterpret_cast<float *>(pws);
+            float *aw = loc + (size_t)p.N * p.Lq * p.M * kL * kP * 2;
+            launch_records_unbin(p, shapes_host, records, loc, aw, gate);
+            p.loc = loc; p.aw = aw;
+        }
     } else if (patch_workspace_bytes(p, shapes_host) > 0 && ablation_env("RLIPV2_MSDA_PATCH", 1)) {
         int *ctl = counter;
-        void *pws = ws + round16(kCtlBytes + mask_bytes(p, pl) + partial_bytes(p, pl));
         const bool cell = cell_backward_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_CELL", 1);
         if (cell) launch_cell_backward(p, f, shapes_host, ctl, pws);
         else k1();

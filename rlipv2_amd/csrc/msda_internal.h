@@ -98,6 +98,7 @@ bool cell_records_supports(const Problem &p, const int64_t *shapes_host);
 size_t cell_records_bytes(const Problem &p, const int64_t *shapes_host);
 const int *launch_cell_records_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, const void *records,
                                         bool out_bf16, bool swap);
+void launch_records_unbin(const Problem &p, const int64_t *shapes_host, const void *records, float *loc, float *aw, const int *gate);
 // the plan of the cell + patch route as int32 values (include/rlipv2_msda.h: msda_backward_plan_info); 0 = route not taken
 int patch_plan_info(const Problem &p, const int64_t *shapes_host, int32_t *out, int out_len);
 void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, int *ctl, void *mask_ws);

@@ -1547,6 +1547,9 @@ void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fus
         if (!f) MSDA_CELL_FWD(0, 0, const_cast<void *>(p.loc), const_cast<void *>(p.aw));      // (REFDIM 0 only reads them)
         else if (f->refdim == 2) MSDA_CELL_FWD(2, 0, f->loc_save, f->aw_save);
         else MSDA_CELL_FWD(4, 0, f->loc_save, f->aw_save);
+    } else if (f && !f->loc_save) {                          // the records are the whole saved state
+        if (f->refdim == 2) MSDA_CELL_FWD(2, 3, nullptr, nullptr);
+        else MSDA_CELL_FWD(4, 3, nullptr, nullptr);
     } else {
         if (!f) MSDA_CELL_FWD(0, 2, const_cast<void *>(p.loc), const_cast<void *>(p.aw));
         else if (f->refdim == 2) MSDA_CELL_FWD(2, 2, f->loc_save, f->aw_save);
@@ -1569,6 +1572,7 @@ const int *launch_cell_records_backward(const Problem &p, const Fused *f, const 
     int *rctl = reinterpret_cast<int *>(rb);
     const int *wtab = reinterpret_cast<const int *>(rb + rl.wtab);
     const uint4 *srec = reinterpret_cast<const uint4 *>(rb + rl.srec);
+    const float *grecs = reinterpret_cast<const float *>(rb + rl.masks + mask_bytes(p, pl));
     const unsigned vbytes = (unsigned)((size_t)p.N * p.S * p.M * kD * 2);
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
 #define MSDA_REC_K(RD, SWAP)                                                                                          \
@@ -1576,7 +1580,7 @@ const int *launch_cell_records_backward(const Problem &p, const Fused *f, const 
         RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)cell_records_backward_kernel<RD, SWAP>,        \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, kFwdWinBytes));  \
         hipLaunchKernelGGL((cell_records_backward_kernel<RD, SWAP>), grid, block, kFwdWinBytes, p.stream, pl,         \
-                           (const bf16_t *)p.value, p.shapes, p.starts, srec, wtab, (const float *)p.aw,              \
+                           (const bf16_t *)p.value, p.shapes, p.starts, srec, wtab, grecs,                            \
                            (const bf16_t *)p.grad_out, p.N, p.S, p.M, p.Lq, vbytes, (float *)p.g_loc, (float *)p.g_aw, \
                            f ? f->ref : nullptr, (bf16_t *)(f ? f->g_qproj : nullptr));                               \
     } while (0)
@@ -1588,6 +1592,18 @@ const int *launch_cell_records_backward(const Problem &p, const Fused *f, const 
 #undef MSDA_REC_K
     launch_patch_dest(p, shapes_host, rctl, rb + rl.masks, out_bf16, true);
     return rctl + kFarWord;
+}
+
+// float32 sampling_loc / attn_weight of the call rebuilt from the group records (only if the gate word is set): for the sorting
+// fallback of a records call whose forward did not save them
+void launch_records_unbin(const Problem &p, const int64_t *shapes_host, const void *records, float *loc, float *aw, const int *gate)
+{
+    PatchPlan pl;
+    make_patch_plan(p, shapes_host, pl);
+    const RecordsLayout rl = records_layout(p, pl);
+    const float *grecs = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(records) + rl.masks + mask_bytes(p, pl));
+    hipLaunchKernelGGL(records_unbin_kernel, dim3(p.N * p.M * pl.CY * pl.CX), dim3(256), 0, p.stream, pl, p.starts, grecs, p.N, p.M,
+                       p.Lq, loc, aw, gate);
 }
 
 bool cell_backward_supports(const Problem &p, const int64_t *shapes_host)

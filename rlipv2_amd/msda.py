@@ -44,6 +44,14 @@ fused_forward_cell = False
 # attribute that only tools / bench.py's experiments set.  records_swap: the other operand order of the 4x4x4 products.
 records_route = False
 records_swap = False
+_records_out = [None]      # the records tensor of the last ms_deform_attn_fused_forward call under records_route (take_records)
+
+
+def take_records():
+    """the records buffer the last ms_deform_attn_fused_forward call filled under msda.records_route (None otherwise); handed over
+    once -- to FusedMSDeformAttnFunction.forward, which saves it for the backward pass in place of sampling_loc / attn_weight"""
+    r, _records_out[0] = _records_out[0], None
+    return r
 # name of the kernel variant the last call of each direction ran (read by bench.py's roofline line)
 last_variant = {}
 
@@ -350,31 +358,33 @@ def fused_supported(value, spatial_shapes, reference_points, Lq, L, P, need_back
 
 def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj, ref, save):
     """value [N, S, M, D], qproj [N, Lq, M*L*P*3] (value's dtype), ref [N, Lq, L, 2|4] float32 ->
-    (out [N, Lq, M*D], sampling_loc | None, attn_weight | None): ms_deform_attn.py:101-117 in one launch."""
+    (out [N, Lq, M*D], sampling_loc | None, attn_weight | None): ms_deform_attn.py:101-117 in one launch.
+    Under msda.records_route (encoder calls): (out, None, None) and the records buffer through take_records()."""
     L = _lib.lib()
     N, S, M, D = value.shape
     nL, Lq = spatial_shapes.shape[0], qproj.shape[1]
     P = qproj.shape[2] // (M * nL * 3)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-    loc = torch.empty((N, Lq, M, nL, P, 2), dtype=torch.float32, device=value.device) if save else None
-    aw = torch.empty((N, Lq, M, nL, P), dtype=torch.float32, device=value.device) if save else None
+    _records_out[0] = None
     if records_route and save and value.dtype == torch.bfloat16 and host_shapes(spatial_shapes) is not None:
         hs = host_shapes(spatial_shapes)
         hs_arr = (ctypes.c_int64 * len(hs))(*hs)
         rec_bytes = int(L.msda_records_bytes(_DTYPES[value.dtype], hs_arr, N, S, M, D, nL, Lq, P))
         if rec_bytes:                                      # (0: not a call the route takes -- the decoders, other shapes)
+            # the records are the whole saved state: no float32 locations / weights (the group records hold the same floats)
             records = torch.empty(rec_bytes, dtype=torch.uint8, device=value.device)
             with _launch(value) as stream:
                 st = L.msda_records_forward(_DTYPES[value.dtype], value.data_ptr(), spatial_shapes.data_ptr(),
                                             level_start_index.data_ptr(), hs_arr, qproj.data_ptr(), ref.data_ptr(), ref.shape[-1],
-                                            loc.data_ptr(), aw.data_ptr(), N, S, M, D, nL, Lq, P, out.data_ptr(),
-                                            records.data_ptr(), rec_bytes, stream)
+                                            None, None, N, S, M, D, nL, Lq, P, out.data_ptr(), records.data_ptr(), rec_bytes, stream)
             if st:
                 _raise(st)
-            roofline.add(roofline.tensor_bytes(value, qproj, ref, out, loc, aw, records))
+            roofline.add(roofline.tensor_bytes(value, qproj, ref, out, records))
             last_variant["fwd"] = "cell+geometry+records"
-            loc.records = records                          # (picked up by FusedMSDeformAttnFunction.forward, saved with loc / aw)
-            return out, loc, aw
+            _records_out[0] = records
+            return out, None, None
+    loc = torch.empty((N, Lq, M, nL, P, 2), dtype=torch.float32, device=value.device) if save else None
+    aw = torch.empty((N, Lq, M, nL, P), dtype=torch.float32, device=value.device) if save else None
     if (fused_forward_cell and save and value.dtype == torch.bfloat16 and Lq == S and nL == 4 and P == 4 and D == 32
             and host_shapes(spatial_shapes) is not None):
         # EXPERIMENT (msda.fused_forward_cell = True; the kernel has not been validated on hardware yet): geometry, the saved float32
@@ -405,10 +415,11 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj
 
 def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, loc, aw, ref, grad_output, host, records=None):
     """-> [grad_value (value's dtype), grad_qproj (value's dtype)]; needs the host copy of the level shapes.
-    records: what ms_deform_attn_fused_forward left on `loc.records` under msda.records_route (the backward then consumes it)."""
+    records: what the forward call left (take_records) under msda.records_route -- loc / aw are None then."""
     L = _lib.lib()
     N, S, M, D = value.shape
-    nL, Lq, P = spatial_shapes.shape[0], loc.shape[1], loc.shape[4]
+    nL, Lq = spatial_shapes.shape[0], grad_output.shape[1]
+    P = loc.shape[4] if loc is not None else 4
     hs_arr = (ctypes.c_int64 * len(host))(*host)
     if sum(host[0::2][k] * host[1::2][k] for k in range(len(host) // 2)) != S:
         raise RuntimeError("ms_deform_attn: sum(H*W) of spatial_shapes != value.shape[1]")   # ms_deform_attn.py:96
@@ -422,12 +433,13 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, loc,
         with _launch(value) as stream:
             st = L.msda_records_backward(flags | (_lib.FLAG_RECORDS_SWAP if records_swap else 0), _DTYPES[value.dtype],
                                          value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), hs_arr,
-                                         loc.data_ptr(), aw.data_ptr(), ref.data_ptr(), ref.shape[-1], go.data_ptr(),
+                                         loc.data_ptr() if loc is not None else None, aw.data_ptr() if aw is not None else None,
+                                         ref.data_ptr(), ref.shape[-1], go.data_ptr(),
                                          N, S, M, D, nL, Lq, P, g_value.data_ptr(), None, None, g_qproj.data_ptr(),
                                          records.data_ptr(), records.numel(), ws.data_ptr(), ws_bytes, stream)
         if st:
             _raise(st)
-        roofline.add(roofline.tensor_bytes(value, records, aw, ref, go, g_value, g_qproj))
+        roofline.add(roofline.tensor_bytes(value, records, ref, go, g_value, g_qproj))
         last_variant["bwd"] = "records+geometry"
         return [g_value, g_qproj]
     with _launch(value) as stream:
@@ -464,18 +476,19 @@ class FusedMSDeformAttnFunction(Function):
         save = ctx.needs_input_grad[0] or ctx.needs_input_grad[3]
         out, loc, aw = ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj, ref, save)
         if save:
-            records = getattr(loc, "records", None)        # (msda.records_route)
+            records = take_records()                       # (msda.records_route: instead of loc / aw)
             ctx.has_records = records is not None
-            ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, aw, ref, *([records] if ctx.has_records else []))
+            ctx.save_for_backward(value, spatial_shapes, level_start_index, ref, *([records] if ctx.has_records else [loc, aw]))
             ctx.host_shapes = host_shapes(spatial_shapes)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, shapes, starts, loc, aw, ref = ctx.saved_tensors[:6]
+        value, shapes, starts, ref = ctx.saved_tensors[:4]
+        loc, aw, records = (None, None, ctx.saved_tensors[4]) if ctx.has_records else (*ctx.saved_tensors[4:6], None)
         g_value, g_qproj = ms_deform_attn_fused_backward(value, shapes, starts, loc, aw, ref, grad_output.contiguous(),
-                                                         ctx.host_shapes, ctx.saved_tensors[6] if ctx.has_records else None)
+                                                         ctx.host_shapes, records)
         return g_value, None, None, g_qproj, None, None
 
 

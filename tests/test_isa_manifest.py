@@ -35,5 +35,5 @@ def test_device_code_equals_the_manifest():
     #  swin.fused_window_attention / deform_attn.sample_then_project, OFF until
     #  routes.validate has compared the Swin step with it against the plain ops on a GPU -- the R50 configurations never reach it;
     #  cell_records_backward_kernel (round 5): behind msda.records_route, OFF)
-    assert all("cell_forward_kernel" in k or "cell_records_backward_kernel" in k or "step_scaled_kernel" in k or k.startswith(("layernorm_wide.hip::", "window_attention.hip::", "msda_rows.hip::"))
+    assert all("cell_forward_kernel" in k or "cell_records_backward_kernel" in k or "records_unbin_kernel" in k or "step_scaled_kernel" in k or k.startswith(("layernorm_wide.hip::", "window_attention.hip::", "msda_rows.hip::"))
                for k in never), never

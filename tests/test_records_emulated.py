@@ -158,6 +158,20 @@ def test_module_operands_bit_equal_to_the_fused_product_route(lib, refdim):
                                          p(gv), None, None, p(gq), p(records), rec_bytes, p(ws), ws_bytes, None) == 0
         assert np.array_equal(gq, gq_ref), f"grad of the projection rows differs (flags {flags:#x})"
         assert np.array_equal(gv, gv_ref), f"grad_value differs (flags {flags:#x})"
+    # the same call with the records as the WHOLE saved state: no float32 locations / weights written or read
+    records2 = np.full(rec_bytes, 0x5A, dtype=np.uint8)
+    out2 = np.zeros_like(out_ref)
+    assert lib.msda_records_forward(BF16, p(vb), p(pyr), p(starts), p(pyr), p(qb), p(ref), refdim, None, None, *dims, p(out2),
+                                    p(records2), rec_bytes, None) == 0
+    assert np.array_equal(out2, out_ref)
+    gv, gq = np.zeros_like(gv_ref), np.zeros_like(gq_ref)
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    assert lib.msda_records_backward(FLAG_BF16_GV | FLAG_SWAP, BF16, p(vb), p(pyr), p(starts), p(pyr), None, None, p(ref), refdim, p(gob),
+                                     *dims, p(gv), None, None, p(gq), p(records2), rec_bytes, p(ws), ws_bytes, None) == 0
+    assert np.array_equal(gq, gq_ref) and np.array_equal(gv, gv_ref)
+    # one of the two pointers alone is refused
+    assert lib.msda_records_forward(BF16, p(vb), p(pyr), p(starts), p(pyr), p(qb), p(ref), refdim, p(loc), None, *dims, p(out2),
+                                    p(records2), rec_bytes, None) != 0
 
 
 def test_far_samples_hand_grad_value_to_the_sorting_pass(lib):
@@ -341,3 +355,48 @@ def test_experiments_child_of_the_route_runs_on_the_model(lib, monkeypatch, caps
     assert out["records"]["fwd_variant"] == "cell+geometry+records" and out["records"]["bwd_variant"] == "records+geometry"
     assert out["product"]["bwd_variant"] == "dest+geometry" and out["records"]["far_flag"] == 0
     assert out["records"]["out_max_diff_rel_to_max"] <= 2.0 ** -6 and "digest" not in json.dumps(out)
+
+
+def test_far_samples_without_saved_locations_rebuild_them_for_the_sorting_pass(lib):
+    """module operands with offsets of tens of pixels on a 1 x 4-cell pyramid, forward called WITHOUT float32 locations / weights:
+    the forward raises the "far" flag, the backward rebuilds the two tensors from the group records inside its workspace
+    (records_unbin_kernel, gated like the pass that reads them) and the sorting pass produces grad_value -- against the product's
+    fused route, which saves them and takes the same detour"""
+    M, L, P, refdim = 1, 4, 4, 2
+    pyr = np.asarray([(16, 64), (8, 32), (4, 16), (2, 8)], dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(pyr[:, 0] * pyr[:, 1])[:-1])).astype(np.int64)
+    S = int((pyr[:, 0] * pyr[:, 1]).sum())
+    rng = np.random.default_rng(77)
+    refp = np.concatenate([np.stack([g.ravel() for g in np.meshgrid((np.arange(W) + 0.5) / W, (np.arange(H) + 0.5) / H)], -1) for H, W in pyr], 0)
+    ref = np.ascontiguousarray(np.broadcast_to(refp[None, :, None, :], (1, S, L, 2)), dtype=np.float32)
+    qproj = rng.standard_normal((1, S, M * L * P * 3))
+    qproj[..., :M * L * P * 2] *= 12.0                                           # pixels: across cells
+    qb = np.ascontiguousarray(bf16_bits(qproj))
+    vb = np.ascontiguousarray(bf16_bits(rng.standard_normal((1, S, M, 32)) * 0.5))
+    gob = np.ascontiguousarray(bf16_bits(rng.standard_normal((1, S, M * 32))))
+    dims = (1, S, M, 32, L, S, P)
+    out_ref = np.zeros((1, S, M * 32), dtype=np.uint16)
+    loc = np.full((1, S, M, L, P, 2), np.nan, dtype=np.float32)
+    aw = np.full((1, S, M, L, P), np.nan, dtype=np.float32)
+    assert lib.msda_fused_forward_hs(CELL, BF16, p(vb), p(pyr), p(starts), p(pyr), p(qb), p(ref), refdim, *dims, p(out_ref), p(loc),
+                                     p(aw), None) == 0
+    ws_bytes = lib.msda_backward_workspace_bytes(BF16, p(pyr), *dims)
+    ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+    gv_ref, gq_ref = np.zeros(vb.shape, dtype=np.uint16), np.zeros(qb.shape, dtype=np.uint16)
+    assert lib.msda_fused_backward_ws(FLAG_BF16_GV, BF16, p(vb), p(pyr), p(starts), p(pyr), p(loc), p(aw), p(ref), refdim, p(gob),
+                                      *dims, p(gv_ref), p(gq_ref), p(ws), ws_bytes, None) == 0
+    assert int(ws[:256].view(np.int32)[60]) != 0                                 # the product route met far samples too
+    rec_bytes = lib.msda_records_bytes(BF16, p(pyr), *dims)
+    records = np.full(rec_bytes, 0xA5, dtype=np.uint8)
+    out = np.zeros_like(out_ref)
+    assert lib.msda_records_forward(BF16, p(vb), p(pyr), p(starts), p(pyr), p(qb), p(ref), refdim, None, None, *dims, p(out),
+                                    p(records), rec_bytes, None) == 0
+    assert np.array_equal(out, out_ref) and int(records[:256].view(np.int32)[60]) != 0
+    gv, gq = np.zeros_like(gv_ref), np.zeros_like(gq_ref)
+    ws = np.full(ws_bytes + 64, 0xEE, dtype=np.uint8)                            # garbage where the rebuilt tensors will live
+    assert lib.msda_records_backward(FLAG_BF16_GV, BF16, p(vb), p(pyr), p(starts), p(pyr), None, None, p(ref), refdim, p(gob), *dims,
+                                     p(gv), None, None, p(gq), p(records), rec_bytes, p(ws), ws_bytes, None) == 0
+    assert np.all(ws[ws_bytes:] == 0xEE)
+    assert np.array_equal(gq, gq_ref)
+    a, b = bf16_val(gv).astype(np.float64), bf16_val(gv_ref).astype(np.float64)  # (host-model order of the sorting pass: see above)
+    assert np.abs(a - b).max() <= 2.0 ** -7 * np.abs(b).max() and np.mean(gv != gv_ref) < 1e-3

@@ -88,7 +88,7 @@ def child_records():
         msda.records_route, msda.records_swap, msda.fused_forward_cell = route, swap, cell
         try:
             o, loc, aw = fwd()
-            records = getattr(loc, "records", None)
+            records = msda.take_records()
             bwd = lambda: msda.ms_deform_attn_fused_backward(inp["value"], inp["shapes"], inp["starts"], loc, aw, ref,   # noqa: E731
                                                              inp["grad_out"], hs, records)
             g = bwd()

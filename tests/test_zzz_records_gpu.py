@@ -124,3 +124,29 @@ def test_records_route_op_signature_against_the_oracle():
     assert np.abs(out.float().cpu().numpy() - o_out).max() <= 2.0 ** -7 * np.abs(o_out).max()
     assert np.abs(res["records"][0].float().numpy() - o_gv).max() <= 2.0 ** -7 * np.abs(o_gv).max()
     np.testing.assert_allclose(res["records"][2].numpy(), o_ga, rtol=1e-4, atol=1e-5 * float(np.abs(o_ga).max()))
+
+
+def test_records_route_with_far_samples_takes_the_sorting_pass():
+    """projection rows whose offsets reach tens of pixels: the forward's binning raises the "far" flag, the backward rebuilds the
+    float32 locations / weights from the group records (the route saves none) and the gated sorting pass writes grad_value --
+    the same bits as the product route, which takes the same detour with its saved tensors (on the hardware the sorting pass
+    is bit-repeatable: per-wave histograms, lane order)"""
+    from rlipv2_amd import msda
+    value0, shapes, starts, qproj0, ref, gout = _encoder_call([(64, 96), (32, 48), (16, 24), (8, 12)], 1, 8, seed=5, refdim=2)
+    qproj0 = qproj0.clone()
+    qproj0[..., :8 * 32] *= 10.0
+
+    def run(route):
+        msda.records_route = route
+        try:
+            value, qproj = value0.clone().requires_grad_(True), qproj0.clone().requires_grad_(True)
+            out = msda.FusedMSDeformAttnFunction.apply(value, shapes, starts, qproj, ref, 64)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            return out.detach(), value.grad, qproj.grad
+        finally:
+            msda.records_route = False
+    base, got = run(False), run(True)
+    assert torch.isfinite(got[1].float()).all() and torch.isfinite(got[2].float()).all()
+    assert torch.equal(got[2].view(torch.int16), base[2].view(torch.int16)), "grad of the projection rows differs"
+    assert torch.equal(got[1].view(torch.int16), base[1].view(torch.int16)), "grad_value differs"

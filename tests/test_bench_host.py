@@ -191,3 +191,36 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
     monkeypatch.undo()
     out = X.run_child(["--fwd"], dict(os.environ), 120)
     assert "error" in out
+
+
+def test_promotion_report_reads_an_experiments_object(tmp_path, capsys):
+    """tools/promote_r05.py on a synthetic bench line: bit-equal + faster -> PROMOTE with the place to edit, differing bits ->
+    REJECT, slower -> KEEP OFF, a child that timed out -> SKIP"""
+    from tools import promote_r05 as P
+    rep = {"experiments": {
+        "encoder_backward_arms": {
+            "default": {"b0": {"us": 540.0, "equal_bits": True, "finite": True}, "fused": {"us": 545.0, "equal_bits": True, "finite": True}},
+            "cell 3": {"b0": {"us": 470.0, "equal_bits": True, "finite": True}, "fused": {"us": 480.0, "equal_bits": True, "finite": True}},
+            "cell 2": {"b0": {"us": 450.0, "equal_bits": False, "finite": True}, "fused": {"us": 455.0, "equal_bits": False, "finite": True}},
+            "patch multi": {"error": "timed out after 45 s (child killed)"}},
+        "encoder_records_route": {
+            "product": {"fwd_us": 190.0, "bwd_us": 545.0},
+            "cell_forward": {"fwd_us": 170.0, "equal_bits": True, "out_max_diff_rel_to_max": 0.004},
+            "records": {"fwd_us": 230.0, "bwd_us": 350.0, "equal_bits": True, "finite": True, "far_flag": 0, "records_MB": 409.3},
+            "records_swap": {"fwd_us": 230.0, "bwd_us": 330.0, "equal_bits": False, "finite": True, "far_flag": 0, "records_MB": 409.3}},
+        "encoder_forward_cell": {"model": {"quad_us": 160.0, "cell_us": 165.0, "max_diff_rel_to_max": 0.004, "non_finite": 0}},
+        "decoder_cross_attention_sample_then_project": {"standard_us": 400.0, "sample_then_project_us": 300.0, "rel_l2_out": 0.004,
+                                                        "rel_l2_d_src": 0.006, "rel_l2_d_value_proj_weight": 0.005},
+        "swin_routes": {"error": "not started: time budget used up"}}}
+    path = tmp_path / "line.json"
+    path.write_text("[bench] some log line\n" + json.dumps(rep) + "\n")
+    rows = {name: (verdict, where) for verdict, name, _, where in P.decide(P.load(str(path)))}
+    assert rows["cell 3"][0] == "PROMOTE" and "kCellMode" in rows["cell 3"][1]
+    assert rows["cell 2"][0] == "REJECT" and rows["patch multi"][0] == "SKIP"
+    assert rows["records route (records)"][0] == "PROMOTE" and "records_route = True" in rows["records route (records)"][1]
+    assert rows["records route (records_swap)"][0] == "REJECT"
+    assert rows["cell forward, B0 signature (model locations)"][0] == "KEEP OFF"
+    assert rows["decoder cross-attention: sample, then project"][0] == "PROMOTE" and rows["Swin routes"][0] == "SKIP"
+    sys.argv = ["promote_r05.py", str(path)]
+    P.main()
+    assert "PROMOTE   records route (records)" in capsys.readouterr().out

@@ -10,3 +10,4 @@ tail -30 $OUT/pytest_gpu.txt
 ( timeout 240 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/smoke.txt ); tail -3 $OUT/smoke.txt
 timeout 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 tail -c 3000 $OUT/bench_line.json; tail -5 $OUT/bench_stderr.txt
+python tools/promote_r05.py $OUT/bench_line.json > $OUT/promote.txt 2>&1; cat $OUT/promote.txt

@@ -583,7 +583,11 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
         line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
     # (LAST, after everything of this process that touches the GPU: the arms run in child processes, and one that has never run
     #  on hardware may leave the device recovering when it is killed)
-    experiments = experiments() if callable(experiments) else experiments
+    if callable(experiments):
+        # insurance: the line as it stands goes to stderr before up to 130 s of child processes -- if anything outside this
+        # process ends the run meanwhile, the measured numbers are in the captured output (stdout still gets exactly ONE line)
+        print("[bench] line before the experiments leg: " + json.dumps(line), file=sys.stderr, flush=True)
+        experiments = experiments()
     if experiments is not None:
         line["experiments"] = experiments
         emit.child_timed_out = "timed out" in json.dumps(experiments)

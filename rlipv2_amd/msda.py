@@ -389,7 +389,7 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, qproj
             and host_shapes(spatial_shapes) is not None):
         # EXPERIMENT (msda.fused_forward_cell = True; the kernel has not been validated on hardware yet): geometry, the saved float32
         # locations / weights and the sampling from LDS windows on the matrix cores in one kernel
-        # (csrc/msda_cell_forward.inc: cell_forward_kernel<refdim>)
+        # (csrc/msda_cell_forward.inc: cell_forward_kernel<refdim, 0>)
         hs = host_shapes(spatial_shapes)
         hs_arr = (ctypes.c_int64 * len(hs))(*hs)
         with _launch(value) as stream:

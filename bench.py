@@ -584,7 +584,7 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
     # (LAST, after everything of this process that touches the GPU: the arms run in child processes, and one that has never run
     #  on hardware may leave the device recovering when it is killed)
     if callable(experiments):
-        # insurance: the line as it stands goes to stderr before up to 130 s of child processes -- if anything outside this
+        # insurance: the line as it stands goes to stderr before up to 150 s of child processes -- if anything outside this
         # process ends the run meanwhile, the measured numbers are in the captured output (stdout still gets exactly ONE line)
         print("[bench] line before the experiments leg: " + json.dumps(line), file=sys.stderr, flush=True)
         experiments = experiments()
@@ -688,7 +688,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-experiments", dest="experiments", action="store_false",
                     help="skip the A/B table of the unmeasured kernel arms that a default 1-GPU run appends after its timed region "
-                         "(tools/experiments_r05.py, at most 130 s, child processes)")
+                         "(tools/experiments_r05.py, at most 150 s, child processes)")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE", dest="overrides",
                     help="A/B runs: set a bool / int attribute of a rlipv2_amd module for this run, e.g. --set decoder.fused_glue=0 "
                          "(the switches INTEGRATION.md lists; recorded in config.overrides)")

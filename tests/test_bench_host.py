@@ -171,15 +171,20 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
         if args[0] == "--stp":
             return {"standard_us": 400.0, "sample_then_project_us": 380.0}
         if args[0] == "--records":
-            return {"product": {"fwd_us": 190.0, "bwd_us": 540.0}, "records": {"fwd_us": 220.0, "bwd_us": 350.0, "equal_bits": True}}
+            return {"product": {"fwd_us": 190.0, "bwd_us": 540.0}, "records": {"fwd_us": 220.0, "bwd_us": 350.0, "equal_bits": True, "finite": True},
+                    "records_swap": {"fwd_us": 220.0, "bwd_us": 330.0, "equal_bits": False, "finite": True}}
         k = int(args[1])
         if k == 3:
             return {"error": "timed out after 75 s (child killed)"}
         d = [[1, 2], [3, 4], [5, 6]] if k != 2 else [[1, 2], [3, 4], [5, 7]]
         return {"b0": {"digest": d, "finite": True, "us": 500.0 - k}, "fused": {"digest": d, "finite": True, "us": 540.0 - k}}
+    steps = []
     monkeypatch.setattr(X, "run_child", fake)
+    monkeypatch.setattr(X, "run_step_child", lambda flags, env, timeout: steps.append(flags) or {"ms_per_step": 35.0, "roofline_frac": 0.14})
     monkeypatch.setattr(X, "ABLATION_LIB", os.path.join(ROOT, "bench.py"))
     rep = X.main()
+    # (the records route was bit-equal in the fake child: the whole step is measured with it, in a child of its own)
+    assert steps == [["--set", "msda.records_route=1"]] and rep["train_step_with_records_route"]["roofline_frac"] == 0.14
     arms = rep["encoder_backward_arms"]
     names = [n for n, _ in X.ARMS]
     assert arms[names[0]]["b0"]["equal_bits"] and arms[names[1]]["fused"]["equal_bits"]
@@ -211,7 +216,9 @@ def test_promotion_report_reads_an_experiments_object(tmp_path, capsys):
         "encoder_forward_cell": {"model": {"quad_us": 160.0, "cell_us": 165.0, "max_diff_rel_to_max": 0.004, "non_finite": 0}},
         "decoder_cross_attention_sample_then_project": {"standard_us": 400.0, "sample_then_project_us": 300.0, "rel_l2_out": 0.004,
                                                         "rel_l2_d_src": 0.006, "rel_l2_d_value_proj_weight": 0.005},
-        "swin_routes": {"error": "not started: time budget used up"}}}
+        "train_step_with_records_route": {"ms_per_step": 34.9, "roofline_frac": 0.146, "mean_launch_us": 350.0, "roofline_kernel": "msda_records"},
+        "swin_routes": {"error": "not started: time budget used up"}},
+        "ms_per_step": 36.1, "roofline": {"frac": 0.094, "mean_launch_us": 542.0}}
     path = tmp_path / "line.json"
     path.write_text("[bench] some log line\n" + json.dumps(rep) + "\n")
     rows = {name: (verdict, where) for verdict, name, _, where in P.decide(P.load(str(path)))}
@@ -219,6 +226,7 @@ def test_promotion_report_reads_an_experiments_object(tmp_path, capsys):
     assert rows["cell 2"][0] == "REJECT" and rows["patch multi"][0] == "SKIP"
     assert rows["records route (records)"][0] == "PROMOTE" and "records_route = True" in rows["records route (records)"][1]
     assert rows["records route (records_swap)"][0] == "REJECT"
+    assert rows["train step with the records route"][0] == "PROMOTE"
     assert rows["cell forward, B0 signature (model locations)"][0] == "KEEP OFF"
     assert rows["decoder cross-attention: sample, then project"][0] == "PROMOTE" and rows["Swin routes"][0] == "SKIP"
     sys.argv = ["promote_r05.py", str(path)]

@@ -12,6 +12,7 @@ Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_
   records    the "records" route (csrc/msda_cell_forward.inc EMIT + csrc/msda_cell_records.inc): the forward leaves per-sample
              records / window tables / patch masks, the backward runs no geometry and no binning -- fused call, forward and
              backward times against the product kernels, gradients bit for bit                                  (same lines)
+  step       if (and only if) the records route's gradients are bit-equal: one short bench.py run of the whole train step with it
   fwd cell   cell_forward_kernel (explicit variant "cell" of the product library) against the product forward (.cuh:237-299)
   swin       the two Swin routes of round 5 (csrc/window_attention.hip, csrc/layernorm_wide.hip; models/swin/swin_transformer.py:
              262-301, 386-401) at the Swin-L stage-0 shapes against the PyTorch op sequences they replace
@@ -265,7 +266,28 @@ def run_child(args, env, timeout):
     return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
 
 
-def main(per_child_timeout=45, budget_s=130):
+def run_step_child(flags, env, timeout):
+    """one short bench.py run (train step, graphed, no CPU baseline, no experiments) with extra flags; -> the numbers of its line that
+    matter for an A/B against the parent's own measurement"""
+    t0 = time.time()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-experiments", *flags]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout} s (child killed)"}
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith("{"):
+            d = json.loads(line)
+            roof = d.get("roofline", {})
+            return {"flags": " ".join(flags), "ms_per_step": d.get("ms_per_step"), "images_per_s": d.get("value"),
+                    "roofline_kernel": roof.get("kernel"), "roofline_frac": roof.get("frac"), "mean_launch_us": roof.get("mean_launch_us"),
+                    "msda_ms_per_step": roof.get("msda_ms_per_step"),
+                    "encoder_kernels_us": {k: v.get("mean_us") for k, v in roof.get("all_kernels", {}).items() if k.startswith("enc")},
+                    "host_routes": d.get("config", {}).get("host_routes"), "wall_s": round(time.time() - t0, 1)}
+    return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+
+
+def main(per_child_timeout=45, budget_s=150):
     """parent: one child per arm / kernel, most informative first; nothing is started after `budget_s` seconds and no child may
     run past the deadline (bench.py's default run must stay within minutes); `--all`: no budget, every arm"""
     everything = "--all" in sys.argv
@@ -296,13 +318,21 @@ def main(per_child_timeout=45, budget_s=130):
             for case in ("b0", "fused"):
                 out[case]["equal_bits"] = digests[case] == base[0][case]
         arms[name] = out
-    # order = value of the evidence: the default pair and the most complete cell arm, the other kernels, then the remaining arms
+    # order = value of the evidence: the default pair, the records route (kernel level, then -- only if its gradients are the product
+    # kernels' bit for bit -- the whole train step with it), the decoders' route, the most complete cell arm, the other kernels
     arm(0)
-    report["encoder_records_route"] = child(["--records"])
+    rec = report["encoder_records_route"] = child(["--records"])
+    report["decoder_cross_attention_sample_then_project"] = child(["--stp"])
+    good = [n for n in ("records", "records_swap") if isinstance(rec.get(n), dict) and rec[n].get("equal_bits") and rec[n].get("finite")]
+    if good and (left() >= 75 or everything):
+        best = min(good, key=lambda n: rec[n]["fwd_us"] + rec[n]["bwd_us"])
+        flags = ["--set", "msda.records_route=1"] + (["--set", "msda.records_swap=1"] if best == "records_swap" else [])
+        report["train_step_with_records_route"] = run_step_child(flags, base_env, int(min(120, left())))
+    elif good:
+        report["train_step_with_records_route"] = {"error": "not started: time budget used up"}
     arm(1)
     report["encoder_backward_arms"] = arms if have_arms else {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
     report["encoder_forward_cell"] = child(["--fwd"])
-    report["decoder_cross_attention_sample_then_project"] = child(["--stp"])
     report["swin_routes"] = child(["--swin"])
     for k in range(2, len(ARMS) if everything else 4):
         arm(k)

@@ -21,7 +21,11 @@ def load(path):
             last = json.loads(line)
     if last is None:
         raise SystemExit(f"{path}: no JSON object found")
-    return last.get("experiments", last)
+    rep = dict(last.get("experiments", last))
+    if "experiments" in last:                      # a bench line: keep what the parent measured itself next to its experiments
+        rep["_parent"] = {"ms_per_step": last.get("ms_per_step"), "roofline_frac": last.get("roofline", {}).get("frac"),
+                          "mean_launch_us": last.get("roofline", {}).get("mean_launch_us")}
+    return rep
 
 
 def faster(new, old):
@@ -68,6 +72,15 @@ def decide(rep):
                             + "; then bench.py --set msda.records_route=1 for the step, GPU suite"))
             else:
                 out.append(("KEEP OFF", f"records route ({name})", detail, ""))
+        st = rep.get("train_step_with_records_route")
+        if st and "error" not in st:
+            par = rep.get("_parent", {})
+            out.append(("PROMOTE" if faster(st.get("ms_per_step"), par.get("ms_per_step")) else "INFO", "train step with the records route",
+                        f"{par.get('ms_per_step')} -> {st.get('ms_per_step')} ms per step, roofline.frac {par.get('roofline_frac')} -> "
+                        f"{st.get('roofline_frac')} ({st.get('roofline_kernel')}: {par.get('mean_launch_us')} -> {st.get('mean_launch_us')} us)",
+                        "the step-level number that decides; same edit as above"))
+        elif st:
+            out.append(("SKIP", "train step with the records route", st["error"], ""))
         c = rec.get("cell_forward")
         if c:
             out.append(("INFO", "cell forward alone", f"forward {p['fwd_us']} -> {c['fwd_us']} us, output differs by "

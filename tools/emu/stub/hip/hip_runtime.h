@@ -41,7 +41,7 @@ constexpr int kMaxThreads = 1024, kLdsBytes = 160 * 1024;
 
 struct Wave {
     Barrier quad[16], row[4], half[2], all;
-    uint64_t slot[64][8];
+    uint64_t slot[4][2][64][8];                     // [scope][parity][lane]: see publish()
     Wave() { for (auto &b : quad) b.reset(4); for (auto &b : row) b.reset(16); for (auto &b : half) b.reset(32); all.reset(64); }
 };
 
@@ -67,14 +67,20 @@ inline Barrier &barrier_of(Scope s)
     Wave &w = wave();
     return s == QUAD ? w.quad[lane() >> 2] : s == ROW ? w.row[lane() >> 4] : s == HALF ? w.half[lane() >> 5] : w.all;
 }
+// A collective = every lane of the scope's group publishes its operands, ONE rendezvous, every lane reads what it needs.  The
+// slots are double-buffered per scope: the next collective of the same scope writes the other buffer, and the one after that can
+// only be reached through the next rendezvous of the same group -- which every lane enters after it has finished reading this
+// one.  (One barrier per collective instead of two: these waits are where the host model spends its time.)
+inline int &parity_ref(Scope s) { thread_local int p[4] = {0, 0, 0, 0}; return p[s]; }
+inline uint64_t (*cur(Scope s))[8] { return wave().slot[s][parity_ref(s)]; }
 inline uint64_t *publish(Scope s, uint64_t a, uint64_t b = 0, uint64_t c = 0, uint64_t d = 0)
 {
-    uint64_t *sl = wave().slot[lane()];
+    uint64_t *sl = cur(s)[lane()];
     sl[0] = a; sl[1] = b; sl[2] = c; sl[3] = d;
     barrier_of(s).wait();
     return sl;
 }
-inline void done(Scope s) { barrier_of(s).wait(); }
+inline void done(Scope s) { parity_ref(s) ^= 1; }
 
 inline int update_dpp(int old, int v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
@@ -90,21 +96,21 @@ inline int update_dpp(int old, int v, int ctrl, int row_mask, int bank_mask, boo
     else { std::fprintf(stderr, "emu: DPP control %#x not modelled\n", ctrl); std::abort(); }
     int r = old;
     const bool enabled = ((row_mask >> row) & 1) && ((bank_mask >> (in_row >> 2)) & 1);
-    if (enabled) r = src >= 0 ? (int)(uint32_t)wave().slot[src][0] : (bound_ctrl ? 0 : old);
+    if (enabled) r = src >= 0 ? (int)(uint32_t)cur(s)[src][0] : (bound_ctrl ? 0 : old);
     done(s);
     return r;
 }
 inline int readfirstlane(int v)
 {
     publish(WAVE, (uint32_t)v);
-    const int r = (int)(uint32_t)wave().slot[0][0];
+    const int r = (int)(uint32_t)cur(WAVE)[0][0];
     done(WAVE);
     return r;
 }
 inline int readlane(int v, int l)
 {
     publish(WAVE, (uint32_t)v);
-    const int r = (int)(uint32_t)wave().slot[l & 63][0];
+    const int r = (int)(uint32_t)cur(WAVE)[l & 63][0];
     done(WAVE);
     return r;
 }
@@ -112,7 +118,7 @@ inline unsigned long long ballot(bool p)
 {
     publish(WAVE, p ? 1 : 0);
     unsigned long long m = 0;
-    for (int i = 0; i < 64; ++i) m |= (unsigned long long)(wave().slot[i][0] & 1) << i;
+    for (int i = 0; i < 64; ++i) m |= (unsigned long long)(cur(WAVE)[i][0] & 1) << i;
     done(WAVE);
     return m;
 }
@@ -124,7 +130,7 @@ template <typename T> inline T shfl_xor(T v, int mask)
     uint64_t u = 0;
     std::memcpy(&u, &v, sizeof(T));
     publish(s, u);
-    const uint64_t o = wave().slot[lane() ^ mask][0];
+    const uint64_t o = cur(s)[lane() ^ mask][0];
     T r;
     std::memcpy(&r, &o, sizeof(T));
     done(s);
@@ -253,7 +259,7 @@ template <typename T> inline T emu_shfl_from(T v, int src)      // every lane na
     uint64_t u = 0;
     std::memcpy(&u, &v, sizeof(T));
     emu::publish(emu::WAVE, u);
-    const uint64_t o = emu::wave().slot[(src >= 0 && src < 64) ? src : emu::lane()][0];
+    const uint64_t o = emu::cur(emu::WAVE)[(src >= 0 && src < 64) ? src : emu::lane()][0];
     T r;
     std::memcpy(&r, &o, sizeof(T));
     emu::done(emu::WAVE);
@@ -313,7 +319,7 @@ inline emu_s16x4 emu_tr_read(unsigned addr, unsigned offset)
     const int l = emu::lane(), base = l & ~15, i = l & 15;
     emu_s16x4 v;
     for (int e = 0; e < 4; ++e) {
-        const unsigned a = (unsigned)emu::wave().slot[base + 4 * e + (i >> 2)][0] + offset + (unsigned)(i & 3) * 2u;
+        const unsigned a = (unsigned)emu::cur(emu::ROW)[base + 4 * e + (i >> 2)][0] + offset + (unsigned)(i & 3) * 2u;
         short x;
         std::memcpy(&x, emu::lds_ptr(a), 2);
         v[e] = x;
@@ -327,10 +333,10 @@ inline emu_f32x4 emu_mfma444(emu_s16x4 a, emu_s16x4 b, emu_f32x4 c)
     std::memcpy(&ua, &a, 8); std::memcpy(&ub, &b, 8);
     emu::publish(emu::QUAD, ua, ub);
     const int l = emu::lane(), blk = l & ~3, j = l & 3;
-    const uint64_t bj = emu::wave().slot[blk + j][1];
+    const uint64_t bj = emu::cur(emu::QUAD)[blk + j][1];
     emu_f32x4 d = c;
     for (int i = 0; i < 4; ++i) {
-        const uint64_t ai = emu::wave().slot[blk + i][0];
+        const uint64_t ai = emu::cur(emu::QUAD)[blk + i][0];
         float acc = c[i];
         for (int k = 0; k < 4; ++k) acc += emu::bf16f((uint32_t)((ai >> (16 * k)) & 0xffff)) * emu::bf16f((uint32_t)((bj >> (16 * k)) & 0xffff));
         d[i] = acc;
@@ -353,7 +359,7 @@ template <typename V> inline emu_f32x4 emu_mfma16(V a, V b, emu_f32x4 c)
         const int row = 4 * rg + i;
         float acc = c[i];
         for (int kg = 0; kg < 4; ++kg) {                         // k = 8 kg + e: A from lane (row, kg), B from lane (col, kg)
-            const uint64_t *sa = emu::wave().slot[kg * 16 + row], *sb = emu::wave().slot[kg * 16 + col];
+            const uint64_t *sa = emu::cur(emu::WAVE)[kg * 16 + row], *sb = emu::cur(emu::WAVE)[kg * 16 + col];
             for (int e = 0; e < 8; ++e) {
                 const uint32_t x = (uint32_t)((sa[e >> 2] >> (16 * (e & 3))) & 0xffff);
                 const uint32_t y = (uint32_t)((sb[2 + (e >> 2)] >> (16 * (e & 3))) & 0xffff);
@@ -386,7 +392,7 @@ template <typename V> inline emu_f32x16 emu_mfma32(V a, V b, emu_f32x16 c)
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float acc = c[r];
         for (int kg = 0; kg < 2; ++kg) {
-            const uint64_t *sa = emu::wave().slot[kg * 32 + row], *sb = emu::wave().slot[kg * 32 + col];
+            const uint64_t *sa = emu::cur(emu::WAVE)[kg * 32 + row], *sb = emu::cur(emu::WAVE)[kg * 32 + col];
             for (int e = 0; e < 8; ++e) {
                 const uint32_t x = (uint32_t)((sa[e >> 2] >> (16 * (e & 3))) & 0xffff);
                 const uint32_t y = (uint32_t)((sb[2 + (e >> 2)] >> (16 * (e & 3))) & 0xffff);

@@ -171,8 +171,8 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
         if args[0] == "--stp":
             return {"standard_us": 400.0, "sample_then_project_us": 380.0}
         if args[0] == "--records":
-            return {"product": {"fwd_us": 190.0, "bwd_us": 540.0}, "records": {"fwd_us": 220.0, "bwd_us": 350.0, "equal_bits": True, "finite": True},
-                    "records_swap": {"fwd_us": 220.0, "bwd_us": 330.0, "equal_bits": False, "finite": True}}
+            return {"product": {"fwd_us": 190.0, "bwd_us": 540.0}, "records": {"fwd_us": 220.0, "bwd_us": 350.0, "equal_bits": False, "accepted": True, "finite": True},
+                    "records_swap": {"fwd_us": 220.0, "bwd_us": 330.0, "equal_bits": False, "accepted": False, "finite": True}}
         k = int(args[1])
         if k == 3:
             return {"error": "timed out after 75 s (child killed)"}
@@ -190,7 +190,7 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
     assert arms[names[0]]["b0"]["equal_bits"] and arms[names[1]]["fused"]["equal_bits"]
     assert not arms[names[2]]["b0"]["equal_bits"] and "error" in arms[names[3]]
     assert rep["encoder_forward_cell"]["model"]["cell_us"] == 110.0 and "swin_routes" in rep
-    assert rep["encoder_records_route"]["records"]["equal_bits"]
+    assert rep["encoder_records_route"]["records"]["accepted"]
     assert "digest" not in json.dumps(rep)
     # a real child that produces nothing (here: no GPU) is an error entry, not an exception
     monkeypatch.undo()
@@ -211,8 +211,8 @@ def test_promotion_report_reads_an_experiments_object(tmp_path, capsys):
         "encoder_records_route": {
             "product": {"fwd_us": 190.0, "bwd_us": 545.0},
             "cell_forward": {"fwd_us": 170.0, "equal_bits": True, "out_max_diff_rel_to_max": 0.004},
-            "records": {"fwd_us": 230.0, "bwd_us": 350.0, "equal_bits": True, "finite": True, "far_flag": 0, "records_MB": 409.3},
-            "records_swap": {"fwd_us": 230.0, "bwd_us": 330.0, "equal_bits": False, "finite": True, "far_flag": 0, "records_MB": 409.3}},
+            "records": {"fwd_us": 230.0, "bwd_us": 350.0, "equal_bits": False, "accepted": True, "finite": True, "far_flag": 0, "records_MB": 409.3},
+            "records_swap": {"fwd_us": 230.0, "bwd_us": 330.0, "equal_bits": False, "accepted": False, "finite": True, "far_flag": 0, "records_MB": 409.3}},
         "encoder_forward_cell": {"model": {"quad_us": 160.0, "cell_us": 165.0, "max_diff_rel_to_max": 0.004, "non_finite": 0}},
         "decoder_cross_attention_sample_then_project": {"standard_us": 400.0, "sample_then_project_us": 300.0, "rel_l2_out": 0.004,
                                                         "rel_l2_d_src": 0.006, "rel_l2_d_value_proj_weight": 0.005},

@@ -16,8 +16,9 @@ Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_
   fwd cell   cell_forward_kernel (explicit variant "cell" of the product library) against the product forward (.cuh:237-299)
   swin       the two Swin routes of round 5 (csrc/window_attention.hip, csrc/layernorm_wide.hip; models/swin/swin_transformer.py:
              262-301, 386-401) at the Swin-L stage-0 shapes against the PyTorch op sequences they replace
-Every backward arm must reproduce the default's three gradients BIT FOR BIT (64-bit digests of the raw bits, computed on the
-device) on the encoder shape (N = 4, 800x1333 pyramid, bf16, model-like locations), B0 signature and fused geometry route;
+Every backward arm is compared with the default's gradients (64-bit digests of the raw bits, computed on the device, and -- through
+a file in /dev/shm the default arm leaves -- per-tensor closeness: grad_value must be bit-equal, the float32-formula gradients within a
+rounding) on the encoder shape (N = 4, 800x1333 pyramid, bf16, model-like locations), B0 signature and fused geometry route;
 time = HIP events around 20 calls of the whole backward.
 """
 import json
@@ -47,6 +48,25 @@ def digest(t):
     return [int(raw.sum()), int((raw * pos).sum())]
 
 
+REF_FILE = "/dev/shm/rlipv2_experiments_default_arm.pt"      # the default arm's gradients, for the other arms' children (parent deletes it)
+
+
+def closeness(res, ref):
+    """per tensor: bit-equal?, largest difference relative to the reference's largest magnitude, share of elements that differ.
+    (What decides on the hardware: grad_value comes out of the SAME kernel from the same operands in every arm and must be bit-equal;
+    the other gradients go through float32 formulas whose FMA contraction the compiler chooses per kernel -- even per sample position
+    inside the product kernel, profiles/r05_records_route_static.txt -- so there the bar is "within a rounding of the output type".)"""
+    import torch
+    rows = []
+    for a, b in zip(res, ref):
+        a32, b32 = a.float(), b.float()
+        rows.append({"equal_bits": bool(torch.equal(a.view(torch.int16 if a.element_size() == 2 else torch.int32),
+                                                    b.view(torch.int16 if b.element_size() == 2 else torch.int32))),
+                     "max_diff_rel_to_max": float((a32 - b32).abs().max() / b32.abs().max().clamp_min(1e-30)),
+                     "differing_share": float((a32 != b32).float().mean())})
+    return rows
+
+
 def child_backward(arm):
     import torch
     from rlipv2_amd import msda
@@ -57,6 +77,7 @@ def child_backward(arm):
     inp = make_inputs(4, mode="model", dtype=torch.bfloat16, seed=3)
     a = (inp["value"], inp["shapes"], inp["starts"], inp["loc"], inp["aw"], inp["grad_out"])
     res = msda.ms_deform_attn_backward(*a, 64)
+    saved = {"b0": [t.cpu() for t in res]}
     out["b0"] = {"digest": [digest(t) for t in res], "finite": all(bool(torch.isfinite(t.float()).all()) for t in res),
                  "us": round(timed(lambda: msda.ms_deform_attn_backward(*a, 64), iters=20), 1)}
     msda.attach_host_shapes(inp["shapes"], PYRAMID_800x1333)
@@ -65,8 +86,15 @@ def child_backward(arm):
     hs = msda.host_shapes(inp["shapes"])
     f = lambda: msda.ms_deform_attn_fused_backward(inp["value"], inp["shapes"], inp["starts"], loc, aw, ref, inp["grad_out"], hs)  # noqa: E731
     res = [t for t in f() if torch.is_tensor(t)]
+    saved["fused"] = [t.cpu() for t in res]
     out["fused"] = {"digest": [digest(t) for t in res], "finite": all(bool(torch.isfinite(t.float()).all()) for t in res),
                     "us": round(timed(f, iters=20), 1)}
+    if arm == 0:
+        torch.save(saved, REF_FILE)                        # (grad_value / grad_loc / grad_aw and grad_value / grad_qproj: ~300 MB of host memory)
+    elif os.path.exists(REF_FILE):
+        ref = torch.load(REF_FILE)
+        for case in ("b0", "fused"):
+            out[case]["vs_default"] = closeness(saved[case], ref[case])    # [grad_value, ...]
     print("RESULT " + json.dumps(out), flush=True)
 
 
@@ -83,7 +111,7 @@ def child_records():
     qproj, ref = fused_problem(4, inp)
     hs = msda.host_shapes(inp["shapes"])
     fwd = lambda: msda.ms_deform_attn_fused_forward(inp["value"], inp["shapes"], inp["starts"], qproj, ref, True)   # noqa: E731
-    out, res = {}, {}
+    out, res, grads = {}, {}, {}
     for name, route, swap, cell in (("product", False, False, False), ("cell_forward", False, False, True),
                                     ("records", True, False, False), ("records_swap", True, True, False)):
         msda.records_route, msda.records_swap, msda.fused_forward_cell = route, swap, cell
@@ -95,9 +123,13 @@ def child_records():
             g = bwd()
             torch.cuda.synchronize()
             res[name] = o.float()
-            out[name] = {"fwd_variant": msda.last_variant["fwd"], "bwd_variant": msda.last_variant["bwd"],
-                         "digest": [digest(t) for t in g], "finite": all(bool(torch.isfinite(t.float()).all()) for t in g),
-                         "fwd_us": round(timed(fwd, iters=20), 1)}
+            if name == "product":
+                grads[name] = [t.clone() for t in g]
+            else:
+                out.setdefault(name, {})["vs_product"] = closeness(g, grads["product"])      # [grad_value, grad_qproj]
+            out.setdefault(name, {}).update({"fwd_variant": msda.last_variant["fwd"], "bwd_variant": msda.last_variant["bwd"],
+                                             "digest": [digest(t) for t in g], "finite": all(bool(torch.isfinite(t.float()).all()) for t in g),
+                                             "fwd_us": round(timed(fwd, iters=20), 1)})
             if name != "cell_forward":
                 out[name]["bwd_us"] = round(timed(bwd, iters=20), 1)
             if records is not None:
@@ -110,6 +142,10 @@ def child_records():
     scale = float(res["product"].abs().max())
     for name in ("cell_forward", "records", "records_swap"):
         out[name]["equal_bits"] = out[name].pop("digest") == base
+        v = out[name]["vs_product"]
+        # grad_value bit-equal (same patch pass, same operands), the projection rows' gradient within a bfloat16 rounding
+        out[name]["accepted"] = bool(out[name]["finite"] and v[0]["equal_bits"] and v[1]["max_diff_rel_to_max"] <= 2.0 ** -7
+                                     and v[1]["differing_share"] <= 0.05)
         out[name]["out_max_diff_rel_to_max"] = float((res[name] - res["product"]).abs().max()) / scale
     print("RESULT " + json.dumps(out), flush=True)
 
@@ -317,13 +353,19 @@ def main(per_child_timeout=45, budget_s=150):
                 base[0] = digests
             for case in ("b0", "fused"):
                 out[case]["equal_bits"] = digests[case] == base[0][case]
+                v = out[case].get("vs_default")
+                if v is not None:        # grad_value bit-equal; float32 gradients to 2e-5, the bfloat16 projection-row gradient to a rounding
+                    lim = 2e-5 if case == "b0" else 2.0 ** -7
+                    out[case]["accepted"] = bool(out[case]["finite"] and v[0]["equal_bits"] and all(r["max_diff_rel_to_max"] <= lim for r in v[1:]))
+                elif k == 0:
+                    out[case]["accepted"] = True
         arms[name] = out
     # order = value of the evidence: the default pair, the records route (kernel level, then -- only if its gradients are the product
     # kernels' bit for bit -- the whole train step with it), the decoders' route, the most complete cell arm, the other kernels
     arm(0)
     rec = report["encoder_records_route"] = child(["--records"])
     report["decoder_cross_attention_sample_then_project"] = child(["--stp"])
-    good = [n for n in ("records", "records_swap") if isinstance(rec.get(n), dict) and rec[n].get("equal_bits") and rec[n].get("finite")]
+    good = [n for n in ("records", "records_swap") if isinstance(rec.get(n), dict) and rec[n].get("accepted")]
     if good and (left() >= 75 or everything):
         best = min(good, key=lambda n: rec[n]["fwd_us"] + rec[n]["bwd_us"])
         flags = ["--set", "msda.records_route=1"] + (["--set", "msda.records_swap=1"] if best == "records_swap" else [])
@@ -336,6 +378,8 @@ def main(per_child_timeout=45, budget_s=150):
     report["swin_routes"] = child(["--swin"])
     for k in range(2, len(ARMS) if everything else 4):
         arm(k)
+    if os.path.exists(REF_FILE):
+        os.remove(REF_FILE)
     report["wall_s"] = round(time.time() - t0, 1)
     return report
 

@@ -3,8 +3,9 @@ numbers decide -- so that the session that finally has a GPU spends its minutes 
 
     python tools/promote_r05.py gpurun_out/r5a/bench_line.json          # or experiments.json
 
-Rules (the ones DESIGN.md section 8 states): an arm of the MSDA backward is promoted only if its gradients are BIT-EQUAL to the
-product kernels' (digests) and it is faster by more than the noise margin (3 %); kernels that replace PyTorch op sequences need
+Rules (the ones DESIGN.md section 8 states): an arm of the MSDA backward is promoted only if its grad_value is BIT-EQUAL to the
+product kernels' and its other gradients agree within a rounding of their type (`accepted`; bit-equal digests imply it) and it is
+faster by more than the noise margin (3 %); kernels that replace PyTorch op sequences need
 agreement within their test tolerance and a speed-up.  Prints one line per candidate: verdict, measured numbers, and the single
 place to edit.  Exit code 0 always (a report, not a gate)."""
 import json
@@ -42,13 +43,15 @@ def decide(rep):
             if "error" in v:
                 out.append(("SKIP", name, v["error"], ""))
                 continue
-            ok = v["fused"].get("equal_bits") and v["b0"].get("equal_bits") and v["fused"].get("finite")
+            # (accepted: grad_value bit-equal + the formula gradients within a rounding, tools/experiments_r05.py; older reports: digests)
+            ok = all(v[c].get("accepted", v[c].get("equal_bits")) for c in ("fused", "b0")) and v["fused"].get("finite")
             us = v["fused"]["us"]
             where = "csrc/msda_patch.hip: kCellMode / kPatchMulti, rebuild, GPU suite"
             if not ok:
                 out.append(("REJECT", name, f"gradients differ from the product kernels' ({us} us)", "delete the arm"))
             elif faster(us, b_us):
-                out.append(("PROMOTE", name, f"{b_us} -> {us} us per fused backward, bit-equal", where))
+                out.append(("PROMOTE", name, f"{b_us} -> {us} us per fused backward, " + ("bit-equal" if v["fused"].get("equal_bits") else
+                            "grad_value bit-equal, the formula gradients within a rounding"), where))
             else:
                 out.append(("KEEP OFF", name, f"{b_us} -> {us} us: not faster", "delete the arm"))
     rec = rep.get("encoder_records_route", {})
@@ -63,7 +66,7 @@ def decide(rep):
             pair_old, pair_new = p["fwd_us"] + p["bwd_us"], v["fwd_us"] + v["bwd_us"]
             detail = (f"forward {p['fwd_us']} -> {v['fwd_us']} us, backward {p['bwd_us']} -> {v['bwd_us']} us, pair {pair_old:.0f} -> "
                       f"{pair_new:.0f} us; far flag {v.get('far_flag')}, {v.get('records_MB')} MB of records")
-            if not (v.get("equal_bits") and v.get("finite")):
+            if not (v.get("accepted", v.get("equal_bits")) and v.get("finite")):
                 out.append(("REJECT", f"records route ({name})", "gradients differ from the product kernels': " + detail,
                             "tests/test_zzz_records_gpu.py names the tensor"))
             elif faster(pair_new, pair_old):

@@ -354,6 +354,7 @@ def test_experiments_child_of_the_route_runs_on_the_model(lib, monkeypatch, caps
     out = json.loads(line[7:])
     assert set(out) == {"product", "cell_forward", "records", "records_swap"}
     assert out["records"]["equal_bits"] and out["records_swap"]["equal_bits"] and out["cell_forward"]["equal_bits"]
+    assert out["records"]["accepted"] and out["records"]["vs_product"][0]["equal_bits"] and out["records"]["vs_product"][1]["differing_share"] == 0.0
     assert out["records"]["fwd_variant"] == "cell+geometry+records" and out["records"]["bwd_variant"] == "records+geometry"
     assert out["product"]["bwd_variant"] == "dest+geometry" and out["records"]["far_flag"] == 0
     assert out["records"]["out_max_diff_rel_to_max"] <= 2.0 ** -6 and "digest" not in json.dumps(out)

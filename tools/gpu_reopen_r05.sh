@@ -4,7 +4,7 @@
 #   1. the GPU suite + smoke on the product library (HEAD has never run on hardware)            -> profiles/r0N_gputest_*.txt
 #   2. one bench line (the driver's metric)                                                     -> bench_line.json
 #   3. A/B of round 4's host-side restructures (tools/r04_host_ab.py)                           -> host_ab.txt
-#   4. A/B of the kernel arms of round 3 (ablation build; bit-equality demanded)                -> experiments.txt
+#   4. every arm of tools/experiments_r05.py (--all: no time budget) + tools/promote_r05.py's reading -> experiments.json, promote.txt
 #   5. cell_forward_kernel: opt-in tests + timing + a bench line with it                        -> pytest_cell_forward.txt, bench_line_fwd_cell.json
 #      and a bench line with the records route (msda.records_route)                             -> bench_line_records.json
 #   6. kernel stats + HBM-traffic counter passes of the kernels that run (tools/gpu_final_r03.sh, separate --pmc passes)
@@ -21,8 +21,6 @@ timeout 900 python bench.py --no-experiments > $OUT/bench_line.json 2> $OUT/benc
 python tools/promote_r05.py $OUT/experiments.json > $OUT/promote.txt 2>&1; cat $OUT/promote.txt
 tail -c 1500 $OUT/bench_line.json
 ( timeout 900 python tools/r04_host_ab.py 20 > $OUT/host_ab.txt 2>&1 ); cat $OUT/host_ab.txt | tail -12
-( export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; timeout 900 python tools/r03_experiments.py > $OUT/experiments.txt 2>&1 )
-cat $OUT/experiments.txt
 ( RLIPV2_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_msda_cell_forward_gpu.py -q -m gpu > $OUT/pytest_cell_forward.txt 2>&1; timeout 300 python tools/cell_forward_check.py >> $OUT/pytest_cell_forward.txt 2>&1 )
 tail -25 $OUT/pytest_cell_forward.txt
 timeout 600 python bench.py --no-cpu-baseline --no-experiments --msda-fwd-cell > $OUT/bench_line_fwd_cell.json 2> $OUT/bench_fwd_cell_stderr.txt

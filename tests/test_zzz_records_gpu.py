@@ -21,14 +21,16 @@ def within_a_rounding(a, b, what):
     """The gradients that go through the float32 formulas of ms_deform_im2col_cuda.cuh:87-159.  On the lane-level model the two
     kernels are bit-equal (same source expressions, same host compiler); on the device the compiler contracts the expressions into
     FMAs per kernel -- even per sample position inside the product kernel (profiles/r05_records_route_static.txt) --, so the bar here
-    is: bit-equal OR within one rounding of the output type on a small share of the elements."""
+    is: bit-equal OR within one rounding of the output type (float32: any number of last-bit differences; bfloat16 rows: a float32
+    last bit only shows where it crosses a bfloat16 rounding boundary, so few elements may differ)."""
     if same_bits(a, b):
         return
     a32, b32 = a.float(), b.float()
     lim = 2.0 ** -7 if a.dtype == torch.bfloat16 else 2e-5
     worst = float((a32 - b32).abs().max() / b32.abs().max().clamp_min(1e-30))
     share = float((a32 != b32).float().mean())
-    assert worst <= lim and share <= 0.05, f"{what}: max difference {worst:.2e} of the maximum, {share:.2%} of the elements differ"
+    assert worst <= lim and (share <= 0.05 or a.dtype != torch.bfloat16), \
+        f"{what}: max difference {worst:.2e} of the maximum, {share:.2%} of the elements differ"
 
 
 def _encoder_call(pyr, N, M, seed, refdim):

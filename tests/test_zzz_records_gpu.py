@@ -171,3 +171,46 @@ def test_records_route_with_far_samples_takes_the_sorting_pass():
     assert torch.isfinite(got[1].float()).all() and torch.isfinite(got[2].float()).all()
     within_a_rounding(got[2], base[2], "grad of the projection rows")
     assert same_bits(got[1], base[1]), "grad_value differs"
+
+
+def test_train_step_with_the_records_route_is_the_same_step():
+    """a small bfloat16 ParSeDA train step (2 x 384 x 480 images, 4 encoder layers) with msda.records_route on against the same
+    step on the product kernels, by the tolerances of the host-route self-check (rlipv2_amd/routes.py): same loss, same gradients
+    within the noise two runs of the plain step show; then the same with the step captured as a HIP graph"""
+    from rlipv2_amd import msda, routes, train
+    from test_zz_round5_gpu import _small_step
+    model, criterion, step, batch = _small_step()
+    try:
+        ref_loss, ref_grads = routes._run(step, criterion, batch, None, 1234)
+        again_loss, again_grads = routes._run(step, criterion, batch, None, 1234)
+        noise = routes.distance(again_grads, ref_grads)
+        seen = []
+        real = msda.ms_deform_attn_fused_backward
+        msda.records_route = True
+        msda.ms_deform_attn_fused_backward = lambda *a: (seen.append(a[8] is not None if len(a) > 8 else False), real(*a))[1]
+        try:
+            loss, grads = routes._run(step, criterion, batch, None, 1234)
+        finally:
+            msda.ms_deform_attn_fused_backward = real
+        assert seen and all(seen[-4:]), "the encoder layers did not take the records route"
+        why = routes.compare(loss, grads, ref_loss, ref_grads, noise)
+        assert why is None, why
+        # captured (the records buffers live in the graph's pool, the control-block memset is a graph node): the gradients the
+        # graphed step delivers with the route on, against the eager product step; dropout must be off for that comparison
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            elif isinstance(getattr(mod, "dropout", None), float):
+                mod.dropout = 0.0
+        msda.records_route = False
+        ref_loss, ref_grads = routes._run(step, criterion, batch, None, 7)
+        noise = routes.distance(routes._run(step, criterion, batch, None, 7)[1], ref_grads)
+        msda.records_route = True
+        graphed = train.graph_step_module(step, model, batch, None, criterion=criterion)
+        _, total = graphed.run(*batch)
+        torch.cuda.synchronize()
+        got = [p.grad.detach().clone() for p in step.parameters() if p.requires_grad]
+        why = routes.compare(float(total.float()), got, ref_loss, ref_grads, noise=noise)
+        assert why is None, why
+    finally:
+        msda.records_route = False

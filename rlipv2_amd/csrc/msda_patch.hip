@@ -914,8 +914,11 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_multi_kernel(
 //     corner j's 4 channels, A rows = the query's grad_out channels -> D[., j] = <grad_out, corner j> after 8
 //     instructions per sample, exact products, float32 accumulation, no unpacking and no cross-lane reduction.
 // ------------------------------------------------------------------------------------------------------------------
-// What the product build runs (the other modes / instantiations are the measured arms of tools/r03_experiments.py; they
-// become the default here, in one place, once a GPU run has shown them bit-identical and faster):
+// What the product build runs (the other modes / instantiations are the arms of tools/experiments_r05.py; they become the
+// default here, in one place, once a GPU run has ACCEPTED them and shown them faster.  Accepted = grad_value bit-identical and the
+// float32-formula gradients within a rounding: "same arithmetic, bit-identical" below holds on the lane-level model; on the device
+// hipcc contracts the formulas into FMAs per kernel -- in this very kernel differently for sample 3 of a level than for samples
+// 0-2 -- see profiles/r05_records_route_static.txt):
 constexpr int kCellMode = 0;                  // cell_backward_kernel<., MODE>
 constexpr int kPatchMulti = 0;                // 1: patch_dest_multi_kernel (ablation build only)
 constexpr int kPatchReps = 1;                 // patches per wave on the fine levels (MULTI only)

@@ -14,7 +14,7 @@ import sys
 def short(name):
     """kernel name of a rocprofv3 row -> key of the traffic table (None: not an MSDA kernel of interest).  REFDIM = 0 is the
     B0-signature instantiation, REFDIM = 2 / 4 carries the module's geometry backward as its epilogue ("+geometry")."""
-    m = re.search(r"(patch_dest_kernel|patch_dest_multi_kernel|cell_backward_kernel<[^>]*>|cell_forward_kernel<[^>]*>|bin2_kernel|"
+    m = re.search(r"(patch_dest_kernel|patch_dest_multi_kernel|cell_backward_kernel<[^>]*>|cell_records_backward_kernel<[^>]*>|cell_forward_kernel<[^>]*>|bin2_kernel|"
                   r"dest_kernel|bin_kernel|combine_kernel|quad_backward_shared_kernel<[^>]*>|quad_forward_fused_kernel|"
                   r"quad_forward_kernel)", name)
     if not m:
@@ -23,8 +23,11 @@ def short(name):
     if k.startswith("cell_backward_kernel"):
         refdim = re.match(r"cell_backward_kernel<\s*(\d+)", k)
         k = "cell_backward_kernel" + ("" if refdim and refdim.group(1) == "0" else "+geometry")
+    elif k.startswith("cell_records_backward_kernel"):
+        refdim = re.match(r"cell_records_backward_kernel<\s*(\d+)", k)
+        k = "cell_records_backward_kernel" + ("" if refdim and refdim.group(1) == "0" else "+geometry")
     elif k.startswith("cell_forward_kernel"):
-        k = "cell_forward_kernel"
+        k = "cell_forward_kernel" + ("+records" if re.search(r", [123]>", k) else "")
     elif k.startswith("quad_backward_shared_kernel"):
         k = "quad_backward_shared_kernel" + ("+geometry" if re.search(r", [24]>", k) else "")
     return k

@@ -17,7 +17,7 @@ cd $GRAFT_REPO_ROOT
 tail -8 $OUT/pytest_gpu.txt
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/smoke.txt ); tail -3 $OUT/smoke.txt
 timeout 900 python bench.py --no-experiments > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
-( timeout 600 python tools/experiments_r05.py --all > $OUT/experiments.json 2> $OUT/experiments_table.txt ); cat $OUT/experiments_table.txt
+( timeout 1000 python tools/experiments_r05.py --all > $OUT/experiments.json 2> $OUT/experiments_table.txt ); cat $OUT/experiments_table.txt
 python tools/promote_r05.py $OUT/experiments.json > $OUT/promote.txt 2>&1; cat $OUT/promote.txt
 tail -c 1500 $OUT/bench_line.json
 ( timeout 900 python tools/r04_host_ab.py 20 > $OUT/host_ab.txt 2>&1 ); cat $OUT/host_ab.txt | tail -12

@@ -87,7 +87,7 @@ class EmuLib:
         return dec(out), dec(g_value), g_loc.astype(np.float64), g_aw.astype(np.float64)
 
 
-FULL = os.environ.get("RLIPV2_TEST_EMU_FULL", "0") == "1"     # the whole matrix takes ~25 minutes (the generic kernels' wave
+FULL = os.environ.get("RLIPV2_TEST_EMU_FULL", "0") == "1"     # the whole matrix takes ~10 minutes (the generic kernels' wave
 #                                                               reductions are thousands of rendezvous per workgroup)
 
 

@@ -41,9 +41,10 @@ fused_forward_cell = False
 # The "records" route of the encoder's fused call (csrc/msda_cell_forward.inc EMIT, csrc/msda_cell_records.inc): the forward pass
 # leaves per-sample records, window tables and the patch pass's masks; the backward pass runs no sample geometry and no binning.
 # Bit-identical to the product kernels on the lane-level model (tests/test_records_emulated.py); NEVER run on hardware: a plain
-# attribute that only tools / bench.py's experiments set.  records_swap: the other operand order of the 4x4x4 products.
+# attribute that only tools / bench.py's experiments set.  records_swap: the operand order of the 4x4x4 products in which every lane
+# receives all four dots (16 DPP moves per level and group less; same products, same sums); False: cell_backward_kernel's order.
 records_route = False
-records_swap = False
+records_swap = True
 _records_out = [None]      # the records tensor of the last ms_deform_attn_fused_forward call under records_route (take_records)
 
 

@@ -184,7 +184,7 @@ def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_pa
     monkeypatch.setattr(X, "ABLATION_LIB", os.path.join(ROOT, "bench.py"))
     rep = X.main()
     # (the records route was bit-equal in the fake child: the whole step is measured with it, in a child of its own)
-    assert steps == [["--set", "msda.records_route=1"]] and rep["train_step_with_records_route"]["roofline_frac"] == 0.14
+    assert steps == [["--set", "msda.records_route=1", "--set", "msda.records_swap=0"]] and rep["train_step_with_records_route"]["roofline_frac"] == 0.14
     arms = rep["encoder_backward_arms"]
     names = [n for n, _ in X.ARMS]
     assert arms[names[0]]["b0"]["equal_bits"] and arms[names[1]]["fused"]["equal_bits"]

@@ -74,7 +74,7 @@ def test_records_route_matches_the_product_kernels_bit_for_bit(pyr, N, M, refdim
             torch.cuda.synchronize()
             return out.detach(), value.grad, qproj.grad, fwd, msda.last_variant["bwd"]
         finally:
-            msda.records_route = msda.records_swap = False
+            msda.records_route, msda.records_swap = False, True
     base = run(False, False)
     assert base[4] == "dest+geometry"
     for swap in (False, True):

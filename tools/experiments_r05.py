@@ -137,7 +137,7 @@ def child_records():
                 out[name]["far_flag"] = int(records[:256].view(torch.int32)[60])
             del o, loc, aw, records, g
         finally:
-            msda.records_route = msda.records_swap = msda.fused_forward_cell = False
+            msda.records_route, msda.records_swap, msda.fused_forward_cell = False, True, False
     base = out["product"].pop("digest")
     scale = float(res["product"].abs().max())
     for name in ("cell_forward", "records", "records_swap"):
@@ -368,7 +368,7 @@ def main(per_child_timeout=45, budget_s=150):
     good = [n for n in ("records", "records_swap") if isinstance(rec.get(n), dict) and rec[n].get("accepted")]
     if good and (left() >= 75 or everything):
         best = min(good, key=lambda n: rec[n]["fwd_us"] + rec[n]["bwd_us"])
-        flags = ["--set", "msda.records_route=1"] + (["--set", "msda.records_swap=1"] if best == "records_swap" else [])
+        flags = ["--set", "msda.records_route=1", "--set", "msda.records_swap=" + ("1" if best == "records_swap" else "0")]
         report["train_step_with_records_route"] = run_step_child(flags, base_env, int(min(120, left())))
     elif good:
         report["train_step_with_records_route"] = {"error": "not started: time budget used up"}

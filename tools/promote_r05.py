@@ -71,7 +71,7 @@ def decide(rep):
                             "tests/test_zzz_records_gpu.py names the tensor"))
             elif faster(pair_new, pair_old):
                 out.append(("PROMOTE", f"records route ({name})", detail,
-                            "rlipv2_amd/msda.py: records_route = True" + (", records_swap = True" if name == "records_swap" else "")
+                            "rlipv2_amd/msda.py: records_route = True, records_swap = " + str(name == "records_swap")
                             + "; then bench.py --set msda.records_route=1 for the step, GPU suite"))
             else:
                 out.append(("KEEP OFF", f"records route ({name})", detail, ""))

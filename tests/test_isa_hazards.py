@@ -74,7 +74,8 @@ def test_loop_carried_read_is_seen_through_the_back_edge():
 
 
 # every kernel file with hand-written LDS reads or waits, and the big LDS users; ":ablation" = with the experiment arms
-FILES = ["token_gemm", "expand_gemm", "msda_patch", "msda_patch:ablation", "msda_window", "alif_attention", "msda_quad", "msda_dest"]
+FILES = ["token_gemm", "expand_gemm", "msda_patch", "msda_patch:ablation", "msda_window", "alif_attention", "msda_quad", "msda_dest",
+         "window_attention", "msda_rows", "msda_sparse"]        # (round 5 / the decoders' pass: compiler-scheduled LDS reads only)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")

@@ -232,3 +232,16 @@ def test_promotion_report_reads_an_experiments_object(tmp_path, capsys):
     sys.argv = ["promote_r05.py", str(path)]
     P.main()
     assert "PROMOTE   records route (records)" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("script", ["gpu_first_r05.sh", "gpu_reopen_r05.sh", "gpu_final_r03.sh", "gpu_ab.sh"])
+def test_gpu_session_scripts_parse_and_name_existing_files(script):
+    """the scripts of the next GPU session cannot be run here; at least they must parse and every repository file they name
+    (tools/*.py, tests/*.py, bench.py) must exist"""
+    import re
+    import subprocess
+    path = os.path.join(ROOT, "tools", script)
+    assert subprocess.run(["bash", "-n", path], capture_output=True).returncode == 0
+    text = open(path).read()
+    for rel in set(re.findall(r"\b((?:tools|tests)/[\w/]+\.(?:py|sh))\b", text)) | ({"bench.py"} if "bench.py" in text else set()):
+        assert os.path.exists(os.path.join(ROOT, rel)), f"{script} names {rel}, which does not exist"

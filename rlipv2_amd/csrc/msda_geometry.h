@@ -105,10 +105,27 @@ __device__ __forceinline__ void forward(const QT *__restrict__ row, const float 
     }
 }
 
+// bfloat16 rows through the hardware's packed conversion (v_cvt_pk_bf16_f32: round to nearest even, the same bits as
+// float_to_bf16_bits for every finite value at a fifth of the instructions).  Only the kernels written after round 3 ask for
+// it (HW_CVT): the device code of the hardware-validated ones stays what it was.
+template <int NV> __device__ __forceinline__ void store_n_hw(bf16_t *p, const float (&v)[NV])
+{
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    uint32_t w[NV / 2];
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+        const f32x2_ f = {v[2 * i], v[2 * i + 1]};
+        w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_));
+    }
+    if (NV == 4) *reinterpret_cast<uint2 *>(p) = make_uint2(w[0], w[1]);
+    else *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[NV == 8 ? 2 : 0], w[NV == 8 ? 3 : 1]);
+}
+
 // Backward, quad lane l of (row, head m): a = the level's attention weights, ga = their gradients (overwritten by
 // the gradients of the logits), gl = gradients of the locations; writes the level's 8 + 4 entries of the
 // projection row's gradient.  Returns the location scale in (sx, sy) for the reference-point gradient.
-template <typename QT, int REFDIM>
+template <typename QT, int REFDIM, bool HW_CVT = false>
 __device__ __forceinline__ void backward(QT *__restrict__ grow, const float *__restrict__ ref_row,
                                          const int64_t *__restrict__ shapes, int m, int M, int l, const float (&a)[4],
                                          float (&ga)[4], const float (&gl)[8])
@@ -120,7 +137,8 @@ __device__ __forceinline__ void backward(QT *__restrict__ grow, const float *__r
     dot = quad_sum(dot);
 #pragma unroll
     for (int i = 0; i < 4; ++i) ga[i] = a[i] * (ga[i] - dot);
-    store_n<QT, 4>(grow + M * 32 + m * 16 + l * 4, ga);
+    if constexpr (HW_CVT) store_n_hw<4>(grow + M * 32 + m * 16 + l * 4, ga);
+    else store_n<QT, 4>(grow + M * 32 + m * 16 + l * 4, ga);
     // offsets: g_off = g_loc * scale
     float o[8], sx, sy;
     level_scale<REFDIM>(ref_row, shapes, l, sx, sy);
@@ -129,7 +147,8 @@ __device__ __forceinline__ void backward(QT *__restrict__ grow, const float *__r
         o[2 * pnt] = gl[2 * pnt] * sx;
         o[2 * pnt + 1] = gl[2 * pnt + 1] * sy;
     }
-    store_n<QT, 8>(grow + m * 32 + l * 8, o);
+    if constexpr (HW_CVT) store_n_hw<8>(grow + m * 32 + l * 8, o);
+    else store_n<QT, 8>(grow + m * 32 + l * 8, o);
 }
 
 }  // namespace geom

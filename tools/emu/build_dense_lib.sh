@@ -12,6 +12,8 @@ FLAGS="-x c++ -std=c++20 -O1 -fPIC -pthread -DMSDA_EMU -I$HERE/stub -I$ROOT/incl
 # EMU_SANITIZE=1: AddressSanitizer + UndefinedBehaviorSanitizer build (global-memory accesses of the kernels against the
 # host allocator's red zones; run python with LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so))
 if [ "${EMU_SANITIZE:-0}" = "1" ]; then FLAGS="$FLAGS -g -fno-omit-frame-pointer -fsanitize=address,undefined -shared-libasan"; SAN="-fsanitize=address,undefined -shared-libasan"; fi
+# EMU_TSAN=1: ThreadSanitizer build (see build_lib.sh)
+if [ "${EMU_TSAN:-0}" = "1" ]; then FLAGS="$FLAGS -g -fno-omit-frame-pointer -fsanitize=thread -shared-libsan"; SAN="-fsanitize=thread -shared-libsan"; fi
 pids=()
 for f in fused_adamw add_layernorm layernorm_wide elementwise groupnorm_tokens decoder_glue alif_attention window_attention token_gemm expand_gemm; do
     $CXX $FLAGS -c $ROOT/rlipv2_amd/csrc/$f.hip -o $TMP/$f.o &

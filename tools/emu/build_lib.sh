@@ -13,6 +13,10 @@ FLAGS="-x c++ -std=c++20 -O1 -fPIC -pthread -DMSDA_EMU -I$HERE/stub -I$ROOT/incl
 # EMU_SANITIZE=1: AddressSanitizer + UndefinedBehaviorSanitizer build (global-memory accesses of the kernels against the
 # host allocator's red zones; run python with LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so))
 if [ "${EMU_SANITIZE:-0}" = "1" ]; then FLAGS="$FLAGS -g -fno-omit-frame-pointer -fsanitize=address,undefined -shared-libasan"; SAN="-fsanitize=address,undefined -shared-libasan"; fi
+# EMU_TSAN=1: ThreadSanitizer build -- every LDS / global access of the lane threads is checked for a happens-before edge (the
+# rendezvous and barriers of the model are what provides one): a missing barrier or wave-level ordering in a kernel shows as a
+# data race even when the test's result happens to come out right (run python with LD_PRELOAD of libclang_rt.tsan-x86_64.so)
+if [ "${EMU_TSAN:-0}" = "1" ]; then FLAGS="$FLAGS -g -fno-omit-frame-pointer -fsanitize=thread -shared-libsan"; SAN="-fsanitize=thread -shared-libsan"; fi
 pids=()
 for f in msda_api msda_generic msda_quad msda_dest msda_patch msda_sparse msda_rows msda_prep msda_window; do
     $CXX $FLAGS -c $ROOT/rlipv2_amd/csrc/$f.hip -o $TMP/$f.o &

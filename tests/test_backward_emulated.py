@@ -33,7 +33,9 @@ def emulator(tmp_path_factory):
     d = tmp_path_factory.mktemp("emu_bwd")
     exe = str(d / "backward_emu")
     emu = os.path.join(ROOT, "tools", "emu")
-    subprocess.run([CLANG, "-x", "c++", "-std=c++20", "-O1", "-pthread", "-I" + os.path.join(emu, "stub"),
+    # EMU_TSAN=1: ThreadSanitizer build (a lane pair that no rendezvous / barrier orders = a data race; tools/emu/README.md)
+    san = ["-g", "-fsanitize=thread"] if os.environ.get("EMU_TSAN") == "1" else []
+    subprocess.run([CLANG, "-x", "c++", "-std=c++20", "-O1", "-pthread", *san, "-I" + os.path.join(emu, "stub"),
                     "-I" + os.path.join(ROOT, "include"), "-Wno-unknown-pragmas", os.path.join(emu, "backward_emu.cpp"),
                     "-o", exe], check=True, capture_output=True, timeout=600)
     pyr, starts, S, value, loc, aw = make_problem(PYR, M, (1.5, 1.5, 1.0, 0.7), seed=11)

@@ -106,6 +106,14 @@ def test_op_signature_bit_equal_to_the_product_route(lib, name, pyr, M, spread):
         assert np.array_equal(gl.view(np.uint32), gl_ref.view(np.uint32)), f"grad_sampling_loc differs (flags {flags:#x}, far {far})"
         assert np.array_equal(ga.view(np.uint32), ga_ref.view(np.uint32)), f"grad_attn_weight differs (flags {flags:#x})"
         assert np.array_equal(gv, gv_ref), f"grad_value differs (flags {flags:#x}, far {far})"
+    if "every level" in name:
+        # run-to-run: the same bits again (no atomics, one writer per element, fixed summation order) -- under a different
+        # interleaving of the 512 lane threads
+        gv2, gl2, ga2 = np.zeros_like(gv_ref), np.full_like(gl_ref, np.nan), np.full_like(ga_ref, np.nan)
+        ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+        assert lib.msda_records_backward(flags, BF16, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), None, 0, p(gob), *dims, p(gv2),
+                                         p(gl2), p(ga2), None, p(records), rec_bytes, p(ws), ws_bytes, None) == 0
+        assert np.array_equal(gv2, gv) and np.array_equal(gl2.view(np.uint32), gl.view(np.uint32)) and np.array_equal(ga2.view(np.uint32), ga.view(np.uint32))
 
 
 @pytest.mark.parametrize("refdim", [2, 4] if FULL else [2])

@@ -222,3 +222,44 @@ def test_round2_entry_points_validate_their_arguments_on_the_host():
     # matcher: argument errors are -2
     sizes = (ctypes.c_int * 1)(3)
     assert L.hoi_assign_batch(None, 1, 1, 4, sizes, None, None, 3) == -2
+
+
+def test_records_entry_points_validate_their_arguments_on_the_host():
+    """msda_records_bytes / msda_records_forward / msda_records_backward (round 5): which calls the route takes, and that every
+    argument error is reported before anything touches a device (real library, no GPU here)"""
+    import ctypes
+    import numpy as np
+    from rlipv2_amd import _lib
+    L = _lib.lib()
+    pyr = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in pyr)
+    hs = (ctypes.c_int64 * 8)(*[v for hw in pyr for v in hw])
+    dims = (4, S, 8, 32, 4, S, 4)
+    need = L.msda_records_bytes(_lib.MSDA_BF16, hs, *dims)
+    cells, items = 7 * 11, 4 * 8 * 7 * 11
+    assert need > 256 + items * 128 + items * 340 * 256 and need % 16 == 0            # control block + window tables + sample records + masks + group records
+    assert cells * 340 >= S                                                             # (every query has a slot in its cell)
+    assert L.msda_records_bytes(_lib.MSDA_F32, hs, *dims) == 0                          # bfloat16 only
+    assert L.msda_records_bytes(_lib.MSDA_BF16, hs, 4, S, 8, 32, 4, 300, 4) == 0        # encoder calls only (Lq == S)
+    assert L.msda_records_bytes(_lib.MSDA_BF16, None, *dims) == 0                       # needs the host copy of the shapes
+    ws = L.msda_backward_workspace_bytes(_lib.MSDA_BF16, hs, *dims)
+    assert ws >= 4 * S * 8 * 16 * 12                                                    # room for rebuilt locations / weights (far fallback)
+    a = np.zeros(64, dtype=np.uint8).ctypes.data                                        # any aligned non-null address: nothing is dereferenced
+    ok_ptrs = dict(value=a, shapes=a, starts=a, out=a, records=a)
+    fwd = lambda **kw: L.msda_records_forward(kw.get("dtype", _lib.MSDA_BF16), kw.get("value", a), a, a, hs, kw.get("qproj"), kw.get("ref"),   # noqa: E731
+                                              kw.get("refdim", 0), kw.get("loc", a), kw.get("aw", a), *dims, kw.get("out", a),
+                                              kw.get("records", a), kw.get("nbytes", need), None)
+    assert fwd(refdim=3) != 0 and fwd(dtype=_lib.MSDA_F32) != 0                          # unsupported reference dimension / dtype
+    assert fwd(out=None) != 0 and fwd(records=None) != 0 and fwd(loc=None) != 0          # op signature needs its locations
+    assert fwd(refdim=2, qproj=None, ref=a) != 0 and fwd(refdim=2, qproj=a, ref=a, loc=a, aw=None) != 0   # both or neither
+    assert fwd(nbytes=need - 1) != 0                                                      # records buffer too small
+    assert fwd(value=a + 4) != 0                                                          # misaligned
+    bwd = lambda **kw: L.msda_records_backward(kw.get("flags", _lib.FLAG_GRAD_VALUE_BF16), _lib.MSDA_BF16, a, a, a, hs, kw.get("loc", a),   # noqa: E731
+                                               kw.get("aw", a), kw.get("ref"), kw.get("refdim", 0), a, *dims, kw.get("gv", a), kw.get("gl", a),
+                                               kw.get("ga", a), kw.get("gq"), kw.get("records", a), kw.get("nbytes", need), kw.get("ws", a),
+                                               kw.get("wsb", ws), None)
+    assert bwd(gv=None) != 0 and bwd(records=None) != 0 and bwd(ws=None) != 0 and bwd(gl=None) != 0
+    assert bwd(refdim=2, ref=a, gq=None) != 0 and bwd(refdim=2, ref=None, gq=a) != 0     # module operands need ref and grad_qproj
+    assert bwd(loc=None) != 0                                                              # op signature needs its locations
+    assert bwd(nbytes=need - 1) != 0 and bwd(wsb=ws - 1) != 0 and bwd(refdim=1) != 0
+    del ok_ptrs

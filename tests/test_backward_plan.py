@@ -128,3 +128,33 @@ def test_closed_form_of_the_patch_ranges_equals_the_enumeration():
                         assert (ts == [] and lo > hi) or (ts and (lo, hi) == (ts[0], ts[-1]) and ts == list(range(lo, hi + 1)))
                         n += 1
     assert n > 100000
+
+
+@pytest.mark.parametrize("shapes", PYRAMIDS)
+@pytest.mark.parametrize("N,M", [(4, 8), (1, 1), (8, 8)])
+def test_records_buffer_layout_follows_the_plan(shapes, N, M):
+    """msda_records_bytes (the saved state of the records route, include/rlipv2_msda.h) = control block + one window table per
+    (image, head, cell) + 340 x 16 sample records of 16 bytes per cell + the patch pass's masks and group records, as the plan
+    sizes them; every query has a slot; the sorting fallback's rebuilt locations / weights fit the workspace the ABI asks for"""
+    L = _lib.lib()
+    n, p = plan(shapes, N=N, M=M)
+    hs = np.asarray(shapes, dtype=np.int64).reshape(-1)
+    S = int(sum(h * w for h, w in shapes))
+    dims = (N, S, M, 32, 4, S, 4)
+    L.msda_records_bytes.restype = ctypes.c_size_t
+    got = int(L.msda_records_bytes(_lib.MSDA_BF16, hs.ctypes.data, *dims))
+    if n <= 0:
+        assert got == 0
+        return
+    lv, tail = p
+    cells = tail["CY"] * tail["CX"]
+    items = N * M * cells
+    masks = N * M * tail["slots"] * 48
+    group_records = N * M * 4 * cells * 340 * 48
+    if tail["bin_lds"] > 60 * 1024:                                   # (the forward keeps the cell's mask table in its window region)
+        assert got == 0
+        return
+    assert got == 256 + items * 128 + items * 340 * 256 + masks + group_records
+    assert cells * 340 >= S and sum(min(16 >> l, 16) ** 2 for l in range(4)) == 340
+    ws = int(L.msda_backward_workspace_bytes(_lib.MSDA_BF16, hs.ctypes.data, *dims))
+    assert ws >= N * S * M * 16 * 12

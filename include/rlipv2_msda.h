@@ -221,8 +221,10 @@ int msda_fused_backward_ws(int flags, int dtype,
  * record per sample (window offset of its top-left corner, the two bilinear fractions, the attention weight), the LDS window
  * table of every (image, head, cell) and the patch masks + group records of the grad_value pass.  The backward pass then runs
  * no sample geometry and no binning: gradients of the locations / weights (reference ms_deform_im2col_cuda.cuh:87-159) from the
- * records on v_mfma_f32_4x4x4_16B_bf16, grad_value from the matrix-core patch pass; results are bit-identical to
- * msda_backward_ws / msda_fused_backward_ws on the same call.
+ * records on v_mfma_f32_4x4x4_16B_bf16, grad_value from the matrix-core patch pass.  Against msda_backward_ws /
+ * msda_fused_backward_ws on the same call: grad_value bit-identical (the same patch pass on the same masks and group records);
+ * the other gradients bit-identical on the lane-level model of tools/emu/ and, on the device, within a rounding of their type
+ * (the compiler contracts the reference's float32 formulas into FMAs per kernel: profiles/r05_records_route_static.txt).
  *   refdim 0: the op's signature -- sampling_loc / attn_weight are INPUTS of both calls (qproj, ref, grad_qproj NULL);
  *   refdim 2 / 4: the module's operands (msda_fused_forward) -- sampling_loc / attn_weight are OUTPUTS of the forward and
  *                 inputs of the backward, or both NULL in both calls: the records then are the whole saved state (the group

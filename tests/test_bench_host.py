@@ -234,7 +234,7 @@ def test_promotion_report_reads_an_experiments_object(tmp_path, capsys):
     assert "PROMOTE   records route (records)" in capsys.readouterr().out
 
 
-@pytest.mark.parametrize("script", ["gpu_first_r05.sh", "gpu_reopen_r05.sh", "gpu_final_r03.sh", "gpu_ab.sh"])
+@pytest.mark.parametrize("script", ["gpu_first_r05.sh", "gpu_quick_r05.sh", "gpu_reopen_r05.sh", "gpu_final_r03.sh", "gpu_ab.sh"])
 def test_gpu_session_scripts_parse_and_name_existing_files(script):
     """the scripts of the next GPU session cannot be run here; at least they must parse and every repository file they name
     (tools/*.py, tests/*.py, bench.py) must exist"""

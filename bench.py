@@ -328,24 +328,13 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         # searches (find_unused_parameters=True in the reference, main.py:517)
         train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
         frozen = True
-    # GPU-only host routes (rlipv2_amd/routes.py) are off in the package; the step's own self-check switches on the ones that
-    # reproduce the plain step's loss and gradients on THIS model and batch (all ranks agree on the verdict)
+    # GPU-only host routes (rlipv2_amd/routes.py) are off in the package.  `--host-routes auto`: main() ran the self-check in a CHILD
+    # process before this process touched the GPU (routes_verdicts_from_child); here the verdicts are only applied -- this process
+    # never executes a route that has not just reproduced the plain step's loss and gradients on the same model and batch.  A child
+    # that crashed, hung or printed nothing leaves every route off.  Data-parallel runs agree with one MIN all-reduce.
     from rlipv2_amd import routes
     if args.host_routes == "auto":
-        if args.graph and dtype is None and not frozen:
-            train.freeze_parameters_without_gradient(step_module, criterion, batch)
-            frozen = True
-        try:
-            host_routes = routes.validate(step_module, criterion, batch, autocast_dtype=dtype,
-                                          log=lambda m: print(m, file=sys.stderr))
-        except Exception as e:                                  # noqa: BLE001 -- the plain step is always available
-            if world > 1:
-                raise                                           # (ranks must not disagree on the graph they run)
-            routes.set_all(False)
-            print(f"[bench] host-route self-check raised, all routes off: {type(e).__name__}: {e}", file=sys.stderr)
-            host_routes = {k: f"off (self-check raised {type(e).__name__})" for k in routes.GPU_ONLY_ROUTES}
-            for p_ in step_module.parameters():
-                p_.grad = None
+        host_routes = apply_route_verdicts(getattr(args, "route_verdicts", None), world, device)
     else:
         routes.set_all(args.host_routes == "on")
         host_routes = {k: ("on (forced, no self-check)" if v else "off (forced)") for k, v in routes.state().items()}
@@ -496,7 +485,7 @@ def traffic_from_table(t, kernel_key):
 
 
 def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls, probe_steps=None, probe_note=None,
-         step_roofline=None, b0=None, host_routes=None, experiments=None):
+         step_roofline=None, b0=None, host_routes=None):
     probe_steps = args.steps if probe_steps is None else probe_steps
     dominant = max(kern, key=lambda n: kern[n]["ms"])
     kd = kern[dominant]
@@ -581,17 +570,10 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
         }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cpu_calls(), "msda_step" if "msda_step" in workload_text[:12] else "train_step")
-    # (LAST, after everything of this process that touches the GPU: the arms run in child processes, and one that has never run
-    #  on hardware may leave the device recovering when it is killed)
-    if callable(experiments):
-        # insurance: the line as it stands goes to stderr before up to 150 s of child processes -- if anything outside this
-        # process ends the run meanwhile, the measured numbers are in the captured output (stdout still gets exactly ONE line)
-        print("[bench] line before the experiments leg: " + json.dumps(line), file=sys.stderr, flush=True)
-        experiments = experiments()
-    if experiments is not None:
-        line["experiments"] = experiments
-        emit.child_timed_out = "timed out" in json.dumps(experiments)
+    # The ONE stdout line the driver parses, as soon as the measurement exists.  Nothing that could lose it runs before it: the
+    # experiments leg (opt-in, `--experiments`) starts only after this line has left the process (experiments_leg below).
     print(json.dumps(line), flush=True)
+    return line
 
 
 def miopen_tuning_report():
@@ -614,20 +596,180 @@ def under_profiler():
                                                                            "ROCPROFILER_REGISTER_LIBRARY"))
 
 
-def run_experiments(args, world):
-    """After the timed region (nothing of this run is measured any more): the A/B table of the kernel arms that have never been
-    timed on hardware, every arm in a child process with a timeout (tools/experiments_r05.py).  Evidence for the next decision,
-    reported under `experiments`; the product path of this run is not touched.  Single-GPU default configuration only."""
-    if (not args.experiments or args.no_cpu_baseline or world != 1 or args.backbone != "resnet50" or args.dtype != "bf16"
-            or args.batch != 4 or args.overrides or args.padded or args.var_targets or under_profiler()):
-        return None                     # (only the full default evidence run; never under rocprofv3: its preload follows children)
+EXPERIMENTS_BUDGET_S = 150          # tools/experiments_r05.py starts no child after this many seconds ...
+EXPERIMENTS_GRACE_S = 60            # ... and the whole leg (a process group of its own) is killed this long after that
+
+
+def experiments_applicable(args, world):
+    """the leg is opt-in (`--experiments`) and only meaningful next to the full default evidence run: 1 GPU, R50, bf16, batch 4,
+    no overrides / variants; never under rocprofv3 (its preload follows children)"""
+    return bool(args.experiments and not args.no_cpu_baseline and world == 1 and args.backbone == "resnet50" and args.dtype == "bf16"
+                and args.batch == 4 and not args.overrides and not args.padded and not args.var_targets and not under_profiler())
+
+
+def experiments_leg(args, world, out_path=None, cmd=None, budget_s=None):
+    """AFTER the stdout line (nothing of this run is measured any more, nothing printed here is parsed by the driver): the A/B
+    table of the kernel arms that have never been timed on hardware -- tools/experiments_r05.py as a child PROCESS GROUP (every arm
+    a grandchild with its own timeout), killed as a group when it overruns.  The object goes to stderr as one `EXPERIMENTS {json}`
+    line and to gpurun_out/experiments_last.json; tools/promote_r05.py reads either.  Never raises."""
+    import signal
+    import subprocess
+    if not experiments_applicable(args, world):
+        return None
+    budget_s = (EXPERIMENTS_BUDGET_S + EXPERIMENTS_GRACE_S) if budget_s is None else budget_s
+    cmd = cmd or [sys.executable, os.path.join(ROOT, "tools", "experiments_r05.py")]
+    out_path = out_path or os.path.join(ROOT, "gpurun_out", "experiments_last.json")
     try:
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()                                  # the children allocate on the same device
-        from tools import experiments_r05
-        return experiments_r05.main()
-    except Exception as e:                                         # noqa: BLE001 -- evidence only, never fatal
-        return {"error": f"{type(e).__name__}: {e}"}
+        if torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()                              # the grandchildren allocate on the same device
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT,
+                                start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=budget_s)
+            rep = None
+            for ln in reversed(out.splitlines()):
+                if ln.startswith("{"):
+                    rep = json.loads(ln)
+                    break
+            if rep is None:
+                rep = {"error": f"rc {proc.returncode}: no JSON object on the leg's stdout"}
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)               # the leg and every arm it started
+            except ProcessLookupError:
+                pass
+            proc.communicate()
+            rep = {"error": f"timed out after {budget_s} s (process group killed)"}
+    except Exception as e:                                        # noqa: BLE001 -- evidence only, never fatal
+        rep = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        print("EXPERIMENTS " + json.dumps(rep), file=sys.stderr, flush=True)
+        os.makedirs(os.path.dirname(out_path), exist_ok=True)
+        with open(out_path, "w") as f:
+            json.dump(rep, f)
+    except Exception as e:                                        # noqa: BLE001
+        print(f"[bench] could not record the experiments object: {type(e).__name__}: {e}", file=sys.stderr)
+    return rep
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# host-route self-check in a child process (rlipv2_amd/routes.py; VERDICT round 5, "next round" item 1)
+
+ROUTES_CHILD_TIMEOUT_S = 300
+_DIST_ENV = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
+             "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+             "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE", "RLIPV2_FORCE_DP")
+
+
+def applicable_routes(backbone):
+    """the Swin routes cannot apply to a ResNet-50 step: not exercised there (two eager steps saved), reported as such"""
+    from rlipv2_amd import routes
+    swin_only = ("fused_wide_layer_norm", "fused_window_attention")
+    return [n for n in routes.GPU_ONLY_ROUTES if backbone.startswith("swin") or n not in swin_only]
+
+
+def routes_child_main(args):
+    """`bench.py --routes-child`: build the very model and batch the timed run will use (same seeds: rank 0's weights -- what every
+    rank holds after the broadcast --, this rank's images), run routes.validate on the applicable routes and print one
+    `ROUTES {json}` line.  A single process on one device: no process group, no optimiser, nothing timed."""
+    from rlipv2_amd import parseda, routes, train
+    rank = args.routes_child_rank
+    torch.cuda.set_device(args.routes_child_device)
+    device = f"cuda:{args.routes_child_device}"
+    margs = parseda.default_args(num_queries=args.queries)
+    if os.environ.get("RLIPV2_MIOPEN_FIND", "0") == "1":
+        torch.backends.cudnn.benchmark = True
+    torch.manual_seed(0)
+    model, criterion = train.build_training(margs, device=device, with_text_encoder=True, backbone_name=args.backbone)
+    master = args.dtype == "bf16" and args.precision == "master"
+    if master:
+        train.to_bf16(model)
+    sizes = [(800, 1333), (736, 1100)] if args.padded else None
+    batch = train.synthetic_batch(args.batch, 800, 1333, n_obj=43, n_verb=21, triplets=8, device=device, seed=rank, sizes=sizes)
+    if master:
+        batch[0].tensors = batch[0].tensors.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    step_module = train.ParSeDATrainStep(model)
+    model.train()
+    dtype = torch.bfloat16 if (args.dtype == "bf16" and not master) else None
+    train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
+    verdict = routes.validate(step_module, criterion, batch, autocast_dtype=dtype, names=applicable_routes(args.backbone),
+                              log=lambda m: print(m, file=sys.stderr))
+    torch.cuda.synchronize()
+    print("ROUTES " + json.dumps(verdict), flush=True)
+
+
+def routes_verdicts_from_child(argv, backbone, rank=0, device_index=0, timeout=ROUTES_CHILD_TIMEOUT_S, cmd=None):
+    """Parent side, called BEFORE this process initialises the GPU: start `bench.py --routes-child` with the same arguments, wait at
+    most `timeout` s, read its `ROUTES {json}` line.  -> {route: "on" | "off (...)"} for every route of routes.GPU_ONLY_ROUTES.
+    A child that dies on a signal (a GPU memory fault is SIGSEGV / SIGABRT, not a Python exception), hangs, or prints no verdict
+    leaves every route off; so does a verdict that names an unknown route or says anything but "on" / "off (...)"."""
+    import signal
+    import subprocess
+    from rlipv2_amd import routes
+    names = list(routes.GPU_ONLY_ROUTES)
+    todo = applicable_routes(backbone)
+    result = {n: "off (not applicable: no such block in a %s step)" % backbone for n in names if n not in todo}
+
+    def all_off(why):
+        result.update({n: f"off (self-check child: {why})" for n in todo})
+        return result
+    cmd = cmd or [sys.executable, os.path.abspath(__file__), *argv, "--routes-child", "--routes-child-rank", str(rank),
+                  "--routes-child-device", str(device_index)]
+    env = {k: v for k, v in os.environ.items() if k not in _DIST_ENV}
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    except OSError as e:
+        return all_off(f"not started, {type(e).__name__}: {e}")
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.communicate()
+        return all_off(f"timed out after {timeout} s, killed")
+    for ln in (err or "").splitlines():
+        if ln.startswith("[routes]"):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        how = f"signal {signal.Signals(-proc.returncode).name}" if proc.returncode < 0 else f"exit code {proc.returncode}"
+        return all_off(f"{how}; {(err or '').strip().splitlines()[-1][:160] if (err or '').strip() else 'no message'}")
+    verdict = None
+    for ln in reversed(out.splitlines()):
+        if ln.startswith("ROUTES "):
+            try:
+                verdict = json.loads(ln[7:])
+            except ValueError:
+                verdict = None
+            break
+    if not isinstance(verdict, dict) or set(verdict) != set(todo) or not all(
+            isinstance(v, str) and (v == "on" or v.startswith("off (")) for v in verdict.values()):
+        return all_off("no well-formed verdict on its stdout")
+    result.update(verdict)
+    return {n: result[n] for n in names}
+
+
+def apply_route_verdicts(verdicts, world, device):
+    """switch on exactly the routes whose verdict is "on" -- on every rank (MIN all-reduce), or on none"""
+    from rlipv2_amd import routes
+    names = list(routes.GPU_ONLY_ROUTES)
+    if verdicts is None:
+        verdicts = {n: "off (no self-check was run)" for n in names}
+    ok = [1 if verdicts.get(n) == "on" else 0 for n in names]
+    if world > 1 and dist.is_initialized():
+        t = torch.tensor(ok, dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        agreed = t.tolist()
+    else:
+        agreed = ok
+    out = {}
+    for n, mine, both in zip(names, ok, agreed):
+        routes.set_route(n, bool(both))
+        out[n] = verdicts.get(n, "off (no verdict)") if (both or not mine) else "off (self-check failed on another rank)"
+    return out
 
 
 def apply_overrides(overrides):
@@ -686,15 +828,22 @@ def main():
     ap.add_argument("--precision", default="master", choices=["master", "autocast"],
                     help="bf16 policy: bf16 parameters + float32 master weights (default) or torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-experiments", dest="experiments", action="store_false",
-                    help="skip the A/B table of the unmeasured kernel arms that a default 1-GPU run appends after its timed region "
-                         "(tools/experiments_r05.py, at most 150 s, child processes)")
+    ap.add_argument("--experiments", action="store_true",
+                    help="AFTER the JSON line has been printed: the A/B table of the kernel arms that have never been timed on "
+                         "hardware (tools/experiments_r05.py in a process group of its own, at most ~3.5 min) -> one `EXPERIMENTS "
+                         "{json}` line on stderr + gpurun_out/experiments_last.json.  Off by default: the metric run touches product "
+                         "kernels only")
+    ap.add_argument("--no-experiments", dest="experiments", action="store_false", help="(the default; kept for older scripts)")
+    ap.add_argument("--routes-child", action="store_true", help=argparse.SUPPRESS)     # internal: the host-route self-check process
+    ap.add_argument("--routes-child-rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--routes-child-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.ATTR=VALUE", dest="overrides",
                     help="A/B runs: set a bool / int attribute of a rlipv2_amd module for this run, e.g. --set decoder.fused_glue=0 "
                          "(the switches INTEGRATION.md lists; recorded in config.overrides)")
     ap.add_argument("--host-routes", default="auto", choices=["auto", "off", "on"],
                     help="GPU-only host routes of the train step (rlipv2_amd/routes.py): auto = switch on the ones that pass the "
-                         "start-up self-check against the plain step (default), off / on = forced")
+                         "start-up self-check against the plain step, run in a child process before this process touches the "
+                         "GPU (default), off / on = forced")
     ap.add_argument("--msda-fwd-cell", action="store_true",
                     help="EXPERIMENT: the encoder's fused MSDA forward through cell_forward_kernel (LDS windows + matrix cores); "
                          "not validated on hardware, never the default")
@@ -710,6 +859,19 @@ def main():
                     help="non-best-case variant: 6 / 8 / 11 triplets per image in rotation (one graph capture per bucket)")
     args = ap.parse_args()
 
+    if args.routes_child:
+        # internal: the host-route self-check of one rank (started by routes_verdicts_from_child with the parent's own arguments,
+        # torch.distributed.run's variables removed): a single process, whatever --gpus says
+        if args.msda_fwd_cell:
+            from rlipv2_amd import msda as _msda
+            _msda.fused_forward_cell = True
+        apply_overrides(args.overrides)
+        if args.deterministic:
+            torch.backends.cudnn.deterministic = True
+        if torch.cuda.device_count() == 0:
+            raise SystemExit("bench.py --routes-child needs a GPU")
+        routes_child_main(args)
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         # Plain `python bench.py --gpus N`: launch the N ranks ourselves (the reference launches with
         # torch.distributed.launch --nproc_per_node, scripts/RLIP_ParSeDA/train_RLIP_ParSeDA_v2_mixed_vgcoco_resnet.sh:1-2).
@@ -727,6 +889,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}, or without RANK in the environment to let bench.py launch its ranks")
+    if torch.cuda.device_count() == 0:            # (reads the driver's device list; does not initialise the GPU on this image)
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.workload == "train_step" and args.host_routes == "auto":
+        # the self-check runs in a child BEFORE this process creates its GPU context: a never-run route that faults or hangs
+        # takes the child with it, never the timed region or the JSON line (the child is a plain subprocess, not an exec)
+        args.route_verdicts = routes_verdicts_from_child(
+            list(sys.argv[1:]), args.backbone, rank=rank, device_index=0 if os.environ.get("RLIPV2_SINGLE_DEVICE") == "1" else local_rank)
+        print("[bench] host routes (self-check in a child process): " + json.dumps(args.route_verdicts), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.deterministic:
@@ -770,16 +940,11 @@ def main():
                  probe_note=("HIP events around every MSDA call in 2 eager steps of the same train step run right after "
                              "the timed region (the timed steps replay HIP graphs, whose kernels cannot be bracketed)")
                  if graphed else None, step_roofline=step_roofline, host_routes=host_routes,
-                 b0=b0_signature_kernels(args.batch, dtype, device) if args.backbone == "resnet50" else None,
-                 experiments=lambda: run_experiments(args, world))
+                 b0=b0_signature_kernels(args.batch, dtype, device) if args.backbone == "resnet50" else None)
         if world > 1:
             dist.destroy_process_group()
-        if getattr(emit, "child_timed_out", False):
-            # a never-run experiment kernel hung in its child process and was killed: the line above is complete; do not let
-            # this process's teardown wait on a device that may be recovering
-            sys.stdout.flush()
-            sys.stderr.flush()
-            os._exit(0)
+        if rank == 0:
+            experiments_leg(args, world)             # opt-in; after the line, in a process group of its own
         return
     calls = build_msda_step(args.batch, dtype, device, rank)
     stream = torch.cuda.current_stream().cuda_stream

@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RLIPV2_LIB_PATH") or os.path.join(_HERE, "librlipv2_msda.so")   # (override: ablation builds)
+LIB_PATH = os.path.join(_HERE, "librlipv2_msda.so")     # (tools load another build of the same C ABI through use_library())
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 # enum msda_dtype / msda_variant (include/rlipv2_msda.h)
@@ -53,11 +53,30 @@ EXPORTS = (
 )
 
 # include/rlipv2_msda_cpu.h (librlipv2_msda_cpu.so: the CPU twins, no HIP)
-CPU_LIB_PATH = os.environ.get("RLIPV2_CPU_LIB_PATH") or os.path.join(_HERE, "librlipv2_msda_cpu.so")   # (override: sanitizer builds)
+CPU_LIB_PATH = os.path.join(_HERE, "librlipv2_msda_cpu.so")     # (sanitizer builds: use_cpu_library())
 CPU_EXPORTS = ("msda_forward_cpu", "msda_backward_cpu", "msda_cpu_strerror", "msda_cpu_abi_version")
 
 _lib = None
 _cpu_lib = None
+
+
+def use_library(path: str) -> None:
+    """Load another build of the C-ABI library (the ablation / timeline / emulated builds of tools/ and tests/) instead of the
+    in-tree product library.  An explicit call a tool makes BEFORE the first kernel call -- the package itself reads no library
+    location from the environment.  Raises if the product library has already been loaded (two builds in one process would
+    each keep their own per-device state)."""
+    global LIB_PATH
+    if _lib is not None and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+        raise RuntimeError(f"use_library({path!r}): {LIB_PATH} is already loaded in this process")
+    LIB_PATH = os.path.abspath(path)
+
+
+def use_cpu_library(path: str) -> None:
+    """the same for the CPU twins (include/rlipv2_msda_cpu.h), e.g. an ASan / UBSan build"""
+    global CPU_LIB_PATH
+    if _cpu_lib is not None and os.path.abspath(path) != os.path.abspath(CPU_LIB_PATH):
+        raise RuntimeError(f"use_cpu_library({path!r}): {CPU_LIB_PATH} is already loaded in this process")
+    CPU_LIB_PATH = os.path.abspath(path)
 
 
 def build(verbose: bool = False) -> str:

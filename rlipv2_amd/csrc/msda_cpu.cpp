@@ -10,7 +10,7 @@
 // tensor never comes here, and a missing HIP library still raises for CUDA tensors (rlipv2_amd/_lib.py).
 //
 // Work partition.  Forward: one (image, query) row per task, heads and channels inside.  Backward: one (image, head, LEVEL)
-// per task -- the task owns the grad_value rows of its level and head (zero-fills them, then accumulates: no atomics, the
+// per task (levels with overlapping row ranges: one (image, head) per task, see backward()) -- the task owns the grad_value rows of its level and head (zero-fills them, then accumulates: no atomics, the
 // order of the sums is fixed by the query order, so results are bit-repeatable for any thread count) and the
 // grad_sampling_loc / grad_attn_weight entries of its level.
 #include <cmath>
@@ -92,19 +92,27 @@ void forward(const T *value, const int64_t *shapes, const int64_t *starts, const
     }
 }
 
+// `disjoint`: the levels' row ranges do not overlap (every real pyramid).  Then a task = (image, head, level) owns its rows.  With
+// overlapping level_start_index ranges (the reference's atomicAdd formulation tolerates any layout, ms_deform_im2col_cuda.cuh:
+// 142-156) two level tasks would zero and accumulate the same rows: there a task = (image, head) walks all levels itself, over a
+// grad_value the caller has zeroed.
 template <typename T>
 void backward(const T *value, const int64_t *shapes, const int64_t *starts, const T *loc, const T *aw, const T *grad_out, int N,
-              int S, int M, int D, int L, int Lq, int P, T *g_value, T *g_loc, T *g_aw)
+              int S, int M, int D, int L, int Lq, int P, T *g_value, T *g_loc, T *g_aw, bool disjoint)
 {
-    const int64_t tasks = int64_t(N) * M * L;
+    const int groups = disjoint ? L : 1;                 // level groups per (image, head)
+    const int64_t tasks = int64_t(N) * M * groups;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t t = 0; t < tasks; ++t) {
-        const int l = int(t % L), m = int((t / L) % M), n = int(t / (int64_t(L) * M));
+        const int g = int(t % groups), m = int((t / groups) % M), n = int(t / (int64_t(groups) * M));
+        const int l_begin = disjoint ? g : 0, l_end = disjoint ? g + 1 : L;
+        for (int l = l_begin; l < l_end; ++l) {
         const int H = int(shapes[2 * l]), W = int(shapes[2 * l + 1]);
         const T *v_lvl = value + ((int64_t(n) * S + starts[l]) * M + m) * D;
         T *gv_lvl = g_value + ((int64_t(n) * S + starts[l]) * M + m) * D;
-        for (int64_t s = 0; s < int64_t(H) * W; ++s)                        // this task's rows of grad_value
-            std::memset(gv_lvl + s * M * D, 0, sizeof(T) * D);
+        if (disjoint)
+            for (int64_t s = 0; s < int64_t(H) * W; ++s)                    // this task's rows of grad_value
+                std::memset(gv_lvl + s * M * D, 0, sizeof(T) * D);
         for (int q = 0; q < Lq; ++q) {
             const int64_t head = (int64_t(n) * Lq + q) * M + m;
             const T *go = grad_out + head * D;
@@ -139,7 +147,21 @@ void backward(const T *value, const int64_t *shapes, const int64_t *starts, cons
                 g_loc[s_idx * 2 + 1] = T(H) * w * (hw * (dot[2] - dot[0]) + c.lw * (dot[3] - dot[1]));
             }
         }
+        }
     }
+}
+
+// do the row ranges [start, start + H W) of the levels overlap?  (L is small: the quadratic test is the clear one)
+bool levels_disjoint(const int64_t *shapes, const int64_t *starts, int L)
+{
+    for (int a = 0; a < L; ++a)
+        for (int b = a + 1; b < L; ++b) {
+            const int64_t a0 = starts[a], a1 = a0 + shapes[2 * a] * shapes[2 * a + 1];
+            const int64_t b0 = starts[b], b1 = b0 + shapes[2 * b] * shapes[2 * b + 1];
+            if (a0 < b1 && b0 < a1)
+                return false;
+        }
+    return true;
 }
 
 int check(int dtype, const void *const *ptrs, int n_ptrs, const int64_t *shapes, const int64_t *starts, int N, int S, int M, int D,
@@ -196,19 +218,20 @@ int msda_backward_cpu(int dtype, const void *value, const int64_t *shapes, const
     if (int st = check(dtype, ptrs, 9, shapes, starts, N, S, M, D, L, Lq, P))
         return st;
     // rows of `value` that belong to no level (S larger than the pyramid) receive no gradient: zero them here, the tasks
-    // zero the rows they own
+    // zero the rows they own.  Overlapping levels: nobody owns a row, everything is zeroed here.
     const size_t elt = dtype == MSDA_CPU_F32 ? sizeof(float) : sizeof(double);
+    const bool disjoint = levels_disjoint(shapes, starts, L);
     int64_t covered = 0;
     for (int l = 0; l < L; ++l)
         covered += shapes[2 * l] * shapes[2 * l + 1];
-    if (covered != S)
+    if ((covered != S || !disjoint) && g_value)
         std::memset(g_value, 0, elt * size_t(N) * S * M * D);
     if (dtype == MSDA_CPU_F32)
         backward<float>((const float *)value, shapes, starts, (const float *)loc, (const float *)aw, (const float *)grad_out, N, S, M,
-                        D, L, Lq, P, (float *)g_value, (float *)g_loc, (float *)g_aw);
+                        D, L, Lq, P, (float *)g_value, (float *)g_loc, (float *)g_aw, disjoint);
     else
         backward<double>((const double *)value, shapes, starts, (const double *)loc, (const double *)aw, (const double *)grad_out, N,
-                         S, M, D, L, Lq, P, (double *)g_value, (double *)g_loc, (double *)g_aw);
+                         S, M, D, L, Lq, P, (double *)g_value, (double *)g_loc, (double *)g_aw, disjoint);
     return 0;
 }
 

@@ -31,7 +31,8 @@ fused_sampling = True
 # Cross-attention with FEW queries (the decoders: 150 / 300 queries into 88 892 memory tokens): sample the UNPROJECTED memory and
 # project the few sampled rows, instead of projecting every memory token in every decoder layer (MSDeformAttn._sampled_projection).
 # OFF: the formulation is exact (CPU tests against the standard one), what it costs on the GPU depends on kernels that have not
-# been timed; rlipv2_amd/routes.validate switches it on for a step it reproduces.
+# been timed.  A plain attribute: tools/experiments_r05.py --stp times it; it is NOT one of routes.py's
+# self-checked routes (nothing switches it on by itself).
 sample_then_project = False
 SAMPLE_THEN_PROJECT_MAX_FRACTION = 0.25       # taken when queries x heads <= this fraction of the memory tokens
 

@@ -110,15 +110,16 @@ def _run(step_module, criterion, batch, autocast_dtype, seed):
     return float(loss.detach().float()), grads
 
 
-def validate(step_module, criterion, batch, autocast_dtype=None, group=None, seed=20251003, log=None) -> dict:
+def validate(step_module, criterion, batch, autocast_dtype=None, group=None, seed=20251003, log=None, names=None) -> dict:
     """Self-check described in the module docstring.  Leaves every route that passed ON and the others OFF, and returns
-    {route: "on" | "off (self-check failed: <reason>)" | "off (not applicable: <why>)"}.  No optimiser step is taken and the
+    {route: "on" | "off (self-check failed: <reason>)" | "off (not applicable: <why>)"} for the routes in `names` (default: all).  No optimiser step is taken and the
     parameters' .grad are left empty; the caller's random state is restored."""
     import torch.distributed as dist
     device = batch[0].tensors.device
     if device.type != "cuda":
         set_all(False)
         return {name: "off (not applicable: the route exists on the GPU only)" for name in GPU_ONLY_ROUTES}
+    names = list(GPU_ONLY_ROUTES) if names is None else [n for n in GPU_ONLY_ROUTES if n in set(names)]
     cpu_state, cuda_state = torch.get_rng_state(), torch.cuda.get_rng_state(device)
     verdict = {}
     try:
@@ -127,7 +128,7 @@ def validate(step_module, criterion, batch, autocast_dtype=None, group=None, see
         _, again = _run(step_module, criterion, batch, autocast_dtype, seed)
         noise = distance(again, ref_grads)
         del again
-        for name in GPU_ONLY_ROUTES:
+        for name in names:
             set_all(False)
             set_route(name, True)
             try:
@@ -143,11 +144,11 @@ def validate(step_module, criterion, batch, autocast_dtype=None, group=None, see
         set_all(False)
         torch.set_rng_state(cpu_state)
         torch.cuda.set_rng_state(cuda_state, device)
-    ok = torch.tensor([0 if verdict[name] is not None else 1 for name in GPU_ONLY_ROUTES], dtype=torch.int32, device=device)
+    ok = torch.tensor([0 if verdict[name] is not None else 1 for name in names], dtype=torch.int32, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)       # every rank runs the same graph
     result = {}
-    for name, passed in zip(GPU_ONLY_ROUTES, ok.tolist()):
+    for name, passed in zip(names, ok.tolist()):
         set_route(name, bool(passed))
         result[name] = "on" if passed else "off (self-check failed: %s)" % (verdict[name] or "on another rank")
     return result

@@ -126,11 +126,11 @@ def test_set_flag_flips_existing_switches_only():
 
 
 def test_package_reads_no_code_path_switch_from_the_environment():
-    """~15 environment-variable A/B switches were read inside the product package.  What is left is
-    configuration of the libraries underneath (library path, MIOpen / hipBLASLt tuning tables)."""
+    """~15 environment-variable A/B switches were read inside the product package.
+    What is left is configuration of the libraries underneath (MIOpen / hipBLASLt tuning tables).  Another build of the C-ABI
+    library is selected by an explicit `_lib.use_library(path)` call; RLIPV2_LIB_PATH is read by the tools package only."""
     import re
-    allowed = {"RLIPV2_LIB_PATH", "RLIPV2_CPU_LIB_PATH", "RLIPV2_TUNED_MIOPEN", "MIOPEN_USER_DB_PATH", "XDG_CACHE_HOME", "RLIPV2_TUNED_GEMM_TABLE",
-               "RLIPV2_TUNED_GEMMS"}
+    allowed = {"RLIPV2_TUNED_MIOPEN", "MIOPEN_USER_DB_PATH", "XDG_CACHE_HOME", "RLIPV2_TUNED_GEMM_TABLE", "RLIPV2_TUNED_GEMMS"}
     pkg = os.path.join(ROOT, "rlipv2_amd")
     seen = set()
     for f in os.listdir(pkg):
@@ -139,25 +139,175 @@ def test_package_reads_no_code_path_switch_from_the_environment():
     assert seen <= allowed, seen - allowed
 
 
-def test_experiments_leg_only_in_the_full_default_run(monkeypatch):
-    """bench.py appends the A/B table of the unmeasured kernel arms (tools/experiments_r05.py, child processes) to the default
-    1-GPU evidence run only -- never under a profiler, with overrides, on another configuration, or on several ranks."""
+def test_use_library_is_explicit_and_refuses_a_second_build(monkeypatch, tmp_path):
+    from rlipv2_amd import _lib
+    import tools
+    monkeypatch.setattr(_lib, "LIB_PATH", _lib.LIB_PATH)
+    monkeypatch.setattr(_lib, "CPU_LIB_PATH", _lib.CPU_LIB_PATH)
+    monkeypatch.setattr(_lib, "_lib", None)
+    _lib.use_library(str(tmp_path / "other.so"))
+    assert _lib.LIB_PATH == str(tmp_path / "other.so")
+    monkeypatch.setattr(_lib, "_lib", object())                       # "already loaded"
+    with pytest.raises(RuntimeError, match="already loaded"):
+        _lib.use_library(str(tmp_path / "third.so"))
+    _lib.use_library(str(tmp_path / "other.so"))                      # the same path again is fine
+    # the tools package is what reads the environment variable
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("RLIPV2_LIB_PATH", str(tmp_path / "from_env.so"))
+    tools.apply_library_overrides()
+    assert _lib.LIB_PATH == str(tmp_path / "from_env.so")
+
+
+def _ns(**kw):
     import argparse
-    from tools import experiments_r05
-    monkeypatch.setattr(experiments_r05, "main", lambda: {"ran": True})
-    monkeypatch.setattr(bench.torch.cuda, "synchronize", lambda: None)
-    monkeypatch.setattr(bench.torch.cuda, "empty_cache", lambda: None)
     base = dict(experiments=True, no_cpu_baseline=False, backbone="resnet50", dtype="bf16", batch=4, overrides=[], padded=False,
                 var_targets=False)
-    assert bench.run_experiments(argparse.Namespace(**base), 1) == {"ran": True}
-    assert bench.run_experiments(argparse.Namespace(**base), 2) is None
+    return argparse.Namespace(**dict(base, **kw))
+
+
+def test_experiments_leg_is_opt_in_and_only_next_to_the_full_default_run(monkeypatch):
+    """the A/B table of the unmeasured kernel arms is opt-in (`--experiments`) and only runs next to the default 1-GPU evidence
+    configuration -- never under a profiler, with overrides, on another configuration, or on several ranks"""
+    assert bench.experiments_applicable(_ns(), 1)
+    assert not bench.experiments_applicable(_ns(), 2)
     for k, v in (("experiments", False), ("no_cpu_baseline", True), ("batch", 8), ("overrides", ["a.b=1"]), ("backbone", "swin_large")):
-        assert bench.run_experiments(argparse.Namespace(**dict(base, **{k: v})), 1) is None
+        assert not bench.experiments_applicable(_ns(**{k: v}), 1)
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
-    assert bench.run_experiments(argparse.Namespace(**base), 1) is None
+    assert not bench.experiments_applicable(_ns(), 1)
     monkeypatch.delenv("LD_PRELOAD")
-    monkeypatch.setattr(experiments_r05, "main", lambda: 1 / 0)
-    assert "ZeroDivisionError" in bench.run_experiments(argparse.Namespace(**base), 1)["error"]
+    assert bench.experiments_leg(_ns(experiments=False), 1) is None
+    # default command line: off
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'ap.add_argument("--experiments", action="store_true"' in src
+
+
+def _leg(tmp_path, body, budget_s=20):
+    script = tmp_path / "leg.py"
+    script.write_text(body)
+    out = tmp_path / "experiments_last.json"
+    return bench.experiments_leg(_ns(), 1, out_path=str(out), cmd=[sys.executable, str(script)], budget_s=budget_s), out
+
+
+def test_experiments_leg_records_the_object_and_survives_a_leg_that_raises_or_hangs(tmp_path, capfd):
+    rep, out = _leg(tmp_path, "import json; print('noise'); print(json.dumps({'encoder_backward_arms': {}}))")
+    assert rep == {"encoder_backward_arms": {}} and json.load(open(out)) == rep
+    assert "EXPERIMENTS " + json.dumps(rep) in capfd.readouterr().err
+    rep, out = _leg(tmp_path, "raise SystemExit(3)")
+    assert "rc 3" in rep["error"] and json.load(open(out)) == rep
+    # a leg that hangs past its budget -- together with a grandchild that ignores SIGTERM -- is killed as a process group
+    (tmp_path / "grandchild.py").write_text(
+        "import os, signal, time\n"
+        "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+        "open(%r, 'w').write(str(os.getpid()))\n"
+        "time.sleep(600)\n" % str(tmp_path / "grandchild.pid"))
+    body = ("import subprocess, sys, time\n"
+            "subprocess.Popen([sys.executable, %r])\n"
+            "time.sleep(600)\n" % str(tmp_path / "grandchild.py"))
+    import time
+    t0 = time.time()
+    rep, out = _leg(tmp_path, body, budget_s=3)
+    assert "timed out" in rep["error"] and time.time() - t0 < 30 and json.load(open(out)) == rep
+    pid = int(open(tmp_path / "grandchild.pid").read())
+    time.sleep(0.5)
+    assert not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z"
+    capfd.readouterr()
+
+
+_EMIT_SNIPPET = """
+import argparse, json, os, signal, sys
+sys.path.insert(0, %r)
+import bench
+class Lib:
+    msda_pick_variant = staticmethod(lambda *a: 0)
+    msda_variant_name = staticmethod(lambda v: b"quad")
+args = argparse.Namespace(batch=4, steps=2, warmup=1, dtype="bf16", no_cpu_baseline=True, experiments=True, backbone="resnet50",
+                          overrides=[], padded=False, var_targets=False)
+kern = {"enc_bwd_fused": {"ms": 1.0, "n": 2, "dims": (4, 22223, 8, 32, 4, 22223, 4), "code": 2, "bwd": True, "variant": "cell+patch",
+                          "bytes": 409600000, "operand_bytes": 300000000}}
+bench.emit(args, 1, 0.08, kern, Lib, workload_text="train_step: test", cpu_calls=None, parallelism="dp1")
+%s
+"""
+
+
+@pytest.mark.parametrize("after", ["os.kill(os.getpid(), signal.SIGKILL)", "raise RuntimeError('experiments blew up')",
+                                   "os.kill(os.getpid(), signal.SIGSEGV)"])
+def test_the_stdout_line_is_out_before_anything_else_can_go_wrong(after):
+    """whatever happens after emit() -- the process killed, an exception, a fault -- the driver's pipe
+    already holds the complete line (printed and flushed before the opt-in experiments leg is even considered)"""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _EMIT_SNIPPET % (ROOT, after)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["ms_per_step"] == pytest.approx(40.0) and line["roofline"]["frac"] > 0 and "experiments" not in line
+
+
+def test_main_prints_the_line_before_the_experiments_leg_in_source_order():
+    """main(): emit(...) comes before experiments_leg(...), and emit() itself no longer knows the leg"""
+    import inspect
+    src = inspect.getsource(bench.main)
+    assert 0 < src.index("emit(args, world, elapsed, kern, lib") < src.index("experiments_leg(args, world)")
+    assert "experiments" not in inspect.signature(bench.emit).parameters
+    code = "\n".join(ln.split("#")[0] for ln in inspect.getsource(bench.emit).splitlines())      # (comments may mention it)
+    assert "experiments" not in code and code.rstrip().endswith("return line")
+
+
+def _routes_child(tmp_path, body, timeout=20, backbone="resnet50"):
+    script = tmp_path / "child.py"
+    script.write_text(body)
+    return bench.routes_verdicts_from_child([], backbone, cmd=[sys.executable, str(script)], timeout=timeout)
+
+
+def test_route_self_check_child_verdicts_and_failures(tmp_path, capfd):
+    """`--host-routes auto`: the self-check runs in a child before the parent touches the GPU.  A child that segfaults, aborts,
+    hangs, exits non-zero or prints a malformed verdict leaves every route off; Swin routes are never exercised on R50."""
+    r50 = ["residual_gradient_in_gemm", "one_launch_box_head"]
+    assert bench.applicable_routes("resnet50") == r50
+    assert bench.applicable_routes("swin_large") == list(routes.GPU_ONLY_ROUTES)
+    good = {"residual_gradient_in_gemm": "on", "one_launch_box_head": "off (self-check failed: loss 1 vs 2)"}
+    v = _routes_child(tmp_path, "import sys, json; print('[routes] step noise 0.001', file=sys.stderr); print('ROUTES ' + json.dumps(%r))" % good)
+    assert v["residual_gradient_in_gemm"] == "on" and v["one_launch_box_head"].startswith("off (self-check failed")
+    assert v["fused_wide_layer_norm"].startswith("off (not applicable") and v["fused_window_attention"].startswith("off (not applicable")
+    assert list(v) == list(routes.GPU_ONLY_ROUTES)
+    assert "[routes] step noise" in capfd.readouterr().err
+    for body, word in (("import os, signal; print('ROUTES {}'); os.kill(os.getpid(), signal.SIGSEGV)", "SIGSEGV"),
+                       ("import os; os.abort()", "SIGABRT"),
+                       ("import time; time.sleep(600)", "timed out"),
+                       ("import sys; print('boom', file=sys.stderr); sys.exit(7)", "exit code 7; boom"),
+                       ("print('ROUTES {not json')", "no well-formed verdict"),
+                       ("import json; print('ROUTES ' + json.dumps({'residual_gradient_in_gemm': 'on'}))", "no well-formed verdict"),
+                       ("import json; print('ROUTES ' + json.dumps({'residual_gradient_in_gemm': 'on', 'one_launch_box_head': 'yes'}))", "no well-formed verdict"),
+                       ("print('nothing')", "no well-formed verdict")):
+        v = _routes_child(tmp_path, body, timeout=3)
+        assert all(x.startswith("off") for x in v.values()), (body, v)
+        assert word in v["residual_gradient_in_gemm"], (body, v)
+    v = bench.routes_verdicts_from_child([], "resnet50", cmd=["/nonexistent/python"], timeout=3)
+    assert all(x.startswith("off") for x in v.values()) and "not started" in v["one_launch_box_head"]
+
+
+def test_route_verdicts_are_applied_exactly(monkeypatch):
+    try:
+        out = bench.apply_route_verdicts({"residual_gradient_in_gemm": "on", "one_launch_box_head": "off (self-check child: signal SIGSEGV)",
+                                          "fused_wide_layer_norm": "off (not applicable: x)", "fused_window_attention": "ON"}, 1, "cpu")
+        assert routes.state() == {"residual_gradient_in_gemm": True, "one_launch_box_head": False, "fused_wide_layer_norm": False,
+                                  "fused_window_attention": False}
+        assert out["residual_gradient_in_gemm"] == "on" and "SIGSEGV" in out["one_launch_box_head"]
+        out = bench.apply_route_verdicts(None, 1, "cpu")
+        assert not any(routes.state().values()) and all(v.startswith("off") for v in out.values())
+    finally:
+        routes.set_all(False)
+
+
+def test_parent_runs_no_route_self_check_itself():
+    """the bench process never calls routes.validate (only the --routes-child process does), and starts the child before its own
+    first GPU-initialising call"""
+    import inspect
+    assert "routes.validate" not in inspect.getsource(bench.run_train_step_bench)
+    assert "routes.validate" in inspect.getsource(bench.routes_child_main)
+    src = inspect.getsource(bench.main)
+    assert src.index("routes_verdicts_from_child(") < src.index("if not torch.cuda.is_available():") < src.index("torch.cuda.set_device(local_rank)")
 
 
 def test_experiment_parent_survives_failing_and_hanging_arms(monkeypatch, tmp_path):

@@ -67,12 +67,14 @@ def test_reference_gradcheck_recipe_on_the_cpu():
     shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
     starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
     S = int(shapes.prod(1).sum())
-    for D in (2, 30, 32, 71):
+    for D in (2, 30, 32, 71, 1025, 2048, 3096):                      # models/ops/test.py:89: 30, 32, 64, 71, 1025, 2048, 3096
         value = (torch.rand(N, S, M, D, dtype=torch.float64) * 0.01).requires_grad_(True)
         loc = torch.rand(N, Lq, M, L, P, 2, dtype=torch.float64).requires_grad_(True)
         aw = torch.rand(N, Lq, M, L, P, dtype=torch.float64) + 1e-5
         aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).requires_grad_(True)
-        assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, starts, loc, aw, 2))
+        # full Jacobians up to 71 channels; the large counts in fast mode (directional derivatives: the full Jacobian of `value`
+        # at 3096 channels is 18 GB)
+        assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, starts, loc, aw, 2), fast_mode=D > 71)
 
 
 def test_bf16_cpu_tensors_are_widened():
@@ -132,6 +134,35 @@ def test_edge_cases():
                                     aw.expand(3, -1, -1, -1, -1).contiguous(), 2)
     with pytest.raises(RuntimeError, match="contiguous"):
         msda.ms_deform_attn_forward(value.transpose(1, 3), shapes, starts, loc2, aw, 64)
+
+
+def test_overlapping_levels_take_the_unowned_route():
+    """level_start_index ranges that overlap (the reference's atomicAdd scatter tolerates any layout, .cuh:142-156): no task owns a
+    grad_value row, so the backward walks all levels of an (image, head) in one task over a zeroed grad_value -- same numbers as
+    the oracle (which scatters like the reference), for any thread count"""
+    from oracle import msda_oracle as O
+    rng = np.random.default_rng(5)
+    shapes = np.array([[6, 4], [3, 2], [5, 3]], dtype=np.int64)
+    starts = np.array([0, 20, 10], dtype=np.int64)                     # level 1 overlaps level 0's tail, level 2 overlaps both
+    N, S, M, D, Lq, L, P = 2, 45, 3, 5, 7, 3, 2                        # (S = sum of H W, as the oracle insists; rows 26.. unused)
+    value = rng.standard_normal((N, S, M, D))
+    loc = rng.uniform(-0.1, 1.1, (N, Lq, M, L, P, 2))
+    aw = rng.uniform(0, 1, (N, Lq, M, L, P))
+    go = rng.standard_normal((N, Lq, M * D))
+    t = lambda a: torch.from_numpy(a)
+    ref_out = O.forward(value, shapes, starts, loc, aw)
+    ref = O.backward(value, shapes, starts, loc, aw, go)
+    omp = ctypes.CDLL("libgomp.so.1")
+    try:
+        for n in (1, 6):
+            omp.omp_set_num_threads(n)
+            out = msda.ms_deform_attn_forward(t(value), t(shapes), t(starts), t(loc), t(aw), 64)
+            got = msda.ms_deform_attn_backward(t(value), t(shapes), t(starts), t(loc), t(aw), t(go), 64)
+            np.testing.assert_allclose(out.numpy(), ref_out, rtol=1e-12, atol=1e-13)
+            for a, b in zip(got, ref):
+                np.testing.assert_allclose(a.numpy(), b, rtol=1e-11, atol=1e-12)
+    finally:
+        omp.omp_set_num_threads(os.cpu_count() or 1)
 
 
 @pytest.mark.parametrize("nd,masked", [(4, True), (4, False), (2, True)])

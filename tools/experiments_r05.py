@@ -17,14 +17,16 @@ Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_
   swin       the two Swin routes of round 5 (csrc/window_attention.hip, csrc/layernorm_wide.hip; models/swin/swin_transformer.py:
              262-301, 386-401) at the Swin-L stage-0 shapes against the PyTorch op sequences they replace
 Every backward arm is compared with the default's gradients (64-bit digests of the raw bits, computed on the device, and -- through
-a file in /dev/shm the default arm leaves -- per-tensor closeness: grad_value must be bit-equal, the float32-formula gradients within a
+a file in a private temporary directory the default arm leaves -- per-tensor closeness: grad_value must be bit-equal, the float32-formula gradients within a
 rounding) on the encoder shape (N = 4, 800x1333 pyramid, bf16, model-like locations), B0 signature and fused geometry route;
 time = HIP events around 20 calls of the whole backward.
 """
 import json
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,7 +50,12 @@ def digest(t):
     return [int(raw.sum()), int((raw * pos).sum())]
 
 
-REF_FILE = "/dev/shm/rlipv2_experiments_default_arm.pt"      # the default arm's gradients, for the other arms' children (parent deletes it)
+REF_ENV = "RLIPV2_EXPERIMENTS_REF_FILE"      # the default arm's gradients, for the other arms' children: a file in a private
+                                             # temporary directory the parent makes (mkdtemp, mode 0700) and removes
+
+
+def ref_file():
+    return os.environ.get(REF_ENV)
 
 
 def closeness(res, ref):
@@ -89,10 +96,10 @@ def child_backward(arm):
     saved["fused"] = [t.cpu() for t in res]
     out["fused"] = {"digest": [digest(t) for t in res], "finite": all(bool(torch.isfinite(t.float()).all()) for t in res),
                     "us": round(timed(f, iters=20), 1)}
-    if arm == 0:
-        torch.save(saved, REF_FILE)                        # (grad_value / grad_loc / grad_aw and grad_value / grad_qproj: ~300 MB of host memory)
-    elif os.path.exists(REF_FILE):
-        ref = torch.load(REF_FILE)
+    if arm == 0 and ref_file():
+        torch.save(saved, ref_file())                      # (grad_value / grad_loc / grad_aw and grad_value / grad_qproj: ~300 MB)
+    elif ref_file() and os.path.exists(ref_file()):
+        ref = torch.load(ref_file(), weights_only=True)    # (tensors only: nothing in the file is executed)
         for case in ("b0", "fused"):
             out[case]["vs_default"] = closeness(saved[case], ref[case])    # [grad_value, ...]
     print("RESULT " + json.dumps(out), flush=True)
@@ -324,6 +331,14 @@ def run_step_child(flags, env, timeout):
 
 
 def main(per_child_timeout=45, budget_s=150):
+    tmp_dir = tempfile.mkdtemp(prefix="rlipv2_experiments_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        return _main(tmp_dir, per_child_timeout, budget_s)
+    finally:
+        shutil.rmtree(tmp_dir, ignore_errors=True)            # (also when the parent is interrupted: ~300 MB of memory-backed file)
+
+
+def _main(tmp_dir, per_child_timeout, budget_s):
     """parent: one child per arm / kernel, most informative first; nothing is started after `budget_s` seconds and no child may
     run past the deadline (bench.py's default run must stay within minutes); `--all`: no budget, every arm"""
     everything = "--all" in sys.argv
@@ -334,6 +349,7 @@ def main(per_child_timeout=45, budget_s=150):
     report = {"what": "unmeasured kernel arms, A/B in child processes (tools/experiments_r05.py); evidence only, product path unchanged",
               "shape": "encoder N=4, 800x1333 pyramid, bf16, model-like locations; us = HIP events around 20 whole calls"}
     base_env = {k: v for k, v in os.environ.items() if k not in KEYS and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    base_env[REF_ENV] = os.path.join(tmp_dir, "default_arm.pt")
     have_arms = os.path.exists(ABLATION_LIB)
     arms, base = {}, [None]
 
@@ -378,8 +394,6 @@ def main(per_child_timeout=45, budget_s=150):
     report["swin_routes"] = child(["--swin"])
     for k in range(2, len(ARMS) if everything else 4):
         arm(k)
-    if os.path.exists(REF_FILE):
-        os.remove(REF_FILE)
     report["wall_s"] = round(time.time() - t0, 1)
     return report
 

@@ -215,12 +215,15 @@ int msda_fused_backward_ws(int flags, int dtype,
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- the "records" route of a bfloat16 encoder call (Lq == S, D = 32, L = P = 4) -------------------------------------------
- * (csrc/msda_cell_forward.inc with EMIT, csrc/msda_cell_records.inc; round 5, written without a GPU: explicit entry points,
+ * (csrc/msda_cell_forward.inc with EMIT, csrc/msda_cell_records.inc; rounds 5-6, written without a GPU: explicit entry points,
  *  never picked by the AUTO variants.)  The forward pass (MSDA_VARIANT_CELL's kernel) leaves, in ONE caller-owned buffer of
- * msda_records_bytes, what the backward pass would otherwise recompute from float32 sampling_loc / attn_weight: a 16-byte
- * record per sample (window offset of its top-left corner, the two bilinear fractions, the attention weight), the LDS window
- * table of every (image, head, cell) and the patch masks + group records of the grad_value pass.  The backward pass then runs
- * no sample geometry and no binning: gradients of the locations / weights (reference ms_deform_im2col_cuda.cuh:87-159) from the
+ * msda_records_bytes, what the backward pass would otherwise recompute from float32 sampling_loc / attn_weight: a 2-byte
+ * record per sample (the LDS-window pixel of its top-left corner), the LDS window table of every (image, head, cell) and the
+ * patch masks + 48-byte group records (locations and weights of a (query, head, level)) of the grad_value pass -- 222 MB per
+ * N = 4 call at 800 x 1333 (round 5's 16-byte records: 408 MB; the product route saves 136 MB of float32 locations / weights
+ * and moves another 194 MB of masks + group records inside its backward).  The backward pass then runs no bounding boxes, no
+ * window placement, no corner clipping and no binning (per sample: the two bilinear fractions from the group record's location,
+ * six instructions): gradients of the locations / weights (reference ms_deform_im2col_cuda.cuh:87-159) from the
  * records on v_mfma_f32_4x4x4_16B_bf16, grad_value from the matrix-core patch pass.  Against msda_backward_ws /
  * msda_fused_backward_ws on the same call: grad_value bit-identical (the same patch pass on the same masks and group records);
  * the other gradients bit-identical on the lane-level model of tools/emu/ and, on the device, within a rounding of their type

@@ -734,7 +734,8 @@ void launch_backward_dest(const Problem &p_in, const Fused *f, const int64_t *sh
     if (records) {
         // the "records" route (msda_cell_records.inc): the forward pass has left every sample's geometry, the patch masks and
         // the group records; nothing is binned here
-        gate = launch_cell_records_backward(p, f, shapes_host, records, out_bf16, records_swap);
+        const size_t gco = patch_gcell_offset(p, shapes_host);          // (ablation build: the CELLG arm's copy; else 0)
+        gate = launch_cell_records_backward(p, f, shapes_host, records, out_bf16, records_swap, gco ? static_cast<unsigned char *>(pws) + gco : nullptr);
         if (!p.loc) {
             // the forward did not save float32 locations / weights: the sorting pass below -- if the gate lets it run at all --
             // reads copies rebuilt from the group records, in the part of the workspace the binning of the product route uses
@@ -749,7 +750,8 @@ void launch_backward_dest(const Problem &p_in, const Fused *f, const int64_t *sh
         const bool cell = cell_backward_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_CELL", 1);
         if (cell) launch_cell_backward(p, f, shapes_host, ctl, pws);
         else k1();
-        launch_patch_dest(p, shapes_host, ctl, pws, out_bf16, cell);
+        const size_t gco = patch_gcell_offset(p, shapes_host);          // (ablation build: the CELLG arm's copy; else 0)
+        launch_patch_dest(p, shapes_host, ctl, pws, out_bf16, cell, gco ? static_cast<unsigned char *>(pws) + gco : nullptr);
         gate = ctl + 60;
     } else {
         k1();

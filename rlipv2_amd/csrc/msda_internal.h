@@ -85,7 +85,10 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
 // `mask_ws` = patch_workspace_bytes of scratch
 bool patch_supports(const Problem &p, const int64_t *shapes_host);
 size_t patch_workspace_bytes(const Problem &p, const int64_t *shapes_host);
-void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned);
+void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned,
+                       void *gcell_ws = nullptr);
+// ablation build only (else 0): offset, inside a patch_workspace_bytes buffer, of the room for the cell-major grad_out copy
+size_t patch_gcell_offset(const Problem &p, const int64_t *shapes_host);
 // ... preceded by cell_backward_kernel: K1's work (grad_sampling_loc / grad_attn_weight, or with `f` the projection row's
 // gradient) from LDS-resident value windows on v_mfma_f32_4x4x4_16B_bf16, plus the binning for the patch pass
 bool cell_backward_supports(const Problem &p, const int64_t *shapes_host);
@@ -97,7 +100,7 @@ void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fus
 bool cell_records_supports(const Problem &p, const int64_t *shapes_host);
 size_t cell_records_bytes(const Problem &p, const int64_t *shapes_host);
 const int *launch_cell_records_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, const void *records,
-                                        bool out_bf16, bool swap);
+                                        bool out_bf16, bool swap, void *gcell_ws = nullptr);
 void launch_records_unbin(const Problem &p, const int64_t *shapes_host, const void *records, float *loc, float *aw, const int *gate);
 // the plan of the cell + patch route as int32 values (include/rlipv2_msda.h: msda_backward_plan_info); 0 = route not taken
 int patch_plan_info(const Problem &p, const int64_t *shapes_host, int32_t *out, int out_len);

@@ -609,11 +609,16 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_kernel(
 // fine levels with the next patch's mask words prefetched, the mask-word prefetch outside a branch, tents through the clamp
 // modifier, operand images staged with exchanged halves (bank-conflict-free transposing reads).  Must reproduce
 // patch_dest_kernel bit for bit.
-template <typename OT, int WPS>
+// CELLG (round 6, RLIPV2_PATCH_CELLG=1): grad_out rows are read from a copy in the group records' CELL-MAJOR order
+// (`gcell`: [(image, head)][cell][query of the cell][32 channels], written by grad_out_cells_kernel below) -- the candidate's
+// record index addresses its grad_out row too: no decode of the query's pyramid position per candidate (the level select chain,
+// ~18 of the step's ~244 VALU instructions), and the rows of a cell's neighbouring queries share 128-byte lines (in grad_out a
+// head's 64-byte row shares its line with another head's, i.e. with a workgroup on another XCD).
+template <typename OT, int WPS, bool CELLG>
 __global__ __launch_bounds__(kThreads, WPS) void patch_dest_multi_kernel(
     PatchPlan pl, const int64_t *__restrict__ starts, const float *__restrict__ recs,
     const bf16_t *__restrict__ grad_out, const uint32_t *__restrict__ masks, const int *__restrict__ ctl,
-    OT *__restrict__ g_value, int N, int S, int M, int Lq, int dbg)
+    OT *__restrict__ g_value, int N, int S, int M, int Lq, int dbg, const bf16_t *__restrict__ gcell)
 {
     constexpr bool MULTI = true;
     MSDA_DYNAMIC_LDS(unsigned char, lds);
@@ -645,6 +650,8 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_multi_kernel(
     const int H = pl.H[l], W = pl.W[l];
     const int nbx = pl.nbx[l], nb2 = pl.nby[l] * nbx, invx = pl.invx[l];
     const float *rbase = recs + ((size_t)nm * kL + l) * (size_t)(pl.CY * pl.CX) * kCellQ * 12;
+    const bf16_t *gbase = CELLG ? gcell + (size_t)nm * (size_t)(pl.CY * pl.CX) * kCellQ * kD : nullptr;
+    (void)gbase;
     const float Hf = (float)H, Wf = (float)W;
     // per-level (start, width) of the query levels, selected per lane below
     const int st0 = (int)starts[0], st1 = (int)starts[1], st2 = (int)starts[2], st3 = (int)starts[3];
@@ -764,19 +771,25 @@ __global__ __launch_bounds__(kThreads, WPS) void patch_dest_multi_kernel(
                 const int code = list[h0 + (kk < avail_n ? kk : 0)];
                 const int slot = code >> 9, bit = code & 511;
                 const int sy = (slot * invx) >> 16, sx = slot - sy * nbx;
-                const int lq = bit < 256 ? 0 : bit < 320 ? 1 : bit < 336 ? 2 : 3;
-                const int r = bit - (lq == 0 ? 0 : lq == 1 ? 256 : lq == 2 ? 320 : 336);
-                const int sh = 4 - lq;
-                const int iy = ((oy + sy) << sh) + (r >> sh), ix = ((ox + sx) << sh) + (r & ((1 << sh) - 1));
-                const int stq = lq == 0 ? st0 : lq == 1 ? st1 : lq == 2 ? st2 : st3;
-                const int Wq = lq == 0 ? W0 : lq == 1 ? W1 : lq == 2 ? W2 : W3;
-                int qm = (nq + stq + iy * Wq + ix) * M + m;                            // < 2^25 (checked by the ABI)
                 int ri = ((oy + sy) * pl.CX + ox + sx) * kCellQ + bit;                 // record of (cell, query)
-                if (MSDA_DBG(dbg) & 2) { qm = (nq + (lane & 7)) * M + m; ri = lane & 7; }   // ablation: cache-resident operands
+                if (MSDA_DBG(dbg) & 2) ri = lane & 7;                                   // ablation: cache-resident operands
+                const uint4 *gp;
+                if (CELLG) {                                                            // the record index is the row's index too
+                    gp = reinterpret_cast<const uint4 *>(gbase + (size_t)ri * kD + half * 16);
+                } else {
+                    const int lq = bit < 256 ? 0 : bit < 320 ? 1 : bit < 336 ? 2 : 3;
+                    const int r = bit - (lq == 0 ? 0 : lq == 1 ? 256 : lq == 2 ? 320 : 336);
+                    const int sh = 4 - lq;
+                    const int iy = ((oy + sy) << sh) + (r >> sh), ix = ((ox + sx) << sh) + (r & ((1 << sh) - 1));
+                    const int stq = lq == 0 ? st0 : lq == 1 ? st1 : lq == 2 ? st2 : st3;
+                    const int Wq = lq == 0 ? W0 : lq == 1 ? W1 : lq == 2 ? W2 : W3;
+                    int qm = (nq + stq + iy * Wq + ix) * M + m;                        // < 2^25 (checked by the ABI)
+                    if (MSDA_DBG(dbg) & 2) qm = (nq + (lane & 7)) * M + m;
+                    gp = reinterpret_cast<const uint4 *>(grad_out + (size_t)qm * kD + half * 16);
+                }
                 const float *rec = rbase + (size_t)ri * 12;
                 xy_n = reinterpret_cast<const float4 *>(rec)[half];
                 a2_n = reinterpret_cast<const float2 *>(rec + 8)[half];
-                const uint4 *gp = reinterpret_cast<const uint4 *>(grad_out + (size_t)qm * kD + half * 16);
                 g0_n = gp[0]; g1_n = gp[1];
             }
             // ---- one MFMA step over the `avail` <= 32 candidates whose operands were requested one iteration ago -------
@@ -1375,6 +1388,33 @@ namespace {
 #undef MSDA_TR_READ_PAIR
 #undef MSDA_MFMA444
 
+#ifdef MSDA_ABLATION
+// grad_out in the group records' cell-major order (the CELLG arm of the patch pass): one workgroup per (image, head, cell)
+// copies the 64-byte rows of the cell's <= 340 queries, four lanes per row.  Gated like the pass that reads the copy.
+__global__ __launch_bounds__(256) void grad_out_cells_kernel(PatchPlan pl, const int64_t *__restrict__ starts,
+                                                             const bf16_t *__restrict__ grad_out, int N, int M, int Lq,
+                                                             bf16_t *__restrict__ gcell, const int *__restrict__ ctl)
+{
+    if (ctl[kFarWord] != 0) return;
+    const int cells = pl.CY * pl.CX;
+    const int c = blockIdx.x % cells, nm = blockIdx.x / cells;
+    const int n = nm / M, m = nm % M;
+    const int cy = c / pl.CX, cx = c % pl.CX;
+    const int lsH0 = pl.H[0], lsH1 = pl.H[1], lsH2 = pl.H[2], lsH3 = pl.H[3];
+    const int lsW0 = pl.W[0], lsW1 = pl.W[1], lsW2 = pl.W[2], lsW3 = pl.W[3];
+    const int lsS0 = (int)starts[0], lsS1 = (int)starts[1], lsS2 = (int)starts[2], lsS3 = (int)starts[3];
+    for (int i = threadIdx.x; i < kCellQ * 4; i += 256) {
+        const int j = i >> 2, piece = i & 3;
+        bool live;
+        const int q = cell_query(MSDA_LS_ARGS, cy, cx, j, live);
+        if (!live) continue;
+        const uint4 *src = reinterpret_cast<const uint4 *>(grad_out + (((size_t)n * Lq + q) * M + m) * kD);
+        uint4 *dst = reinterpret_cast<uint4 *>(gcell + (((size_t)nm * cells + c) * kCellQ + j) * kD);
+        dst[piece] = src[piece];
+    }
+}
+#endif
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 bool make_patch_plan(const Problem &p, const int64_t *hs, PatchPlan &pl)
 {
@@ -1459,10 +1499,28 @@ bool patch_supports(const Problem &p, const int64_t *shapes_host)
     return mask_bytes(p, pl) + rec_bytes(p, pl) <= ((size_t)1 << 31);
 }
 
+// (ablation build: + room for the cell-major grad_out copy of the CELLG arm, behind the masks and group records)
+static size_t gcell_bytes(const Problem &p, const PatchPlan &pl)
+{
+#ifdef MSDA_ABLATION
+    return (size_t)p.N * p.M * pl.CY * pl.CX * kCellQ * kD * 2;
+#else
+    (void)p; (void)pl;
+    return 0;
+#endif
+}
+
 size_t patch_workspace_bytes(const Problem &p, const int64_t *shapes_host)
 {
     PatchPlan pl;
     if (!patch_supports(p, shapes_host) || !make_patch_plan(p, shapes_host, pl)) return 0;
+    return mask_bytes(p, pl) + rec_bytes(p, pl) + gcell_bytes(p, pl);
+}
+
+size_t patch_gcell_offset(const Problem &p, const int64_t *shapes_host)
+{
+    PatchPlan pl;
+    if (!patch_supports(p, shapes_host) || !make_patch_plan(p, shapes_host, pl) || gcell_bytes(p, pl) == 0) return 0;
     return mask_bytes(p, pl) + rec_bytes(p, pl);
 }
 
@@ -1492,8 +1550,8 @@ bool cell_forward_supports(const Problem &p, const int64_t *shapes_host)
 }
 
 // ---- the records buffer: what cell_forward_kernel<., EMIT> leaves for the backward pass (one allocation, saved by the caller)
-//   [control block 256 B | window table 128 B per (image, head, cell) | sample records 256 B per (.., query of the cell)
-//    | patch masks | group records]            (the last two exactly as launch_patch_dest expects them: masks, then records)
+//   [control block 256 B | window table 128 B per (image, head, cell) | sample records: 2 B per sample, kRecQ query slots per
+//    (.., cell, level) | patch masks | group records]  (the last two exactly as launch_patch_dest expects them: masks, then records)
 struct RecordsLayout { size_t wtab, srec, masks, total; };
 constexpr size_t kRecCtlBytes = 256;
 static RecordsLayout records_layout(const Problem &p, const PatchPlan &pl)
@@ -1502,7 +1560,7 @@ static RecordsLayout records_layout(const Problem &p, const PatchPlan &pl)
     RecordsLayout r;
     r.wtab = kRecCtlBytes;
     r.srec = r.wtab + items * kL * 8 * 4;
-    r.masks = r.srec + items * kCellQ * 256;
+    r.masks = r.srec + items * kL * kRecQ * kP * sizeof(srec_t);       // (a multiple of 128 bytes per item)
     r.total = r.masks + mask_bytes(p, pl) + rec_bytes(p, pl);
     return r;
 }
@@ -1512,7 +1570,7 @@ bool cell_records_supports(const Problem &p, const int64_t *shapes_host)
     PatchPlan pl;
     if (!cell_forward_supports(p, shapes_host) || !patch_supports(p, shapes_host) || !make_patch_plan(p, shapes_host, pl)) return false;
     if (pl.bin_lds > kFwdWinBytes || !quad_supports(p)) return false;         // the forward's mask table; buffer addressing of the direct route
-    return (size_t)p.N * p.M * pl.CY * pl.CX * kCellQ * 16 < ((size_t)1 << 31);
+    return (size_t)p.N * p.M * pl.CY * pl.CX * kL * kRecQ * kP < ((size_t)1 << 31);      // 32-bit record indices
 }
 
 size_t cell_records_bytes(const Problem &p, const int64_t *shapes_host)
@@ -1535,7 +1593,7 @@ void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fus
     if (rb && hipMemsetAsync(rb, 0, kRecCtlBytes, p.stream) != hipSuccess) return;      // (the error stays recorded)
     int *rctl = reinterpret_cast<int *>(rb);
     int *wtab = rb ? reinterpret_cast<int *>(rb + rl.wtab) : nullptr;
-    uint4 *srec = rb ? reinterpret_cast<uint4 *>(rb + rl.srec) : nullptr;
+    srec_t *srec = rb ? reinterpret_cast<srec_t *>(rb + rl.srec) : nullptr;
     uint32_t *masks = rb ? reinterpret_cast<uint32_t *>(rb + rl.masks) : nullptr;
     float *grecs = rb ? reinterpret_cast<float *>(rb + rl.masks + mask_bytes(p, pl)) : nullptr;
 #define MSDA_CELL_FWD(RD, EMIT, LOC, AW)                                                                              \
@@ -1566,7 +1624,7 @@ void launch_cell_forward(const Problem &p, const int64_t *shapes_host, const Fus
 // "far sample" word of the records' control block: non-zero -> the patch pass has returned without writing and the caller's
 // sorting pass must produce grad_value.
 const int *launch_cell_records_backward(const Problem &p, const Fused *f, const int64_t *shapes_host, const void *records,
-                                        bool out_bf16, bool swap)
+                                        bool out_bf16, bool swap, void *gcell_ws)
 {
     PatchPlan pl;
     make_patch_plan(p, shapes_host, pl);
@@ -1574,7 +1632,7 @@ const int *launch_cell_records_backward(const Problem &p, const Fused *f, const 
     unsigned char *rb = reinterpret_cast<unsigned char *>(const_cast<void *>(records));
     int *rctl = reinterpret_cast<int *>(rb);
     const int *wtab = reinterpret_cast<const int *>(rb + rl.wtab);
-    const uint4 *srec = reinterpret_cast<const uint4 *>(rb + rl.srec);
+    const srec_t *srec = reinterpret_cast<const srec_t *>(rb + rl.srec);
     const float *grecs = reinterpret_cast<const float *>(rb + rl.masks + mask_bytes(p, pl));
     const unsigned vbytes = (unsigned)((size_t)p.N * p.S * p.M * kD * 2);
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
@@ -1593,7 +1651,7 @@ const int *launch_cell_records_backward(const Problem &p, const Fused *f, const 
     else MSDA_REC(4);
 #undef MSDA_REC
 #undef MSDA_REC_K
-    launch_patch_dest(p, shapes_host, rctl, rb + rl.masks, out_bf16, true);
+    launch_patch_dest(p, shapes_host, rctl, rb + rl.masks, out_bf16, true, gcell_ws);
     return rctl + kFarWord;
 }
 
@@ -1657,8 +1715,9 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
 }
 
 // ctl: the control block of launch_backward_dest (zeroed by the caller on the stream), masks: patch_workspace_bytes;
-// binned: cell_backward_kernel has already written the masks and records
-void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned)
+// binned: cell_backward_kernel has already written the masks and records; gcell_ws (ablation build, may be null): room for the
+// cell-major grad_out copy of the CELLG arm (patch_gcell_offset)
+void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned, void *gcell_ws)
 {
     PatchPlan pl;
     make_patch_plan(p, shapes_host, pl);
@@ -1670,21 +1729,37 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
                            (const float *)p.loc, (const float *)p.aw, p.M, p.Lq, masks, recs, ctl);
     const int grid = pl.items * p.N * p.M;
     static const int wps = ablation_env("RLIPV2_PATCH_WPS", 4);
+#define MSDA_PATCH_ARGS(OT)                                                                                          \
+    pl, p.starts, (const float *)recs, (const bf16_t *)p.grad_out, masks, (const int *)ctl, (OT *)p.g_value, p.N, p.S, p.M, p.Lq, \
+        ablation_env("RLIPV2_PATCH_DBG", 0)
 #define MSDA_PATCH(KERNEL, OT, WPS)                                                                                  \
-    hipLaunchKernelGGL((KERNEL<OT, WPS>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, pl,              \
-                       p.starts, (const float *)recs, (const bf16_t *)p.grad_out, masks,                            \
-                       (const int *)ctl, (OT *)p.g_value, p.N, p.S, p.M, p.Lq, ablation_env("RLIPV2_PATCH_DBG", 0))
+    hipLaunchKernelGGL((KERNEL<OT, WPS>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, MSDA_PATCH_ARGS(OT))
 #ifdef MSDA_ABLATION
+#define MSDA_PATCH_MULTI(OT, CELLG)                                                                                  \
+    hipLaunchKernelGGL((patch_dest_multi_kernel<OT, 4, CELLG>), dim3(grid), dim3(kThreads), kWaves * kWaveLds, p.stream, \
+                       MSDA_PATCH_ARGS(OT), (const bf16_t *)gcell)
     bool multi = ablation_env("RLIPV2_PATCH_MULTI", kPatchMulti) != 0;      // (the experiment kernel, also with 1 patch per wave)
     for (int l = 0; l < kL; ++l) multi = multi || pl.reps[l] > 1;
+    bf16_t *gcell = nullptr;
+    if (gcell_ws && ablation_env("RLIPV2_PATCH_CELLG", 0) != 0) {           // the experiment kernel on a cell-major grad_out copy
+        gcell = reinterpret_cast<bf16_t *>(gcell_ws);
+        hipLaunchKernelGGL(grad_out_cells_kernel, dim3(p.N * p.M * pl.CY * pl.CX), dim3(256), 0, p.stream, pl, p.starts,
+                           (const bf16_t *)p.grad_out, p.N, p.M, p.Lq, gcell, (const int *)ctl);
+        multi = true;
+    }
     if (multi) {
-        if (out_bf16) MSDA_PATCH(patch_dest_multi_kernel, bf16_t, 4); else MSDA_PATCH(patch_dest_multi_kernel, float, 4);
+        if (gcell) { if (out_bf16) MSDA_PATCH_MULTI(bf16_t, true); else MSDA_PATCH_MULTI(float, true); }
+        else { if (out_bf16) MSDA_PATCH_MULTI(bf16_t, false); else MSDA_PATCH_MULTI(float, false); }
         return;
     }
+#undef MSDA_PATCH_MULTI
+#else
+    (void)gcell_ws;
 #endif
     if (out_bf16) { if (wps == 5) MSDA_PATCH(patch_dest_kernel, bf16_t, 5); else MSDA_PATCH(patch_dest_kernel, bf16_t, 4); }
     else { if (wps == 5) MSDA_PATCH(patch_dest_kernel, float, 5); else MSDA_PATCH(patch_dest_kernel, float, 4); }
 #undef MSDA_PATCH
+#undef MSDA_PATCH_ARGS
 }
 
 }  // namespace msda

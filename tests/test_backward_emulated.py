@@ -5,7 +5,7 @@ CPU against the lane-level workgroup model of tools/emu/ and run on a small enco
   16x16x32 MFMA operand layouts, transposing LDS reads, DPP scans and broadcasts, ballot / readlane, buffer loads);
 * every EXPERIMENT arm of round 3 (written while the GPU pool was closed: geometry once per quad, swapped MFMA operands,
   level starts without the dependent vector load, window copies issued up front, the un-branched mask-word prefetch, several
-  patches per wave) must reproduce the product kernels' three gradients BIT FOR BIT, B0 signature and fused geometry.
+  patches per wave; round 6: grad_out rows read from a cell-major copy) must reproduce the product kernels' three gradients BIT FOR BIT, B0 signature and fused geometry.
 
 What this cannot see: the compiler's code generation, timing, anything the hardware does differently from the measured
 semantics the model encodes.  The GPU runs of tools/r03_experiments.py remain the last word."""
@@ -108,7 +108,8 @@ def test_product_kernels_on_the_model_reproduce_the_oracle(emulator):
 
 
 ARMS = [{"RLIPV2_CELL_SHARED": "3"}, {"RLIPV2_CELL_SHARED": "4"}, {"RLIPV2_PATCH_MULTI": "1"},
-        {"RLIPV2_CELL_SHARED": "2", "RLIPV2_PATCH_REPS": "3"}]
+        {"RLIPV2_CELL_SHARED": "2", "RLIPV2_PATCH_REPS": "3"},
+        {"RLIPV2_PATCH_CELLG": "1"}, {"RLIPV2_PATCH_CELLG": "1", "RLIPV2_PATCH_REPS": "3", "RLIPV2_CELL_SHARED": "3"}]     # round 6
 if os.environ.get("RLIPV2_TEST_EMU_FULL", "0") == "1":       # (the default set covers every code path of the arms once)
     ARMS += [{"RLIPV2_CELL_SHARED": "1"}, {"RLIPV2_CELL_SHARED": "2"}, {"RLIPV2_PATCH_REPS": "2"}, {"RLIPV2_PATCH_REPS": "4"},
              {"RLIPV2_PATCH_REPS": "8"}, {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_REPS": "4"}]

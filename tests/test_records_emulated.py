@@ -1,7 +1,8 @@
 """The "records" route of the encoder backward (csrc/msda_cell_forward.inc with EMIT, csrc/msda_cell_records.inc; round 5, never
 run on hardware) on the lane-level model of tools/emu/, through the C ABI (msda_records_bytes / msda_records_forward /
-msda_records_backward): the forward pass leaves a 16-byte record per sample, the cells' window tables and the patch pass's masks
-and group records; the backward pass then runs no sample geometry and no binning.
+msda_records_backward): the forward pass leaves a 2-byte record per sample (round 6's record diet; the bilinear fractions and the
+weight come from the group records), the cells' window tables and the patch pass's masks and group records; the backward pass
+then runs no window placement, no corner clipping and no binning.
 
 The bar is the verdict's: BIT-EQUAL to the product kernels (msda_backward_ws / msda_fused_backward_ws: cell_backward_kernel +
 patch_dest_kernel, both validated on hardware in round 3) on the same call, both operand orders of the 4x4x4 products; the

@@ -1,7 +1,8 @@
 // backward_emu.cpp -- rlipv2_amd/csrc/msda_patch.hip ITSELF (kernels and their launchers) compiled for the CPU against the
 // lane-level workgroup model of tools/emu/stub/hip/hip_runtime.h: the encoder backward's cell + patch route
 // (cell_backward_kernel -> patch_dest_kernel) on a small problem.  Test infrastructure (tests/test_backward_emulated.py).
-// The ablation switches of the launchers are live (MSDA_ABLATION): RLIPV2_CELL_SHARED, RLIPV2_PATCH_MULTI, RLIPV2_PATCH_REPS
+// The ablation switches of the launchers are live (MSDA_ABLATION): RLIPV2_CELL_SHARED, RLIPV2_PATCH_MULTI, RLIPV2_PATCH_REPS,
+// RLIPV2_PATCH_CELLG
 // select the experiment arms, so their LOGIC can be checked against the oracle -- and against the product kernels, which a
 // GPU has validated and which therefore calibrate the model -- without a GPU.
 // usage: backward_emu problem.bin out.bin     (problem: see main; out: g_value bf16 | g_loc f32 | g_aw f32 | far flag int32;
@@ -62,7 +63,8 @@ int main(int argc, char **argv)
         fz.ref = ref.data(); fz.refdim = 2; fz.g_qproj = gq.data();
     }
     msda::launch_cell_backward(p, fused ? &fz : nullptr, hs, ctl, ws.data());
-    msda::launch_patch_dest(p, hs, ctl, ws.data(), true, true);
+    const size_t gco = msda::patch_gcell_offset(p, hs);                   // RLIPV2_PATCH_CELLG=1: the cell-major grad_out copy
+    msda::launch_patch_dest(p, hs, ctl, ws.data(), true, true, gco ? ws.data() + gco : nullptr);
     f = std::fopen(argv[2], "wb");
     std::fwrite(gv.data(), 2, gv.size(), f);
     if (fused) std::fwrite(gq.data(), 2, gq.size(), f);

@@ -320,7 +320,8 @@ def run_train_step_bench(args, world, rank, local_rank, device):
     synchronizer = None
     eager_step = step_module
     force_dp = os.environ.get("RLIPV2_FORCE_DP") == "1" and dist.is_initialized()   # 1-rank plumbing check
-    overlap = bool(args.dp_overlap)
+    schedule = "overlapped" if args.dp_overlap else args.dp_schedule        # auto | flat | overlapped (data-parallel runs only)
+    overlap, schedule_reason = schedule == "overlapped", None
     frozen = False
     if world > 1 or force_dp:
         train.broadcast_parameters(model, 0)
@@ -347,20 +348,44 @@ def run_train_step_bench(args, world, rank, local_rank, device):
                 if not frozen:
                     train.freeze_parameters_without_gradient(step_module, criterion, batch)
             else:
-                synchronizer = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
-                # the 1 / world of the gradient average is applied inside the fused optimiser's kernels (no extra pass
-                # over the 425 MB gradient buffer); the float32-parameter optimiser path scales in the synchronizer
-                synchronizer.scale_in_optimizer = bool(master)
-                if overlap and not train.captured_collective_selftest(device):
-                    # (RCCL only; every other backend is answered "no" without a capture attempt)
-                    # (all ranks agree on the verdict) captured collectives do not replay here: flat schedule
+                def make_sync():
+                    s_ = train.GradientSynchronizer([p for p in step_module.parameters() if p.requires_grad])
+                    # the 1 / world of the gradient average is applied inside the fused optimiser's kernels (no extra pass
+                    # over the 425 MB gradient buffer); the float32-parameter optimiser path scales in the synchronizer
+                    s_.scale_in_optimizer = bool(master)
+                    return s_
+                crit_in_graph = criterion if args.graph_criterion else None
+                chosen = None
+                if schedule == "auto" and crit_in_graph is not None:
+                    # overlapped iff captured collectives replay on all ranks AND the first overlapped step equals the flat
+                    # step (loss, gradient norm to 1e-3) on all ranks -- train.choose_dp_schedule; every rank decides alike
+                    chosen, picked, schedule_reason = train.choose_dp_schedule(
+                        lambda ov: train.graph_step_module(step_module, model, batch, make_sync(), criterion=crit_in_graph, overlap=ov),
+                        batch, device, log=lambda m: print(m, file=sys.stderr))
+                    overlap = picked == "overlapped"
+                    print(f"[bench] gradient schedule (auto): {picked} -- {schedule_reason}", file=sys.stderr)
+                    import gc
+                    gc.collect()                                    # (the step that was not chosen: its graphs and flat buffer)
+                    torch.cuda.empty_cache()
+                elif schedule == "auto":
+                    overlap, schedule_reason = False, "auto needs the criterion inside the graphs (--no-graph-criterion): flat"
+                elif overlap and not train.captured_collective_selftest(device):
+                    # (RCCL only; every other backend is answered "no" without a capture attempt; all ranks agree)
                     print("[bench] collectives cannot be captured into the backward graph here (not RCCL, or the self-test "
-                          "failed): one flat all-reduce after the backward graph",
-                          file=sys.stderr)
-                    overlap = False
+                          "failed): one flat all-reduce after the backward graph", file=sys.stderr)
+                    overlap, schedule_reason = False, "forced overlapped, but the capture self-test failed: flat"
+                if chosen is not None and not args.var_targets:
+                    synchronizer = chosen.synchronizer
+                else:
+                    chosen = None                                   # (variable targets: the cache captures per bucket, below)
+                    torch.cuda.empty_cache()
+                    synchronizer = make_sync()
             if args.var_targets:
                 step_module = train.GraphedStepCache(step_module, model, synchronizer, criterion=criterion, overlap=overlap)
                 step_module.register(rotation)                  # capture every bucket before the timed region
+            elif world > 1 or force_dp:
+                step_module = chosen if chosen is not None else train.graph_step_module(
+                    step_module, model, batch, synchronizer, criterion=criterion if args.graph_criterion else None, overlap=overlap)
             else:
                 step_module = train.graph_step_module(step_module, model, batch, synchronizer,
                                                       criterion=criterion if args.graph_criterion else None, overlap=overlap)
@@ -440,19 +465,24 @@ def run_train_step_bench(args, world, rank, local_rank, device):
         except Exception as e:                                  # noqa: BLE001 -- accounting only, never fatal
             print(f"[bench] step roofline probe failed: {type(e).__name__}: {e}", file=sys.stderr)
             step_roofline = {"error": f"{type(e).__name__}: {e}"}   # the line says so instead of dropping the key
-    dp = {"graphed": graphed, "overlap": bool(graphed and overlap and (world > 1 or force_dp)), "dp_group": bool(world > 1 or force_dp)}
+    dp = {"graphed": graphed, "overlap": bool(graphed and overlap and (world > 1 or force_dp)), "dp_group": bool(world > 1 or force_dp),
+          "schedule": schedule, "schedule_reason": schedule_reason}
     return elapsed, timer.summary(), float(loss), n_params, dp, step_roofline, host_routes
 
 
-def parallelism_text(world, graphed, overlap, dp_group):
-    """`config.parallelism` of the train-step line: what carried the gradients between the ranks and how the model ran."""
+def parallelism_text(world, graphed, overlap, dp_group, schedule=None, reason=None):
+    """`config.parallelism` of the train-step line: what carried the gradients between the ranks and how the model ran; for a
+    data-parallel run also how the schedule was chosen (`--dp-schedule auto`: train.choose_dp_schedule's verdict)."""
+    how = ""
+    if dp_group and schedule is not None:
+        how = f"; schedule {schedule}" + (f": {reason}" if reason else "")
     if graphed and dp_group and overlap:
         return (f"dp{world} (bf16 RCCL gradient all-reduce in buckets of arrival order, captured inside the backward graph on a "
                 "communication stream: bucket k travels while autograd computes the earlier layers); model forward/backward "
-                "replayed as HIP graphs")
+                "replayed as HIP graphs" + how)
     if graphed:
         return (f"dp{world} (one flat bf16 RCCL all-reduce of the gradients after the backward graph); "
-                "model forward/backward replayed as HIP graphs")
+                "model forward/backward replayed as HIP graphs" + how)
     return f"dp{world} (DDP: bucketed RCCL gradient all-reduce overlapped with backward); eager launches"
 
 
@@ -465,7 +495,7 @@ def newest_traffic_file():
 
 def pmc_traffic(kernel_key, args):
     """HBM bytes per launch (fetch + write) of the dominant kernel from the committed rocprofv3 --pmc passes of THIS round's
-    kernels (the newest profiles/r0N_final_traffic.json, written by tools/gpu_final_r03.sh: separate FETCH_SIZE / WRITE_SIZE runs with
+    kernels (the newest profiles/r0N_final_traffic.json, written by tools/gpu_profiles_r06.sh: separate FETCH_SIZE / WRITE_SIZE runs with
     --kernel-trace only, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  A recorded value, not measured by this
     run: it is only reported when the file names the same kernels the call ran (a kernel revision that renames or
     replaces them makes the key `null` instead of quoting stale bytes) and the configuration matches."""
@@ -528,7 +558,7 @@ def emit(args, world, elapsed, kern, lib, workload_text, parallelism, cpu_calls,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": pmc_traffic(dominant, args),
-            "traffic_source": "recorded: %s (rocprofv3 --pmc passes of the same kernels, tools/gpu_final_r03.sh); null when "
+            "traffic_source": "recorded: %s (rocprofv3 --pmc passes of the same kernels, tools/gpu_profiles_r06.sh); null when "
                               "no profile of the kernels that ran is committed" % (
                                   os.path.relpath(newest_traffic_file(), ROOT) if newest_traffic_file() else "no profiles/r0N_final_traffic.json"),
             "algorithmic_bytes_per_launch": kd["bytes"],
@@ -847,9 +877,12 @@ def main():
     ap.add_argument("--msda-fwd-cell", action="store_true",
                     help="EXPERIMENT: the encoder's fused MSDA forward through cell_forward_kernel (LDS windows + matrix cores); "
                          "not validated on hardware, never the default")
-    ap.add_argument("--dp-overlap", action="store_true", default=os.environ.get("RLIPV2_DP_OVERLAP", "0") == "1",
-                    help="data-parallel runs: bucketed gradient all-reduce captured inside the backward graph (overlapped "
-                         "with the backward pass) instead of one flat all-reduce after it; off until verified on >= 2 GPUs")
+    ap.add_argument("--dp-schedule", default="auto", choices=["auto", "flat", "overlapped"],
+                    help="data-parallel runs, how the gradients travel: overlapped = bucketed all-reduce captured inside the "
+                         "backward graph (reference: DDP, main.py:515-517), flat = one all-reduce after it, auto (default) = "
+                         "overlapped iff captured collectives replay on all ranks and the first overlapped step's loss and "
+                         "gradient norm equal the flat step's to 1e-3, else flat; the choice is reported in config.parallelism")
+    ap.add_argument("--dp-overlap", action="store_true", help="the same as --dp-schedule overlapped (older scripts)")
     ap.add_argument("--deterministic", action="store_true",
                     help="MIOpen restricted to deterministic convolution solvers (torch.backends.cudnn.deterministic): the one "
                          "source of run-to-run noise in the step is a MIOpen convolution (tools/nondet_modules.py)")
@@ -934,7 +967,7 @@ def main():
                 + ("; VARIANT padded batch: images of 800x1333 and 736x1100 padded together, padding masks live" if args.padded else "")
                 + ("; VARIANT variable targets: 8 / 6 / 11 triplets per image in rotation, one graph capture per bucket" if args.var_targets else "")
                 + ("; VARIANT eager launches (no HIP graphs)" if not args.graph else "")),
-                 parallelism=parallelism_text(world, dp["graphed"], dp["overlap"], dp["dp_group"]),
+                 parallelism=parallelism_text(world, dp["graphed"], dp["overlap"], dp["dp_group"], dp["schedule"], dp["schedule_reason"]),
                  cpu_calls=lambda: build_msda_step(1, torch.float32, device, 0),
                  probe_steps=2 if graphed else None,
                  probe_note=("HIP events around every MSDA call in 2 eager steps of the same train step run right after "

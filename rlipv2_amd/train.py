@@ -571,6 +571,75 @@ def captured_collective_selftest(device, group=None):
     return bool(int(flag.item()))
 
 
+SCHEDULE_RTOL = 1e-3          # choose_dp_schedule: loss and gradient norm of the overlapped step against the flat step's
+
+
+def choose_dp_schedule(build_step, batch, device, group=None, rtol=SCHEDULE_RTOL, selftest=None, seed=20251004, log=None):
+    """The `auto` gradient schedule of a data-parallel run (reference: DistributedDataParallel's bucketed all-reduce overlapped
+    with the backward pass, main.py:515-517).  The OVERLAPPED schedule (buckets in arrival order, captured inside the backward
+    graph on a communication stream) is taken when
+      (1) this process group's collectives can be captured and replayed at all (`captured_collective_selftest`, on all ranks), and
+      (2) one forward + backward of `batch` on it reproduces the FLAT schedule's step (one all-reduce after the backward graph):
+          loss and norm of the synchronised gradient equal to `rtol`, under the same random state, on every rank;
+    otherwise the flat schedule runs.  Every rank reaches the same decision (MIN all-reduces); no optimiser step is taken and the
+    parameters' `.grad` are left empty.
+
+    `build_step(overlap) -> step`: a GraphedStep / EagerSyncStep-like object on its OWN GradientSynchronizer (`run(samples, text,
+    targets) -> (loss dict, total)`, `parameters()`, `grad_scale`).  All ranks must call this function together.
+    -> (step, "overlapped" | "flat", reason)."""
+    import torch.distributed as dist
+    dev = torch.device(device)
+
+    def agree(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
+
+    def probe(step):
+        params = [p for p in step.parameters() if p.requires_grad]
+        for p in params:
+            p.grad = None
+        torch.manual_seed(seed)                       # (CPU and every device generator: the dropouts draw the same masks twice)
+        _, total = step.run(*batch)
+        grads = [p.grad for p in params if p.grad is not None]
+        sq = torch.stack([g.detach().float().square().sum() for g in grads]).sum() if grads else torch.zeros((), device=dev)
+        out = float(total.detach().float()), float(sq.sqrt()) * float(getattr(step, "grad_scale", 1.0))
+        for p in params:
+            p.grad = None
+        return out
+
+    cpu_state = torch.get_rng_state()
+    cuda_state = torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None
+    try:
+        can = agree((selftest or captured_collective_selftest)(device, group))
+        flat = build_step(False)
+        if not can:
+            return flat, "flat", "the group's collectives cannot be captured into a graph here (self-test)"
+        loss_f, norm_f = probe(flat)
+        over, why = None, None
+        try:
+            over = build_step(True)
+        except Exception as e:                                  # noqa: BLE001 -- the flat schedule is always available
+            why = f"the overlapped step could not be built: {type(e).__name__}: {e}"
+        if not agree(over is not None):
+            return flat, "flat", why or "the overlapped step could not be built on another rank"
+        loss_o, norm_o = probe(over)
+        same = (loss_o == loss_o and norm_o == norm_o and abs(loss_o - loss_f) <= rtol * max(abs(loss_f), 1e-12)
+                and abs(norm_o - norm_f) <= rtol * max(norm_f, 1e-12))
+        if log is not None:
+            log(f"[dp schedule] flat: loss {loss_f:.6g}, gradient norm {norm_f:.6g}; overlapped: loss {loss_o:.6g}, "
+                f"gradient norm {norm_o:.6g} -> {'equal' if same else 'DIFFERENT'} at rtol {rtol:g} on this rank")
+        if agree(same):
+            return over, "overlapped", f"captured collectives replay and its first step equals the flat schedule's to {rtol:g}"
+        del over
+        return flat, "flat", (f"the overlapped step differs from the flat one (loss {loss_o:.6g} vs {loss_f:.6g}, gradient norm "
+                              f"{norm_o:.6g} vs {norm_f:.6g})" if not same else "the overlapped step differs on another rank")
+    finally:
+        torch.set_rng_state(cpu_state)
+        if cuda_state is not None:
+            torch.cuda.set_rng_state(cuda_state, dev)
+
+
 def broadcast_parameters(module, src=0):
     """Rank `src`'s parameters and buffers to every rank (what DistributedDataParallel does when it wraps)."""
     import torch.distributed as dist

@@ -26,6 +26,12 @@ def test_parallelism_text(world):
     assert bench.parallelism_text(world, graphed=True, overlap=True, dp_group=False) == bench.parallelism_text(world, True, False, False)
     eager = bench.parallelism_text(world, graphed=False, overlap=True, dp_group=True)
     assert eager.startswith(f"dp{world} (DDP") and "eager" in eager
+    # `--dp-schedule auto`: the line says which schedule ran and why (train.choose_dp_schedule's verdict)
+    auto = bench.parallelism_text(world, True, True, True, schedule="auto", reason="captured collectives replay and its first step equals the flat schedule's to 0.001")
+    assert auto.startswith(f"dp{world} (bf16 RCCL gradient all-reduce in buckets") and auto.endswith("; schedule auto: captured collectives replay and its first step equals the flat schedule's to 0.001")
+    fell = bench.parallelism_text(world, True, False, True, schedule="auto", reason="the overlapped step differs from the flat one (loss 1 vs 2, gradient norm 3 vs 4)")
+    assert fell.startswith(f"dp{world} (one flat") and "schedule auto: the overlapped step differs" in fell
+    assert "schedule" not in bench.parallelism_text(world, True, False, False, schedule="auto")      # no process group: nothing to choose
 
 
 def test_emit_of_a_multi_rank_line_needs_nothing_from_the_step_function(monkeypatch, capsys):
@@ -384,7 +390,7 @@ def test_promotion_report_reads_an_experiments_object(tmp_path, capsys):
     assert "PROMOTE   records route (records)" in capsys.readouterr().out
 
 
-@pytest.mark.parametrize("script", ["gpu_first_r05.sh", "gpu_quick_r05.sh", "gpu_reopen_r05.sh", "gpu_final_r03.sh", "gpu_ab.sh"])
+@pytest.mark.parametrize("script", ["gpu_triage_r06.sh", "gpu_profiles_r06.sh", "gpu_ab.sh"])
 def test_gpu_session_scripts_parse_and_name_existing_files(script):
     """the scripts of the next GPU session cannot be run here; at least they must parse and every repository file they name
     (tools/*.py, tests/*.py, bench.py) must exist"""
@@ -395,3 +401,57 @@ def test_gpu_session_scripts_parse_and_name_existing_files(script):
     text = open(path).read()
     for rel in set(re.findall(r"\b((?:tools|tests)/[\w/]+\.(?:py|sh))\b", text)) | ({"bench.py"} if "bench.py" in text else set()):
         assert os.path.exists(os.path.join(ROOT, rel)), f"{script} names {rel}, which does not exist"
+
+
+def test_triage_families_cover_every_never_run_kernel_within_the_budget():
+    """tools/gpu_triage_r06.py: every kernel the manifest records as never run on hardware belongs to exactly one family (one child
+    process group + one verdict line each), the families' GPU timeouts add up to <= 20 minutes, the order is (default path after
+    promotion) first, and every test file / tool a family names exists"""
+    import re
+    from tools import gpu_triage_r06 as T
+    claimed, unclaimed = T.assign()
+    assert unclaimed == [], unclaimed
+    assert sum(len(v) for v in claimed.values()) == len(T.never_run_kernels()) > 0
+    assert sum(f["timeout"] for f in T.FAMILIES) <= T.BUDGET_S == 1200
+    flags = [f["default_after_promotion"] for f in T.FAMILIES]
+    assert flags == sorted(flags, reverse=True)                      # promotable families first
+    for f in T.FAMILIES:
+        assert f["gpu"] and f["emu"], f["name"]
+        for cmd, _ in f["gpu"] + f["emu"]:
+            for tok in cmd:
+                if re.fullmatch(r"(tests|tools)/[\w/]+\.py", tok):
+                    assert os.path.exists(os.path.join(ROOT, tok)), (f["name"], tok)
+        if f["kernels"]:
+            assert claimed[f["name"]], f"{f['name']}: no never-run kernel matches {f['kernels']}"
+
+
+def test_triage_survives_failing_hanging_and_crashing_children(tmp_path, monkeypatch, capsys):
+    from tools import gpu_triage_r06 as T
+    py = sys.executable
+    fams = [dict(name="ok", row="a1", default_after_promotion=True, what="w", kernels=[], timeout=30,
+                 gpu=[([py, "-c", "print('fine')"], {})], emu=[([py, "-c", "print('fine')"], {})]),
+            dict(name="fails", row="a2", default_after_promotion=True, what="w", kernels=[], timeout=30,
+                 gpu=[([py, "-c", "raise SystemExit(3)"], {}), ([py, "-c", "print('second child still runs')"], {})], emu=[]),
+            dict(name="hangs", row="a2", default_after_promotion=False, what="w", kernels=[], timeout=2,
+                 gpu=[([py, "-c", "import time; time.sleep(600)"], {})], emu=[]),
+            dict(name="segfaults", row="f3", default_after_promotion=False, what="w", kernels=[], timeout=30,
+                 gpu=[([py, "-c", "import os, signal; os.kill(os.getpid(), signal.SIGSEGV)"], {})], emu=[])]
+    monkeypatch.setattr(T, "FAMILIES", fams)
+    monkeypatch.setattr(T, "never_run_kernels", lambda: [])
+    monkeypatch.setattr(T, "device_alive", lambda env, log: True)
+    rc = T.main(["--out", str(tmp_path)])
+    rep = json.load(open(tmp_path / "triage.json"))
+    got = {r["family"]: r["verdict"] for r in rep["families"]}
+    assert got == {"ok": "PASS", "fails": "FAIL", "hangs": "TIMEOUT", "segfaults": "FAIL"} and rc == 1
+    assert len(rep["families"][1]["steps"]) == 2                      # a failing child does not stop its family
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("TRIAGE ")]
+    assert len(lines) == 4 and "family=hangs verdict=TIMEOUT" in lines[2]
+    # a device that does not answer after a family: the rest is skipped, and said so
+    monkeypatch.setattr(T, "device_alive", lambda env, log: "segfaults" not in log and "hangs" not in log)
+    T.main(["--out", str(tmp_path)])
+    got = [r["verdict"] for r in json.load(open(tmp_path / "triage.json"))["families"]]
+    assert got == ["PASS", "FAIL", "DEVICE-LOST", "SKIPPED"]
+    # the dry run uses the lane-model commands
+    monkeypatch.setattr(T, "device_alive", lambda env, log: (_ for _ in ()).throw(AssertionError("no GPU in a dry run")))
+    T.main(["--dry-run", "--only", "ok", "--out", str(tmp_path)])
+    assert json.load(open(tmp_path / "triage_dry_run.json"))["families"][0]["verdict"] == "PASS"

@@ -387,3 +387,80 @@ def test_graphed_step_redelivers_gradients_somebody_cleared():
     g.params[0].grad = None                                          # the sampled ones are noticed at once
     g._deliver()
     assert g.params[0].grad is g.static_grads[0]
+
+
+def _schedule_worker(rank, world, port, out_dir, case):
+    """train.choose_dp_schedule (bench.py --dp-schedule auto) on two gloo ranks: the decision path itself -- self-test verdict,
+    flat probe, overlapped probe, comparison, agreement -- with EagerSyncStep standing in for the captured steps (HIP graphs need
+    a GPU; the eager bucketed schedule issues the same collectives and runs on any backend)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    model, crit, train = _build()
+    batch = _batch(train, 2, seed=100 + rank)
+    step = train.ParSeDATrainStep(model)
+    train.freeze_parameters_without_gradient(step, crit, batch)
+    params = [p for p in step.parameters() if p.requires_grad]
+    built = []
+
+    def build_step(overlap):
+        built.append(overlap)
+        sync = train.GradientSynchronizer(params, bucket_bytes=1 << 20)
+        s = train.EagerSyncStep(step, crit, sync, overlap=overlap)
+        if overlap:                                   # (a GraphedStep plans in its constructor: rank 0's arrival order for all)
+            s.run(*batch)
+            sync.plan_collectively(s.arrival)
+            assert sync.planned and len(sync.buckets) >= 2
+            if case == "overlapped_wrong_on_rank1" and rank == 1:
+                real = s.run
+
+                def wrong(*b):                        # a schedule that loses a bucket's worth of gradient on ONE rank
+                    out = real(*b)
+                    for p in params[:40]:
+                        if p.grad is not None:
+                            p.grad.mul_(0.0)
+                    return out
+                s.run = wrong
+        return s
+
+    selftest = {"agree": lambda device, group=None: True,
+                "overlapped_wrong_on_rank1": lambda device, group=None: True,
+                "selftest_fails_on_rank1": lambda device, group=None: rank == 0,
+                "real_selftest_on_gloo": None}[case]
+    before = torch.get_rng_state().clone()
+    logs = []
+    chosen, schedule, reason = train.choose_dp_schedule(build_step, batch, "cpu", selftest=selftest, log=logs.append)
+    assert torch.equal(before, torch.get_rng_state()) and all(p.grad is None for p in params)
+    # the chosen step works: its synchronised gradient is the average of the ranks' own gradients
+    out = step(*batch)
+    local = torch.autograd.grad(crit.weighted_sum(crit(out, batch[2])), params, allow_unused=True)
+    flat = torch.cat([(torch.zeros_like(p) if g is None else g).reshape(-1) for p, g in zip(params, local)])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    chosen.run(*batch)
+    got = torch.cat([p.grad.reshape(-1) for p in params]) * chosen.grad_scale
+    err = float((got - sum(both) / world).abs().max()) / float((sum(both) / world).abs().max())
+    torch.save({"schedule": schedule, "reason": reason, "built": built, "overlap": bool(chosen.overlap), "err": err, "logs": logs},
+               os.path.join(out_dir, f"schedule_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["agree", "overlapped_wrong_on_rank1", "selftest_fails_on_rank1", "real_selftest_on_gloo"])
+def test_auto_gradient_schedule_decision_two_ranks(tmp_path, case):
+    """the schedule is `auto` -- overlapped iff captured collectives replay on ALL ranks and
+    the first overlapped step's loss and gradient norm equal the flat schedule's to 1e-3 on ALL ranks, else flat; both ranks
+    always reach the same decision, and the chosen step delivers the average of the ranks' gradients."""
+    port = 29500 + os.getpid() % 1000 + 23 + ["agree", "overlapped_wrong_on_rank1", "selftest_fails_on_rank1", "real_selftest_on_gloo"].index(case)
+    mp.spawn(_schedule_worker, args=(2, port, str(tmp_path), case), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"schedule_{r}.pt")) for r in range(2))
+    assert r0["schedule"] == r1["schedule"] and r0["overlap"] == r1["overlap"]
+    assert r0["err"] < 1e-5 and r1["err"] < 1e-5, (r0["err"], r1["err"])
+    if case == "agree":
+        assert r0["schedule"] == "overlapped" and r0["overlap"] and r0["built"] == [False, True] == r1["built"]
+        assert "equal" in r0["logs"][0] and "equal" in r1["logs"][0]
+    elif case == "overlapped_wrong_on_rank1":
+        assert r0["schedule"] == "flat" and not r0["overlap"] and r0["built"] == [False, True]
+        assert "another rank" in r0["reason"] and "differs from the flat one" in r1["reason"]
+    else:                                             # no capture -> the overlapped step is never even built
+        assert r0["schedule"] == "flat" and r0["built"] == [False] == r1["built"] and "self-test" in r0["reason"]

@@ -9,6 +9,8 @@ Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_
   cell 2-4   cell_backward_kernel<., MODE>: geometry once per quad + operand swap | + loads up front, scalar level starts |
              mode 3 without the swap (the last two arms only with --all)                                  (reference work: ms_deform_im2col_cuda.cuh:87-159, 301-403)
   patch multi   patch_dest_multi_kernel (mask-word prefetch not in a branch)
+  patch cellg   (round 6) that kernel reading grad_out rows from a cell-major copy -- no query decode per candidate, neighbouring
+                candidates share 128-byte lines; the copy kernel's time is part of the arm
   records    the "records" route (csrc/msda_cell_forward.inc EMIT + csrc/msda_cell_records.inc): the forward leaves per-sample
              records / window tables / patch masks, the backward runs no geometry and no binning -- fused call, forward and
              backward times against the product kernels, gradients bit for bit                                  (same lines)
@@ -38,8 +40,11 @@ ARMS = [("default", {}),
         ("cell 2 (geometry once per quad + operand swap)", {"RLIPV2_CELL_SHARED": "2"}),
         ("patch multi", {"RLIPV2_PATCH_MULTI": "1"}),
         ("cell 4 (3 without swap)", {"RLIPV2_CELL_SHARED": "4"}),
-        ("cell 3 + patch multi", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_MULTI": "1"})]
-KEYS = ("RLIPV2_CELL_SHARED", "RLIPV2_PATCH_REPS", "RLIPV2_PATCH_MULTI")
+        ("cell 3 + patch multi", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_MULTI": "1"}),
+        # round 6: the patch pass reads grad_out rows from a cell-major copy (grad_out_cells_kernel + patch_dest_multi_kernel<., ., true>)
+        ("patch cellg", {"RLIPV2_PATCH_CELLG": "1"}),
+        ("cell 3 + patch cellg", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_CELLG": "1"})]
+KEYS = ("RLIPV2_CELL_SHARED", "RLIPV2_PATCH_REPS", "RLIPV2_PATCH_MULTI", "RLIPV2_PATCH_CELLG")
 
 
 def digest(t):
@@ -338,7 +343,19 @@ def main(per_child_timeout=45, budget_s=150):
         shutil.rmtree(tmp_dir, ignore_errors=True)            # (also when the parent is interrupted: ~300 MB of memory-backed file)
 
 
-def _main(tmp_dir, per_child_timeout, budget_s):
+def main_arms(per_child_timeout=60):
+    """`--arms`: every backward arm of the ablation build against the default arm, nothing else (tools/gpu_triage_r06.py's
+    family `backward_arms`).  Builds the ablation library first if it is missing (hipcc is on the GPU box too)."""
+    if not os.path.exists(ABLATION_LIB):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rlipv2_amd", "csrc"), "-j8", "ablation"], timeout=900)
+    tmp_dir = tempfile.mkdtemp(prefix="rlipv2_experiments_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        return _main(tmp_dir, per_child_timeout, 3600, arms_only=True)
+    finally:
+        shutil.rmtree(tmp_dir, ignore_errors=True)
+
+
+def _main(tmp_dir, per_child_timeout, budget_s, arms_only=False):
     """parent: one child per arm / kernel, most informative first; nothing is started after `budget_s` seconds and no child may
     run past the deadline (bench.py's default run must stay within minutes); `--all`: no budget, every arm"""
     everything = "--all" in sys.argv
@@ -376,6 +393,12 @@ def _main(tmp_dir, per_child_timeout, budget_s):
                 elif k == 0:
                     out[case]["accepted"] = True
         arms[name] = out
+    if arms_only:
+        for k in range(len(ARMS)):
+            arm(k)
+        report["encoder_backward_arms"] = arms if have_arms else {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
+        report["wall_s"] = round(time.time() - t0, 1)
+        return report
     # order = value of the evidence: the default pair, the records route (kernel level, then -- only if its gradients are the product
     # kernels' bit for bit -- the whole train step with it), the decoders' route, the most complete cell arm, the other kernels
     arm(0)
@@ -410,7 +433,12 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "--stp":
         child_stp()
     else:
-        rep = main()
+        rep = main_arms() if "--arms" in sys.argv else main()
         for name, v in rep.get("encoder_backward_arms", {}).items():
             print(f"{name:36s} {json.dumps(v)}", file=sys.stderr)
         print(json.dumps(rep))
+        if "--arms" in sys.argv:       # (the triage reads the exit code: every arm ran and was accepted against the default arm)
+            arms = rep.get("encoder_backward_arms", {})
+            ok = bool(arms) and "error" not in arms and all(
+                "error" not in v and all(v[c].get("accepted") for c in ("b0", "fused")) for v in arms.values())
+            sys.exit(0 if ok else 1)

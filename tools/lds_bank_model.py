@@ -9,7 +9,7 @@ Prints, per layout, the conflict degree (cycles per lane group; 1 = conflict-fre
     (first version) vs the odd group on the other half (as built), over random windows and sample positions.
 
 The guide warns that the transposing read has further conflict classes; the counters (SQ_LDS_BANK_CONFLICT) have the last word
-(tools/gpu_reopen_r05.sh collects them).  CPU only.   usage: python tools/lds_bank_model.py
+(tools/gpu_triage_r06.sh collects them).  CPU only.   usage: python tools/lds_bank_model.py
 """
 import numpy as np
 

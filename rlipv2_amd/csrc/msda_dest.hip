@@ -130,55 +130,80 @@ __device__ __forceinline__ void source_tile(const DestPlan &pl, const int64_t *_
 // ------------------------------------------------------------------------------------------------------------------
 // bin_kernel
 // ------------------------------------------------------------------------------------------------------------------
+// The body of one item = one (image, source tile, head) as a MACRO over the item index: bin_kernel (ITEM = blockIdx.x) compiles
+// from exactly the tokens it always had -- its device code is pinned to a hardware run (tests/test_isa_manifest.py) --, the
+// ablation build's bin_queue_kernel strides over the items with the same text.
+#define MSDA_BIN_ITEM(ITEM) \
+    const int tid = threadIdx.x;                                                                                      \
+    const int m = (ITEM) % M;                                                                                         \
+    const int s = ((ITEM) / M) % pl.Ts;                                                                               \
+    const int n = (ITEM) / (M * pl.Ts);                                                                               \
+    for (int i = tid; i < pl.Td * 8; i += 256) bmask[i] = 0u;                                                         \
+    int q0, pitch, rows, cols;                                                                                        \
+    source_tile(pl, starts, s, q0, pitch, rows, cols);                                                                \
+    __syncthreads();                                                                                                  \
+    /* 8 lanes read the 128 bytes of one (query, head): lane c holds points (2c & 3, +1) of level c / 2 */            \
+    const int chunk = tid & 7, l = chunk >> 1;                                                                        \
+    const int H = pl.H[l], W = pl.W[l], txl = pl.tx[l], tb = pl.tbase[l];                                             \
+_Pragma("unroll 2")                                                                                                   \
+    for (int pass = 0; pass < 8; ++pass) {                                                                            \
+        const int ql = pass * 32 + (tid >> 3);                                                                        \
+        const int qy = ql >> 4, qx = ql & 15;                                                                         \
+        const int q = pl.tiled ? q0 + qy * pitch + qx : q0 + ql;                                                      \
+        const bool live = pl.tiled ? (qy < rows && qx < cols) : (q < Lq);                                             \
+        if (!live) continue;                                                                                          \
+        const float4 v = reinterpret_cast<const float4 *>(loc)[(((long)n * Lq + q) * M + m) * 8 + chunk];             \
+        const uint32_t bit = 1u << (ql & 31);                                                                         \
+        const int word = ql >> 5;                                                                                     \
+_Pragma("unroll")                                                                                                     \
+        for (int k = 0; k < 2; ++k) {                                                                                 \
+            const Foot f = footprint(k ? v.z : v.x, k ? v.w : v.y, H, W);                                             \
+            if (!f.inside) continue;                                                                                  \
+            /* the (up to) four tiles under the 2x2 footprint */                                                      \
+            const int y0 = max(f.h_low, 0), y1 = min(f.h_low + 1, H - 1);                                             \
+            const int x0 = max(f.w_low, 0), x1 = min(f.w_low + 1, W - 1);                                             \
+            const int ta = pl.th == 8 ? y0 >> 3 : y0 >> 4, tb_ = pl.th == 8 ? y1 >> 3 : y1 >> 4, tc = x0 >> 4, td = x1 >> 4; \
+            atomicOr(&bmask[(tb + ta * txl + tc) * 8 + word], bit);                                                   \
+            if (td != tc) atomicOr(&bmask[(tb + ta * txl + td) * 8 + word], bit);                                     \
+            if (tb_ != ta) {                                                                                          \
+                atomicOr(&bmask[(tb + tb_ * txl + tc) * 8 + word], bit);                                              \
+                if (td != tc) atomicOr(&bmask[(tb + tb_ * txl + td) * 8 + word], bit);                                \
+            }                                                                                                         \
+        }                                                                                                             \
+    }                                                                                                                 \
+    __syncthreads();                                                                                                  \
+    /* masks[(n, m)][destination tile][source tile][8 words] */                                                       \
+    const long nm = (long)n * M + m;                                                                                  \
+    for (int i = tid; i < pl.Td * 8; i += 256)                                                                        \
+        masks[((nm * pl.Td + (i >> 3)) * pl.Ts + s) * 8 + (i & 7)] = bmask[i];                                        \
+    do { } while (0)
 __global__ __launch_bounds__(256) void bin_kernel(DestPlan pl, const int64_t *__restrict__ starts,
                                                   const float *__restrict__ loc, int M, int Lq,
                                                   uint32_t *__restrict__ masks, const int *__restrict__ gate)
 {
     MSDA_DYNAMIC_LDS_PLAIN(uint32_t, bmask);          // [Td][8]
     if (gate && *gate == 0) return;                   // the patch pass of msda_patch.hip has taken the call
-    const int tid = threadIdx.x;
-    const int m = blockIdx.x % M;
-    const int s = (blockIdx.x / M) % pl.Ts;
-    const int n = blockIdx.x / (M * pl.Ts);
-    for (int i = tid; i < pl.Td * 8; i += 256) bmask[i] = 0u;
-    int q0, pitch, rows, cols;
-    source_tile(pl, starts, s, q0, pitch, rows, cols);
-    __syncthreads();
-    // 8 lanes read the 128 bytes of one (query, head): lane c holds points (2c & 3, +1) of level c / 2
-    const int chunk = tid & 7, l = chunk >> 1;
-    const int H = pl.H[l], W = pl.W[l], txl = pl.tx[l], tb = pl.tbase[l];
-#pragma unroll 2
-    for (int pass = 0; pass < 8; ++pass) {
-        const int ql = pass * 32 + (tid >> 3);
-        const int qy = ql >> 4, qx = ql & 15;
-        const int q = pl.tiled ? q0 + qy * pitch + qx : q0 + ql;
-        const bool live = pl.tiled ? (qy < rows && qx < cols) : (q < Lq);
-        if (!live) continue;
-        const float4 v = reinterpret_cast<const float4 *>(loc)[(((long)n * Lq + q) * M + m) * 8 + chunk];
-        const uint32_t bit = 1u << (ql & 31);
-        const int word = ql >> 5;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const Foot f = footprint(k ? v.z : v.x, k ? v.w : v.y, H, W);
-            if (!f.inside) continue;
-            // the (up to) four tiles under the 2x2 footprint
-            const int y0 = max(f.h_low, 0), y1 = min(f.h_low + 1, H - 1);
-            const int x0 = max(f.w_low, 0), x1 = min(f.w_low + 1, W - 1);
-            const int ta = pl.th == 8 ? y0 >> 3 : y0 >> 4, tb_ = pl.th == 8 ? y1 >> 3 : y1 >> 4, tc = x0 >> 4, td = x1 >> 4;
-            atomicOr(&bmask[(tb + ta * txl + tc) * 8 + word], bit);
-            if (td != tc) atomicOr(&bmask[(tb + ta * txl + td) * 8 + word], bit);
-            if (tb_ != ta) {
-                atomicOr(&bmask[(tb + tb_ * txl + tc) * 8 + word], bit);
-                if (td != tc) atomicOr(&bmask[(tb + tb_ * txl + td) * 8 + word], bit);
-            }
-        }
-    }
-    __syncthreads();
-    // masks[(n, m)][destination tile][source tile][8 words]
-    const long nm = (long)n * M + m;
-    for (int i = tid; i < pl.Td * 8; i += 256)
-        masks[((nm * pl.Td + (i >> 3)) * pl.Ts + s) * 8 + (i & 7)] = bmask[i];
+    MSDA_BIN_ITEM(blockIdx.x);
 }
+
+#ifdef MSDA_ABLATION
+// Arm RLIPV2_DEST_QUEUE (round 6): the gated launches of the sorting fallback with a FIXED grid whose
+// workgroups stride over the items -- a launch that finds its gate word zero is <= 512 empty workgroups instead of one per item
+// (13.7 k for the kernels of an N = 4 encoder call).  Same item bodies, same results.
+__global__ __launch_bounds__(256) void bin_queue_kernel(DestPlan pl, const int64_t *__restrict__ starts,
+                                                        const float *__restrict__ loc, int M, int Lq,
+                                                        uint32_t *__restrict__ masks, const int *__restrict__ gate, int items)
+{
+    MSDA_DYNAMIC_LDS_PLAIN(uint32_t, bmask);
+    if (gate && *gate == 0) return;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        {
+            MSDA_BIN_ITEM(item);
+        }
+        __syncthreads();                              // the table is zeroed again by the next item
+    }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // dest_kernel
@@ -584,6 +609,30 @@ __global__ __launch_bounds__(Geo<TH>::kThreads, WAVES) void dest_kernel(
 }
 
 // sums the partial tiles of a split level in part order and writes the rows
+// (the item body as a macro over the item index, for the same reason as MSDA_BIN_ITEM: combine_kernel keeps its tokens)
+#define MSDA_COMBINE_ITEM(ITEM) \
+    const int NM = N * M;                                                                                             \
+    const int nm = (ITEM) % NM, t = (ITEM) / NM;                                                                      \
+    int l = 0;                                                                                                        \
+_Pragma("unroll")                                                                                                     \
+    for (int k = 0; k < kL; ++k) l = (pl.cbase[k] >= 0 && t >= pl.cbase[k] && t < pl.cbase[k] + pl.tx[k] * pl.ty[k]) ? k : l; \
+    const int d = t - pl.cbase[l];                                                                                    \
+    const int nparts = pl.parts[l];                                                                                   \
+    const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;                                                          \
+    constexpr int kPix = Geo<TH>::kPix;                                                                               \
+    const int y = (d / pl.tx[l]) * TH + (grp >> 4), x = (d % pl.tx[l]) * kTile + (grp & 15);                          \
+    if (y >= pl.H[l] || x >= pl.W[l]) return;                                                                         \
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                                                          \
+    for (int j = 0; j < nparts; ++j) {                                                                                \
+        float v[8];                                                                                                   \
+        Vec8<float>::load(partials + (((size_t)(pl.pbase[l] + d * nparts + j) * NM + nm) * kPix + grp) * kD + sub * 8, v); \
+_Pragma("unroll")                                                                                                     \
+        for (int k = 0; k < 8; ++k) acc[k] += v[k];                                                                   \
+    }                                                                                                                 \
+    const int n = nm / M, m = nm % M;                                                                                 \
+    const long pix = (long)n * S + (long)starts[l] + (long)y * pl.W[l] + x;                                           \
+    store_out8<OT>(g_value + (pix * M + m) * kD + sub * 8, acc);                                                      \
+    do { } while (0)
 template <typename OT, int TH>
 __global__ __launch_bounds__(Geo<TH>::kThreads) void combine_kernel(DestPlan pl, const int64_t *__restrict__ starts,
                                                            const float *__restrict__ partials,
@@ -591,28 +640,23 @@ __global__ __launch_bounds__(Geo<TH>::kThreads) void combine_kernel(DestPlan pl,
                                                            const int *__restrict__ gate)
 {
     if (gate && *gate == 0) return;
-    const int NM = N * M;
-    const int nm = blockIdx.x % NM, t = blockIdx.x / NM;
-    int l = 0;
-#pragma unroll
-    for (int k = 0; k < kL; ++k) l = (pl.cbase[k] >= 0 && t >= pl.cbase[k] && t < pl.cbase[k] + pl.tx[k] * pl.ty[k]) ? k : l;
-    const int d = t - pl.cbase[l];
-    const int nparts = pl.parts[l];
-    const int grp = threadIdx.x >> 2, sub = threadIdx.x & 3;
-    constexpr int kPix = Geo<TH>::kPix;
-    const int y = (d / pl.tx[l]) * TH + (grp >> 4), x = (d % pl.tx[l]) * kTile + (grp & 15);
-    if (y >= pl.H[l] || x >= pl.W[l]) return;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < nparts; ++j) {
-        float v[8];
-        Vec8<float>::load(partials + (((size_t)(pl.pbase[l] + d * nparts + j) * NM + nm) * kPix + grp) * kD + sub * 8, v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += v[k];
-    }
-    const int n = nm / M, m = nm % M;
-    const long pix = (long)n * S + (long)starts[l] + (long)y * pl.W[l] + x;
-    store_out8<OT>(g_value + (pix * M + m) * kD + sub * 8, acc);
+    MSDA_COMBINE_ITEM(blockIdx.x);
 }
+
+#ifdef MSDA_ABLATION
+template <typename OT, int TH>
+__global__ __launch_bounds__(Geo<TH>::kThreads) void combine_queue_kernel(DestPlan pl, const int64_t *__restrict__ starts,
+                                                                 const float *__restrict__ partials,
+                                                                 OT *__restrict__ g_value, int N, int S, int M,
+                                                                 const int *__restrict__ gate, int items)
+{
+    if (gate && *gate == 0) return;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        auto one = [&]() __attribute__((always_inline)) { MSDA_COMBINE_ITEM(item); };    // (the body returns for pixels outside the level)
+        one();
+    }
+}
+#endif
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 constexpr int kDestTH = 8;                   // destination tile height in use
@@ -750,6 +794,11 @@ void launch_backward_dest(const Problem &p_in, const Fused *f, const int64_t *sh
         const bool cell = cell_backward_supports(p, shapes_host) && ablation_env("RLIPV2_MSDA_CELL", 1);
         if (cell) launch_cell_backward(p, f, shapes_host, ctl, pws);
         else k1();
+#ifdef MSDA_ABLATION
+        // arm RLIPV2_CELL_FAR_RETURN: the cell kernel's workgroups stop once a far sample has been seen; K1, gated on the same
+        // word, then writes every gradient of the locations / weights (an empty launch on every other call)
+        if (cell && ablation_env("RLIPV2_CELL_FAR_RETURN", 0)) launch_quad_backward_gated(p, f, ctl + 60);
+#endif
         const size_t gco = patch_gcell_offset(p, shapes_host);          // (ablation build: the CELLG arm's copy; else 0)
         launch_patch_dest(p, shapes_host, ctl, pws, out_bf16, cell, gco ? static_cast<unsigned char *>(pws) + gco : nullptr);
         gate = ctl + 60;
@@ -757,6 +806,17 @@ void launch_backward_dest(const Problem &p_in, const Fused *f, const int64_t *sh
         k1();
     }
     RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax));
+#ifdef MSDA_ABLATION
+    const bool queue = gate != nullptr && ablation_env("RLIPV2_DEST_QUEUE", 0) != 0;      // arm: fixed grids striding over the items
+    if (queue) {
+        RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)bin_queue_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDestLdsMax));
+        const int items = p.N * pl.Ts * p.M;
+        hipLaunchKernelGGL(bin_queue_kernel, dim3(items < 512 ? items : 512), dim3(256), pl.Td * 32, p.stream, pl, p.starts,
+                           (const float *)p.loc, p.M, p.Lq, masks, gate, items);
+    } else
+#else
+    const bool queue = false;
+#endif
     hipLaunchKernelGGL(bin_kernel, dim3(p.N * pl.Ts * p.M), dim3(256), pl.Td * 32, p.stream, pl, p.starts,
                        (const float *)p.loc, p.M, p.Lq, masks, gate);
     constexpr int TH = kDestTH, kThreads = Geo<TH>::kThreads;
@@ -781,6 +841,19 @@ void launch_backward_dest(const Problem &p_in, const Fused *f, const int64_t *sh
 #undef MSDA_LAUNCH_DEST
     if (pl.ctiles > 0) {
         const int cgrid = pl.ctiles * p.N * p.M;
+#ifdef MSDA_ABLATION
+        if (queue) {
+            const int qgrid = cgrid < 512 ? cgrid : 512;
+            if (p.dtype == MSDA_BF16 && out_bf16)
+                hipLaunchKernelGGL((combine_queue_kernel<bf16_t, TH>), dim3(qgrid), dim3(kThreads), 0, p.stream, pl, p.starts, partials,
+                                   (bf16_t *)p.g_value, p.N, p.S, p.M, gate, cgrid);
+            else
+                hipLaunchKernelGGL((combine_queue_kernel<float, TH>), dim3(qgrid), dim3(kThreads), 0, p.stream, pl, p.starts, partials,
+                                   (float *)p.g_value, p.N, p.S, p.M, gate, cgrid);
+            return;
+        }
+#endif
+        (void)queue;
         if (p.dtype == MSDA_BF16 && out_bf16)
             hipLaunchKernelGGL((combine_kernel<bf16_t, TH>), dim3(cgrid), dim3(kThreads), 0, p.stream, pl, p.starts, partials,
                                (bf16_t *)p.g_value, p.N, p.S, p.M, gate);

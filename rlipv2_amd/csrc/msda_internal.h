@@ -67,6 +67,9 @@ void launch_quad_forward_fused(const Problem &p, const Fused &f);
 bool coarse_forward_applies(const Problem &p);        // bfloat16, many queries: coarse levels resident in LDS
 void launch_quad_forward_coarse(const Problem &p);
 void launch_quad_backward_reduce_fused(const Problem &p, const Fused &f);   // writes f.g_qproj instead of g_loc / g_aw
+#ifdef MSDA_ABLATION
+void launch_quad_backward_gated(const Problem &p, const Fused *f, const int *gate);   // K1 (+ epilogue with f) iff *gate != 0
+#endif
 
 bool window_supports(const Problem &p, bool backward);
 void launch_window_forward(const Problem &p);

@@ -1148,6 +1148,20 @@ __global__ __launch_bounds__(kCellThreads, 4) void cell_backward_kernel(
     CTS(1);
 
     if (MSDA_DBG(dbg) & 1) return;                                             // ablation: binning only
+#ifdef MSDA_ABLATION
+    // Arm RLIPV2_CELL_FAR_RETURN (round 6): a "far" sample anywhere in the call (as far as this workgroup can
+    // see by now) means the patch pass will return without writing and the sorting pass takes grad_value -- and with this arm a
+    // K1 launch gated on the same word writes EVERY location / weight gradient (launch_quad_backward_gated), so what this
+    // workgroup would compute from here on is overwritten: stop.  One lane reads the word, the workgroup agrees through LDS (a
+    // workgroup must return as a whole: barriers follow).  The final result is a pure function of the input: whether the word
+    // is set at the end of the launch is, and then K1 has written everything.
+    if (dbg & 16) {
+        __shared__ int far_seen;
+        if (tid == 0) far_seen = atomicOr(ctl + kFarWord, 0);
+        __syncthreads();
+        if (far_seen != 0) return;
+    }
+#endif
     // ---- phase 2: the windows of the four levels, smallest first, as long as they fit ----------------------------------
     int wx0[kL], wy0[kL], wpitch[kL], wbase[kL], wcols[kL], wrows[kL];
     {
@@ -1695,7 +1709,7 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
                            p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw, (const bf16_t *)p.grad_out, \
                            p.N, p.S, p.M, p.Lq, vbytes, (float *)p.g_loc, (float *)p.g_aw, f ? f->ref : nullptr,      \
                            (bf16_t *)(f ? f->g_qproj : nullptr), masks, recs, ctl,                                    \
-                           ablation_env("RLIPV2_CELL_DBG", 0));                                                       \
+                           ablation_env("RLIPV2_CELL_DBG", 0) | (ablation_env("RLIPV2_CELL_FAR_RETURN", 0) ? 16 : 0)); \
     } while (0)
 #ifdef MSDA_ABLATION
 #define MSDA_CELL(RD)                                                                                                 \

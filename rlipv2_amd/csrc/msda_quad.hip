@@ -815,6 +815,15 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_shared_kernel(
     int S, int M, int Lq, unsigned value_bytes, float *__restrict__ g_loc, float *__restrict__ g_aw,
     const float *__restrict__ ref, VT *__restrict__ g_qproj)
 {
+    // REFDIM | 8 (ablation build only, launch_quad_backward_gated): the kernel runs only when a gate word is non-zero -- the
+    // fallback of cell_backward_kernel's "far sample: stop here" arm.  The word travels in the pointer argument the instantiation
+    // does not use (g_loc with a geometry epilogue, ref without): the product instantiations' argument list stays what it is.
+    constexpr bool GATED = (REFDIM & 8) != 0;
+    constexpr int RDIM = REFDIM & 7;
+    if (GATED) {
+        const int *gate = RDIM != 0 ? reinterpret_cast<const int *>(g_loc) : reinterpret_cast<const int *>(ref);
+        if (*gate == 0) return;
+    }
     const int t = xcd_block_id() * kBlock + threadIdx.x;
     int qm = t >> 2;
     const int sub = t & 3;
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_shared_kernel(
         if (sub == l) { gla = ra; glb = rb; ga = rw; }
         quad_rotate(la); quad_rotate(lb); quad_rotate(wa);
     }
-    if (REFDIM == 0) {
+    if (RDIM == 0) {
         if (live) {
             float4 *gl4 = reinterpret_cast<float4 *>(g_loc) + (long)qm * 8 + sub * 2;
             gl4[0] = gla;
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void quad_backward_shared_kernel(
             reinterpret_cast<float4 *>(g_aw)[(long)qm * 4 + sub] = ga;
         }
     } else if (live) {          // (a quad is live or dead as a whole; after 4 rotations wa is this lane's level again)
-        constexpr int RD = REFDIM == 0 ? 2 : REFDIM;
+        constexpr int RD = RDIM == 0 ? 2 : RDIM;
         const long row = qm / M;
         const float a[4] = {wa.x, wa.y, wa.z, wa.w};
         float g[4] = {ga.x, ga.y, ga.z, ga.w};
@@ -1099,5 +1108,30 @@ void launch_quad_backward_reduce_fused(const Problem &p, const Fused &f)
     else { if (f.refdim == 2) MSDA_K1_FUSED(bf16_t, 2); else MSDA_K1_FUSED(bf16_t, 4); }
 #undef MSDA_K1_FUSED
 }
+
+#ifdef MSDA_ABLATION
+// K1 (with or without the geometry epilogue) behind a gate word: runs only if *gate != 0 (see quad_backward_shared_kernel)
+void launch_quad_backward_gated(const Problem &p, const Fused *f, const int *gate)
+{
+    const int total_qm = p.N * p.Lq * p.M;
+    const int grid = (int)(((long)total_qm * 4 + kBlock - 1) / kBlock);
+    float *gate_f = reinterpret_cast<float *>(const_cast<int *>(gate));
+#define MSDA_K1_GATED(VT, RD, GLOC, GAW, REF, GQ)                                                                      \
+    hipLaunchKernelGGL((quad_backward_shared_kernel<VT, 4, (RD) | 8>), dim3(grid), dim3(kBlock), 0, p.stream,          \
+                       (const VT *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,            \
+                       (const VT *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), GLOC, GAW, REF, GQ)
+    if (!f) {
+        if (p.dtype == MSDA_F32) MSDA_K1_GATED(float, 0, (float *)p.g_loc, (float *)p.g_aw, (const float *)gate_f, (float *)nullptr);
+        else MSDA_K1_GATED(bf16_t, 0, (float *)p.g_loc, (float *)p.g_aw, (const float *)gate_f, (bf16_t *)nullptr);
+    } else if (p.dtype == MSDA_F32) {
+        if (f->refdim == 2) MSDA_K1_GATED(float, 2, gate_f, (float *)nullptr, f->ref, (float *)f->g_qproj);
+        else MSDA_K1_GATED(float, 4, gate_f, (float *)nullptr, f->ref, (float *)f->g_qproj);
+    } else {
+        if (f->refdim == 2) MSDA_K1_GATED(bf16_t, 2, gate_f, (float *)nullptr, f->ref, (bf16_t *)f->g_qproj);
+        else MSDA_K1_GATED(bf16_t, 4, gate_f, (float *)nullptr, f->ref, (bf16_t *)f->g_qproj);
+    }
+#undef MSDA_K1_GATED
+}
+#endif
 
 }  // namespace msda

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import msda_oracle as O  # noqa: E402  (tests may use the oracle)
 from conftest import boundary_samples, kink_samples, load_golden  # noqa: E402
-from test_cell_forward_emulated import CLANG, bf16_bits, bf16_val  # noqa: E402
+from test_cell_forward_emulated import CLANG, bf16_bits, bf16_val, make_problem  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm clang++ (ext_vector_type) as host compiler")
 
@@ -250,6 +250,65 @@ def test_samples_out_of_reach_take_the_sorting_pass_within_the_same_call(lib):
     close32(ga, ref_ga)
     keep = ~kink_samples(g)
     close32(gl[keep], ref_gl[keep])
+
+
+@pytest.fixture(scope="module")
+def ablation_lib(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("emu_lib_ablation") / "libmsda_emu_ablation.so")
+    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900,
+                   env=dict(os.environ, EMU_DEFINES="-DMSDA_ABLATION"))
+    return EmuLib(so)
+
+
+def test_far_return_arm_hands_every_gradient_to_the_gated_k1(ablation_lib, monkeypatch):
+    """Arm RLIPV2_CELL_FAR_RETURN (round 6; VERDICT r4 item 3e / r5 item 3c, ablation build): on a call with "far" samples the
+    workgroups of cell_backward_kernel stop after their binning phase once the flag is up, and a K1 launch gated on the same word
+    (quad_backward_shared_kernel<., ., REFDIM | 8>) writes every gradient of the locations / weights.  Bar: bit-equal to the route
+    that runs K1 unconditionally (RLIPV2_MSDA_CELL=0: same K1 arithmetic, same sorting pass), whatever the interleaving of the
+    workgroups; on a call WITHOUT far samples the arm changes nothing (the gated launch returns)."""
+    lib = ablation_lib
+    M = 1
+    pyr, starts, S, ref2, value, grad_out, rng = _encoder_problem([(40, 54), (20, 27), (10, 14), (5, 7)], 1, M, seed=31)
+    loc = rng.random((1, S, M, 4, 4, 2)).astype(np.float32)                         # anywhere in the image: far samples
+    aw = rng.random((1, S, M, 4, 4))
+    aw = (aw / aw.sum((-1, -2), keepdims=True)).astype(np.float32)
+    far = dict(value=value, loc=loc, aw=aw, grad_out=grad_out, shapes=pyr, starts=starts)
+    for k in ("RLIPV2_MSDA_CELL", "RLIPV2_CELL_FAR_RETURN"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("RLIPV2_MSDA_CELL", "0")
+    _, gv_k1, gl_k1, ga_k1 = lib.run("quad", "dest", BF16, far)
+    monkeypatch.delenv("RLIPV2_MSDA_CELL")
+    monkeypatch.setenv("RLIPV2_CELL_FAR_RETURN", "1")
+    for _ in range(2):                                                              # (twice: another interleaving of the workgroups)
+        _, gv, gl, ga = lib.run("quad", "dest", BF16, far)
+        # grad_value comes from the sorting pass in both routes.  On the lane-level model that pass is repeatable only to a
+        # bfloat16 rounding: a wave's LDS atomics return their slots in the order the model's lane THREADS arrive (the hardware
+        # serves the lanes of one instruction in lane order: bit-repeatable there, profiles/r03_nondeterminism.txt)
+        assert np.abs(gv - gv_k1).max() <= 2.0 ** -7 * np.abs(gv_k1).max() and (gv != gv_k1).mean() < 1e-3
+        assert np.array_equal(gl.astype(np.float32).view(np.uint32), gl_k1.astype(np.float32).view(np.uint32))
+        assert np.array_equal(ga.astype(np.float32).view(np.uint32), ga_k1.astype(np.float32).view(np.uint32))
+    ref_gv, ref_gl, ref_ga = O.backward(value.astype(np.float64), pyr, starts, loc.astype(np.float64), aw.astype(np.float64),
+                                        grad_out.astype(np.float64))
+    close32(ga, ref_ga)
+    # arm RLIPV2_DEST_QUEUE on top: the sorting fallback's bin / combine launches as fixed grids striding over the items
+    # (bin_queue_kernel, combine_queue_kernel: the item bodies are the product kernels' own text) -- the same grad_value
+    monkeypatch.setenv("RLIPV2_DEST_QUEUE", "1")
+    _, gv_q, gl_q, ga_q = lib.run("quad", "dest", BF16, far)
+    monkeypatch.delenv("RLIPV2_DEST_QUEUE")
+    assert np.abs(gv_q - gv_k1).max() <= 2.0 ** -7 * np.abs(gv_k1).max() and (gv_q != gv_k1).mean() < 1e-3
+    np.testing.assert_allclose(gv_q, ref_gv, rtol=2.0 ** -7, atol=1e-3 * float(np.abs(ref_gv).max()))
+    assert np.array_equal(ga_q.astype(np.float32).view(np.uint32), ga_k1.astype(np.float32).view(np.uint32))
+    # no far sample: the product kernels' results, bit for bit
+    pyr2, starts2, S2, value2, loc2, aw2 = make_problem([(20, 27), (10, 14), (5, 7), (3, 4)], 1, (1.5, 1.5, 1.0, 0.7), seed=11)
+    go2 = bf16_val(bf16_bits(np.random.default_rng(5).standard_normal((1, S2, 32)))).astype(np.float32)
+    near = dict(value=value2, loc=loc2, aw=aw2, grad_out=go2, shapes=pyr2, starts=starts2)
+    monkeypatch.setenv("RLIPV2_DEST_QUEUE", "1")                                     # (both arms: three empty launches of <= 512 workgroups)
+    with_arm = lib.run("quad", "dest", BF16, near)
+    monkeypatch.delenv("RLIPV2_CELL_FAR_RETURN")
+    monkeypatch.delenv("RLIPV2_DEST_QUEUE")
+    without = lib.run("quad", "dest", BF16, near)
+    for a, b in zip(with_arm[1:], without[1:]):                                     # (the patch pass: repeatable on the model too)
+        assert np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
 
 
 def test_plain_b0_signature_without_host_shapes(lib):

@@ -9,7 +9,8 @@ ROOT=$(cd "$HERE/../.." && pwd)
 OUT=${1:-/tmp/libmsda_emu.so}
 CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 TMP=$(mktemp -d)
-FLAGS="-x c++ -std=c++20 -O1 -fPIC -pthread -DMSDA_EMU -I$HERE/stub -I$ROOT/include -Wno-unknown-pragmas -Wno-unused-value"
+# EMU_DEFINES="-DMSDA_ABLATION": the ablation build of the same sources (the experiment arms behind their environment switches)
+FLAGS="-x c++ -std=c++20 -O1 -fPIC -pthread -DMSDA_EMU ${EMU_DEFINES:-} -I$HERE/stub -I$ROOT/include -Wno-unknown-pragmas -Wno-unused-value"
 # EMU_SANITIZE=1: AddressSanitizer + UndefinedBehaviorSanitizer build (global-memory accesses of the kernels against the
 # host allocator's red zones; run python with LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so))
 if [ "${EMU_SANITIZE:-0}" = "1" ]; then FLAGS="$FLAGS -g -fno-omit-frame-pointer -fsanitize=address,undefined -shared-libasan"; SAN="-fsanitize=address,undefined -shared-libasan"; fi

@@ -16,6 +16,8 @@ Arms (ablation build, tools/_build/librlipv2_msda_ablation.so = `make -C rlipv2_
              backward times against the product kernels, gradients bit for bit                                  (same lines)
   step       if (and only if) the records route's gradients are bit-equal: one short bench.py run of the whole train step with it
   fwd cell   cell_forward_kernel (explicit variant "cell" of the product library) against the product forward (.cuh:237-299)
+  uniform    (round 6, `--uniform-arms`) SURVEY 8d input A, uniform locations: the far-return arm (cell kernel stops once a far sample
+             is seen, gated K1 writes the location / weight gradients) and the queue-fed launches of the sorting fallback
   swin       the two Swin routes of round 5 (csrc/window_attention.hip, csrc/layernorm_wide.hip; models/swin/swin_transformer.py:
              262-301, 386-401) at the Swin-L stage-0 shapes against the PyTorch op sequences they replace
 Every backward arm is compared with the default's gradients (64-bit digests of the raw bits, computed on the device, and -- through
@@ -44,7 +46,7 @@ ARMS = [("default", {}),
         # round 6: the patch pass reads grad_out rows from a cell-major copy (grad_out_cells_kernel + patch_dest_multi_kernel<., ., true>)
         ("patch cellg", {"RLIPV2_PATCH_CELLG": "1"}),
         ("cell 3 + patch cellg", {"RLIPV2_CELL_SHARED": "3", "RLIPV2_PATCH_CELLG": "1"})]
-KEYS = ("RLIPV2_CELL_SHARED", "RLIPV2_PATCH_REPS", "RLIPV2_PATCH_MULTI", "RLIPV2_PATCH_CELLG")
+KEYS = ("RLIPV2_CELL_SHARED", "RLIPV2_PATCH_REPS", "RLIPV2_PATCH_MULTI", "RLIPV2_PATCH_CELLG", "RLIPV2_CELL_FAR_RETURN", "RLIPV2_DEST_QUEUE")
 
 
 def digest(t):
@@ -299,6 +301,63 @@ def child_stp():
           flush=True)
 
 
+UNIFORM_ARMS = [("default", {}), ("far return", {"RLIPV2_CELL_FAR_RETURN": "1"}),
+                ("far return + queue-fed fallback", {"RLIPV2_CELL_FAR_RETURN": "1", "RLIPV2_DEST_QUEUE": "1"})]
+
+
+def child_uniform():
+    """SURVEY 8d input A -- UNIFORM sampling locations (the reference's test recipe, models/ops/test.py:38), where every call has
+    "far" samples and takes the sorting fallback: the whole backward of the encoder shape (N = 4, bf16, B0 signature) on the
+    ablation library, once per process with the arm's switches in the environment (round 3: 1 339 us; round 2's kernels 975-1 130).
+    Also timed on model-like locations: what the arm's idle launches cost the normal case."""
+    import torch
+    from rlipv2_amd import msda
+    from tools.msda_inputs import PYRAMID_800x1333, make_inputs
+    from tools.patch_check import timed
+    out = {}
+    for mode in ("uniform", "model"):
+        inp = make_inputs(4, mode=mode, dtype=torch.bfloat16, seed=3)
+        msda.attach_host_shapes(inp["shapes"], PYRAMID_800x1333)
+        a = (inp["value"], inp["shapes"], inp["starts"], inp["loc"], inp["aw"], inp["grad_out"])
+        res = msda.ms_deform_attn_backward(*a, 64)
+        torch.cuda.synchronize()
+        out[mode] = {"digest": [digest(t) for t in res], "finite": all(bool(torch.isfinite(t.float()).all()) for t in res),
+                     "us": round(timed(lambda: msda.ms_deform_attn_backward(*a, 64), iters=10), 1),
+                     "again_equal_bits": [digest(t) for t in msda.ms_deform_attn_backward(*a, 64)] == [digest(t) for t in res]}
+        if ref_file():
+            path = ref_file() + "." + mode
+            if not os.path.exists(path):
+                torch.save([t.cpu() for t in res], path)
+            else:
+                out[mode]["vs_default"] = closeness([t.cpu() for t in res], torch.load(path, weights_only=True))
+    print("RESULT " + json.dumps(out), flush=True)
+
+
+def main_uniform(per_child_timeout=90):
+    """`--uniform-arms`: the three arms of the uniform-location case, each in a child process on the ablation library"""
+    if not os.path.exists(ABLATION_LIB):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rlipv2_amd", "csrc"), "-j8", "ablation"], timeout=900)
+    tmp_dir = tempfile.mkdtemp(prefix="rlipv2_experiments_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        base_env = {k: v for k, v in os.environ.items() if k not in KEYS and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        base_env.update({REF_ENV: os.path.join(tmp_dir, "default_arm.pt"), "RLIPV2_LIB_PATH": ABLATION_LIB})
+        rep = {}
+        for name, env in UNIFORM_ARMS:
+            r = run_child(["--uniform"], dict(base_env, **env), per_child_timeout)
+            for mode in ("uniform", "model"):
+                if isinstance(r.get(mode), dict):
+                    r[mode].pop("digest", None)
+                    v = r[mode].get("vs_default")
+                    # the location / weight gradients come from K1 instead of the cell kernel under "far return" (uniform): within a
+                    # float32 rounding of the formulas; grad_value from the same sorting pass: bit-equal
+                    r[mode]["accepted"] = bool(r[mode]["finite"] and r[mode]["again_equal_bits"] and (
+                        v is None or (v[0]["equal_bits"] and all(x["max_diff_rel_to_max"] <= 2e-5 for x in v[1:]))))
+            rep[name] = r
+        return {"uniform_location_arms": rep}
+    finally:
+        shutil.rmtree(tmp_dir, ignore_errors=True)
+
+
 def run_child(args, env, timeout):
     t0 = time.time()
     try:
@@ -432,6 +491,13 @@ if __name__ == "__main__":
         child_swin()
     elif len(sys.argv) > 1 and sys.argv[1] == "--stp":
         child_stp()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--uniform":
+        child_uniform()
+    elif "--uniform-arms" in sys.argv:
+        rep = main_uniform()
+        print(json.dumps(rep))
+        ok = all("error" not in r and all(r[m].get("accepted") for m in ("uniform", "model")) for r in rep["uniform_location_arms"].values())
+        sys.exit(0 if ok else 1)
     else:
         rep = main_arms() if "--arms" in sys.argv else main()
         for name, v in rep.get("encoder_backward_arms", {}).items():

@@ -42,10 +42,12 @@ FAMILIES = [
          gpu=[(PYTEST + ["-m", "gpu", "tests/test_msda_cell_forward_gpu.py"], {"RLIPV2_TEST_EXPERIMENTAL": "1"}), (X + ["--fwd"], {})],
          emu=[(PYTEST + ["tests/test_cell_forward_emulated.py"], {})], timeout=150),
     dict(name="backward_arms", row="a2", default_after_promotion=True,
-         what="ablation build: cell_backward_kernel modes 2-4, patch_dest_multi_kernel (MULTI, REPS, CELLG + grad_out_cells_kernel)",
+         what="ablation build: cell_backward_kernel modes 2-4, patch_dest_multi_kernel (MULTI, REPS, CELLG + grad_out_cells_kernel); "
+              "uniform locations: far-return + gated K1, queue-fed fallback launches",
          kernels=[],                                                 # (ablation-only instantiations: not in the product manifest)
-         gpu=[(X + ["--arms"], {})],
-         emu=[(PYTEST + ["tests/test_backward_emulated.py"], {})], timeout=270),
+         gpu=[(X + ["--arms"], {}), (X + ["--uniform-arms"], {})],
+         emu=[(PYTEST + ["tests/test_backward_emulated.py"], {}),
+              (PYTEST + ["tests/test_msda_emulated_library.py", "-k", "far_return"], {})], timeout=270),
     dict(name="scaled_optimizer_step", row="e", default_after_promotion=True,
          what="fused AdamW with grad_scale != 1: the data-parallel form of the optimiser step (fused_adamw.hip step_scaled_kernel)",
          kernels=[r"fused_adamw\.hip::.*step_scaled_kernel"],

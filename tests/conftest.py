@@ -14,13 +14,60 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "first_contact(timeout=300): GPU test of device code / a host route that has NEVER executed on "
+                                       "hardware -- runs in a child process with a timeout (a hang or a fault costs that test, not "
+                                       "the suite) and counts as XPASS / XFAIL, not as pass / failure: the code under test is OFF in "
+                                       "the product, the colour of the suite is the product path's")
+
+
+FIRST_CONTACT_CHILD = "RLIPV2_TEST_FIRST_CONTACT_CHILD"
+
+
+def run_isolated(nodeid, timeout, python=sys.executable, extra_env=None):
+    """one test node in a child pytest (own process group, killed as a group on timeout) -> (ok, tail of its output).  The child
+    runs with --runxfail: ITS exit code is the test's real outcome."""
+    import signal
+    import subprocess
+    env = dict(os.environ, **{FIRST_CONTACT_CHILD: "1"}, **(extra_env or {}))
+    proc = subprocess.Popen([python, "-m", "pytest", nodeid, "-q", "-x", "--runxfail", "-p", "no:cacheprovider", "-m", "gpu or not gpu"],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT, env=env, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        return False, f"timed out after {timeout} s (child process group killed)\n" + (out or "")[-1500:]
+    return proc.returncode == 0, (out or "")[-2500:]
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_pyfunc_call(pyfuncitem):
+    m = pyfuncitem.get_closest_marker("first_contact")
+    if m is None or os.environ.get(FIRST_CONTACT_CHILD) == "1":
+        return None                                              # run normally (also: inside the child)
+    ok, tail = run_isolated(pyfuncitem.nodeid, int(m.kwargs.get("timeout", 300)))
+    if not ok:
+        pytest.fail("first contact with the hardware FAILED in the child process:\n" + tail, pytrace=False)
+    return True
+
+
+def pytest_itemcollected(item):
+    # first-contact tests never colour the suite: non-strict xfail (pass -> XPASS, fail -> XFAIL; both are printed with -rxX)
+    m = item.get_closest_marker("first_contact")
+    # (counts=True: isolated, but a failure IS a failure -- never-run code on a default path, e.g. the optimiser step of N > 1 runs)
+    if m is not None and not m.kwargs.get("counts", False) and os.environ.get(FIRST_CONTACT_CHILD) != "1":
+        item.add_marker(pytest.mark.xfail(strict=False, reason="device code / route that has never run on hardware (first contact)"))
 
 
 # Order of the GPU suite = evidence per minute under `pytest -x`: the op-level oracle / golden tests of the
 # hot path first, then the other kernels, the modules, the newest tests, and the whole-bench contract last
 # (one failure in a late, broad test must not hide the op-level parity results).
-GPU_SUITE_ORDER = ["test_msda_gpu", "test_msda_cell_forward_gpu", "test_norm_gpu", "test_linear_gpu", "test_optim_gpu",
-                   "test_modules_gpu", "test_zz_round4_gpu", "test_zz_round5_gpu", "test_bench_contract", "test_zzz_records_gpu"]
+GPU_SUITE_ORDER = ["test_msda_gpu", "test_norm_gpu", "test_linear_gpu", "test_optim_gpu",
+                   "test_modules_gpu", "test_zz_round4_gpu", "test_zz_round5_gpu", "test_bench_contract", "test_zzz_records_gpu",
+                   "test_msda_cell_forward_gpu"]
 
 
 def gpu_suite_rank(nodeid):

@@ -134,7 +134,8 @@ def test_closed_form_of_the_patch_ranges_equals_the_enumeration():
 @pytest.mark.parametrize("N,M", [(4, 8), (1, 1), (8, 8)])
 def test_records_buffer_layout_follows_the_plan(shapes, N, M):
     """msda_records_bytes (the saved state of the records route, include/rlipv2_msda.h) = control block + one window table per
-    (image, head, cell) + 340 x 16 sample records of 16 bytes per cell + the patch pass's masks and group records, as the plan
+    (image, head, cell) + 2-byte sample records ([level][352 query slots][point] per cell: whole 128-byte lines; round 5 stored 16
+    bytes per sample) + the patch pass's masks and group records, as the plan
     sizes them; every query has a slot; the sorting fallback's rebuilt locations / weights fit the workspace the ABI asks for"""
     L = _lib.lib()
     n, p = plan(shapes, N=N, M=M)
@@ -154,7 +155,7 @@ def test_records_buffer_layout_follows_the_plan(shapes, N, M):
     if tail["bin_lds"] > 60 * 1024:                                   # (the forward keeps the cell's mask table in its window region)
         assert got == 0
         return
-    assert got == 256 + items * 128 + items * 340 * 256 + masks + group_records
+    assert got == 256 + items * 128 + items * 4 * 352 * 4 * 2 + masks + group_records
     assert cells * 340 >= S and sum(min(16 >> l, 16) ** 2 for l in range(4)) == 340
     ws = int(L.msda_backward_workspace_bytes(_lib.MSDA_BF16, hs.ctypes.data, *dims))
     assert ws >= N * S * M * 16 * 12

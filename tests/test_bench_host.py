@@ -455,3 +455,17 @@ def test_triage_survives_failing_hanging_and_crashing_children(tmp_path, monkeyp
     monkeypatch.setattr(T, "device_alive", lambda env, log: (_ for _ in ()).throw(AssertionError("no GPU in a dry run")))
     T.main(["--dry-run", "--only", "ok", "--out", str(tmp_path)])
     assert json.load(open(tmp_path / "triage_dry_run.json"))["families"][0]["verdict"] == "PASS"
+
+
+def test_first_contact_tests_run_isolated_and_never_colour_the_suite():
+    """tests/conftest.py: a GPU test marked `first_contact` (device code / host route that has never executed on hardware) runs in a
+    child pytest with a timeout -- a hang or a fault costs that test, not the suite -- and is reported as XPASS / XFAIL: the suite
+    goes on under -x and its exit code stays the product path's."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "first_contact_probe.py"), "-q", "-x", "-rxX",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    out = r.stdout
+    assert r.returncode == 0, out[-3000:]
+    assert "1 passed" in out and "3 xfailed" in out and "1 xpassed" in out, out[-1500:]
+    assert "XPASS tests/first_contact_probe.py::test_probe_passes" in out
+    assert "XFAIL tests/first_contact_probe.py::test_probe_hangs" in out and "XFAIL tests/first_contact_probe.py::test_probe_faults" in out

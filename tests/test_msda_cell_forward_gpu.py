@@ -1,8 +1,9 @@
 """The experimental forward variant MSDA_VARIANT_CELL (csrc/msda_patch.hip: cell_forward_kernel -- per-cell sampling
 windows in LDS, bilinear sums on the matrix cores) against the CPU oracle and against the product forward kernel.
 
-The kernel was written while no GPU was available to the build; until a run has shown it correct it is opt-in here as
-well (RLIPV2_TEST_EXPERIMENTAL=1), so that an unvalidated kernel cannot turn the GPU suite red.  Tolerance: bfloat16
+The kernel was written while no GPU was available to the build and has never run on hardware: every test here is a
+`first_contact` test (tests/conftest.py) -- it runs in a child process with a timeout and is reported as XPASS / XFAIL, so that
+an unvalidated kernel can neither hang nor colour the GPU suite; the file is sorted last.  Tolerance: bfloat16
 output, weights split hi + lo (2^-16 relative) -> the same bar as every other bfloat16 forward kernel of the suite."""
 import os
 import sys
@@ -18,9 +19,7 @@ from conftest import load_golden  # noqa: E402
 from rlipv2_amd import msda  # noqa: E402
 from test_msda_gpu import PYRAMID, bf16_round, random_problem, run_hip  # noqa: E402
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("RLIPV2_TEST_EXPERIMENTAL", "0") != "1",
-                                 reason="experimental kernel: set RLIPV2_TEST_EXPERIMENTAL=1")]
+pytestmark = [pytest.mark.gpu, pytest.mark.first_contact(timeout=300)]
 
 
 def _check(value, shapes, starts, loc, aw):

@@ -106,6 +106,7 @@ def test_full_parseda_bf16_gradients_against_float32_on_rounded_weights():
         assert c >= 0.95, (name, c, r)
 
 
+@pytest.mark.first_contact(timeout=420)
 def test_linked_encoder_layer_equals_the_unlinked_nodes_bf16():
     """DeformableTransformerEncoderLayer in bfloat16 with its two residual blocks linked (the value projection's and the FFN's
     input-gradient GEMMs accumulate into the tensors the fused LayerNorms return; encoder.py / linear.py, round 4) against the
@@ -158,6 +159,7 @@ def test_linked_encoder_layer_equals_the_unlinked_nodes_bf16():
         assert float((a - b).norm()) <= 2e-2 * float(b.norm()) + 1e-3 * biggest, (float((a - b).norm()), float(b.norm()))
 
 
+@pytest.mark.first_contact(timeout=420)
 def test_gradient_links_change_nothing_in_the_train_step_bf16():
     """Whole train step of a small bf16 model (encoder layers with both residual blocks linked, the image memory shared by the
     decoders' value projections: linear.residual_gradient_in_gemm) against the same step with plain autograd sums: same loss,
@@ -201,6 +203,7 @@ def test_gradient_links_change_nothing_in_the_train_step_bf16():
         assert d <= 5e-2 * float(g.norm()) + 1e-3 * biggest, (n, d, float(g.norm()))
 
 
+@pytest.mark.first_contact(timeout=420)
 def test_residual_gradient_in_the_ffn_gemm_matches_the_unlinked_nodes():
     """linear.ffn_residual_norm: norm(x + FFN(x)) with the residual's gradient accumulated by the FFN's last GEMM (beta = 1, in
     place into the tensor the LayerNorm's backward returned) against the same two nodes unlinked (autograd sums the two
@@ -278,6 +281,7 @@ def test_step_cache_keeps_one_off_shapes_eager_and_evicts():
     assert cache.captures == 3 and cache.evictions == 2 and len(cache.graphs) == 1
 
 
+@pytest.mark.first_contact(timeout=420)
 def test_box_head_equals_the_op_sequence():
     """decoder.box_head (one launch of the refinement kernel forward, sigmoid's backward) against
     sigmoid(delta + inverse_sigmoid(ref)) as PyTorch ops: values within 1e-6, gradients equal after the cast back."""

@@ -29,6 +29,7 @@ def _small_step():
     return model, criterion, step, batch
 
 
+@pytest.mark.first_contact(timeout=420)
 def test_host_route_self_check_switches_the_routes_on():
     """routes.validate on a small bf16 train step (2 x 384 x 480 images = 7 656 tokens: the fused FFN and both linked blocks
     apply): both GPU-only routes reproduce the plain step and come out ON; the random state of the caller is untouched and no
@@ -58,6 +59,7 @@ def test_host_route_self_check_switches_the_routes_on():
         routes.set_all(False)
 
 
+@pytest.mark.first_contact(timeout=420)
 def test_graphed_step_with_the_routes_on_matches_the_eager_plain_step():
     """The linked backward nodes under HIP-graph capture (their in-place GEMM epilogues are captured on the side stream like
     every other kernel): the gradients the graphed step delivers with both routes ON against the eager step with both OFF,
@@ -103,6 +105,7 @@ def test_two_rank_bench_prints_one_line():
     assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
 
 
+@pytest.mark.first_contact(timeout=420)
 @pytest.mark.parametrize("C,form", [(192, "pre_norm"), (384, "pre_norm"), (768, "plain"), (1536, "pre_norm"), (96, "plain")])
 def test_wide_layer_norm_against_torch(C, form):
     """csrc/layernorm_wide.hip through norm.residual_pre_norm (the Swin blocks' add + LayerNorm, models/swin/swin_transformer.py:
@@ -143,6 +146,7 @@ def test_wide_layer_norm_against_torch(C, form):
         torch.testing.assert_close(g, x.grad, rtol=2.0 ** -6, atol=2.0 ** -6 * float(x.grad.abs().max()))
 
 
+@pytest.mark.first_contact(timeout=420)
 def test_swin_step_with_the_fused_norms_matches_the_plain_ops():
     """routes.validate on a small Swin-L train step (configs 4-5): the fused add + LayerNorm route reproduces the plain step."""
     from rlipv2_amd import train
@@ -162,6 +166,7 @@ def test_swin_step_with_the_fused_norms_matches_the_plain_ops():
         routes.set_all(False)
 
 
+@pytest.mark.first_contact(timeout=420)
 @pytest.mark.parametrize("ws,heads,shift", [(7, 6, True), (7, 12, False), (8, 3, True)])
 def test_window_attention_module_fused_against_the_op_sequence(ws, heads, shift):
     """swin.WindowAttention with the fused kernel (csrc/window_attention.hip) against its own PyTorch op sequence (matmul + bias +
@@ -200,6 +205,7 @@ def test_window_attention_module_fused_against_the_op_sequence(ws, heads, shift)
         assert float((a - b).norm()) <= 3e-2 * float(b.norm()), (float((a - b).norm()), float(b.norm()))
 
 
+@pytest.mark.first_contact(timeout=420)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_rows_backward_against_the_general_backward(dtype):
     """csrc/msda_rows.hip (msda.SampleRowsFunction: the op with one head of 256 channels, the decoders' sample-then-project route)
@@ -238,6 +244,7 @@ def test_rows_backward_against_the_general_backward(dtype):
     assert float((res[0][2] - ref[2])[keep].abs().max()) <= 1e-4 * float(ref[2].abs().max())
 
 
+@pytest.mark.first_contact(timeout=420)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_sample_then_project_module_on_the_gpu(dtype):
     """MSDeformAttn with deform_attn.sample_then_project (generic forward with M' = 1, D' = 256 + the rows backward) against the

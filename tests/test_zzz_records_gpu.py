@@ -8,7 +8,8 @@ import sys
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+# first_contact: each test in a child process with a timeout, outcome XPASS / XFAIL (tests/conftest.py) -- the route is OFF in the product
+pytestmark = [pytest.mark.gpu, pytest.mark.first_contact(timeout=420)]
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

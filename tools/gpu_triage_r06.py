@@ -25,7 +25,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PY = sys.executable
-PYTEST = [PY, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider"]
+# (--runxfail + the child marker: a family's child IS the isolation, so its `first_contact` tests run in-process and count)
+PYTEST = [PY, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "--runxfail"]
 X = [PY, os.path.join("tools", "experiments_r05.py")]
 
 # name, SURVEY 8 row, on the default path once promoted?, regexes over the manifest's never_run kernel names, GPU commands (each
@@ -39,7 +40,7 @@ FAMILIES = [
     dict(name="cell_forward", row="a1", default_after_promotion=True,
          what="encoder MSDA forward from LDS windows on the matrix cores (cell_forward_kernel<., 0>, explicit variant `cell`)",
          kernels=[r"cell_forward_kernel<\d, 0>"],
-         gpu=[(PYTEST + ["-m", "gpu", "tests/test_msda_cell_forward_gpu.py"], {"RLIPV2_TEST_EXPERIMENTAL": "1"}), (X + ["--fwd"], {})],
+         gpu=[(PYTEST + ["-m", "gpu", "tests/test_msda_cell_forward_gpu.py"], {}), (X + ["--fwd"], {})],
          emu=[(PYTEST + ["tests/test_cell_forward_emulated.py"], {})], timeout=150),
     dict(name="backward_arms", row="a2", default_after_promotion=True,
          what="ablation build: cell_backward_kernel modes 2-4, patch_dest_multi_kernel (MULTI, REPS, CELLG + grad_out_cells_kernel); "
@@ -131,6 +132,7 @@ def main(argv=None):
     only = {s for s in args.only.split(",") if s}
     claimed, unclaimed = assign()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["RLIPV2_TEST_FIRST_CONTACT_CHILD"] = "1"
     tag = "triage_dry_run" if args.dry_run else "triage"
     rows, lost = [], False
     t_start = time.time()

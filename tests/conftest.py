@@ -14,33 +14,50 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "first_contact(timeout=300): GPU test of device code / a host route that has NEVER executed on "
-                                       "hardware -- runs in a child process with a timeout (a hang or a fault costs that test, not "
-                                       "the suite) and counts as XPASS / XFAIL, not as pass / failure: the code under test is OFF in "
-                                       "the product, the colour of the suite is the product path's")
+    config.addinivalue_line("markers", "first_contact(timeout=300, counts=False): GPU test of device code / a host route that has NEVER "
+                                       "executed on hardware -- the first_contact tests of a file run together in ONE child process "
+                                       "with a timeout (a hang or a fault costs those tests, not the suite) and count as XPASS / "
+                                       "XFAIL, not as pass / failure: the code under test is OFF in the product, the colour of the "
+                                       "suite is the product path's (counts=True: isolated, but a failure is a failure)")
 
 
 FIRST_CONTACT_CHILD = "RLIPV2_TEST_FIRST_CONTACT_CHILD"
+_first_contact_results = {}          # test file -> {test name incl. parameters: (ok, text)} | "the child's failure as a whole"
 
 
-def run_isolated(nodeid, timeout, python=sys.executable, extra_env=None):
-    """one test node in a child pytest (own process group, killed as a group on timeout) -> (ok, tail of its output).  The child
-    runs with --runxfail: ITS exit code is the test's real outcome."""
+def run_isolated(path, timeout, python=sys.executable, extra_env=None):
+    """ALL `first_contact` tests of one test file in ONE child pytest (own process group, killed as a group on timeout; one
+    process start for the file, not one per test) -> {test name: (ok, message)}; tests the child did not get to (it was killed, or
+    it died with the device) are absent.  The child runs with --runxfail and without -x: every test gets its real outcome."""
     import signal
     import subprocess
+    import tempfile
+    import xml.etree.ElementTree as ET
     env = dict(os.environ, **{FIRST_CONTACT_CHILD: "1"}, **(extra_env or {}))
-    proc = subprocess.Popen([python, "-m", "pytest", nodeid, "-q", "-x", "--runxfail", "-p", "no:cacheprovider", "-m", "gpu or not gpu"],
-                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT, env=env, start_new_session=True)
-    try:
-        out, _ = proc.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
+    with tempfile.TemporaryDirectory() as tmp:
+        xml = os.path.join(tmp, "report.xml")
+        proc = subprocess.Popen([python, "-m", "pytest", path, "-q", "--runxfail", "-p", "no:cacheprovider", "-m", "first_contact",
+                                 "--junitxml", xml, "-o", "junit_family=xunit1"],
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT, env=env, start_new_session=True)
+        note = ""
         try:
-            os.killpg(proc.pid, signal.SIGKILL)
-        except ProcessLookupError:
-            pass
-        out, _ = proc.communicate()
-        return False, f"timed out after {timeout} s (child process group killed)\n" + (out or "")[-1500:]
-    return proc.returncode == 0, (out or "")[-2500:]
+            out, _ = proc.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, _ = proc.communicate()
+            note = f"the file's child process timed out after {timeout} s and was killed; "
+        res = {}
+        if os.path.exists(xml):                                  # (written at the end of the session: absent after a kill / fault)
+            for case in ET.parse(xml).getroot().iter("testcase"):
+                bad = [c for c in case if c.tag in ("failure", "error")]
+                skipped = [c for c in case if c.tag == "skipped"]
+                res[case.get("name")] = (not bad, (bad[0].get("message", "") + "\n" + (bad[0].text or ""))[-2000:] if bad
+                                         else ("skipped in the child: " + skipped[0].get("message", "") if skipped else ""))
+        res["__whole__"] = (proc.returncode == 0 and not note, note + f"child exit code {proc.returncode}\n" + (out or "")[-2000:])
+        return res
 
 
 @pytest.hookimpl(tryfirst=True)
@@ -48,9 +65,17 @@ def pytest_pyfunc_call(pyfuncitem):
     m = pyfuncitem.get_closest_marker("first_contact")
     if m is None or os.environ.get(FIRST_CONTACT_CHILD) == "1":
         return None                                              # run normally (also: inside the child)
-    ok, tail = run_isolated(pyfuncitem.nodeid, int(m.kwargs.get("timeout", 300)))
+    path = str(pyfuncitem.fspath)
+    if path not in _first_contact_results:
+        items = [it for it in pyfuncitem.session.items if str(it.fspath) == path and it.get_closest_marker("first_contact")]
+        budget = sum(int(it.get_closest_marker("first_contact").kwargs.get("timeout", 300)) for it in items)
+        _first_contact_results[path] = run_isolated(os.path.relpath(path, ROOT), min(budget, 1200))
+    res = _first_contact_results[path]
+    ok, text = res.get(pyfuncitem.name, (False, "no result from the child process -- " + res["__whole__"][1]))
     if not ok:
-        pytest.fail("first contact with the hardware FAILED in the child process:\n" + tail, pytrace=False)
+        pytest.fail("first contact with the hardware FAILED in the child process:\n" + text, pytrace=False)
+    if text.startswith("skipped in the child"):
+        pytest.skip(text)
     return True
 
 

@@ -1,4 +1,4 @@
-"""NOT part of the suite (the file name does not match test_*.py): four `first_contact` tests with known outcomes, run by
+"""NOT part of the suite (the file name does not match test_*.py): `first_contact` tests with known outcomes (tests/first_contact_probe_fatal.py: a file whose child hangs / dies), run by
 tests/test_bench_host.py::test_first_contact_tests_run_isolated_and_never_colour_the_suite in a child pytest to check the
 isolation mechanism of tests/conftest.py without a GPU."""
 import os
@@ -18,14 +18,10 @@ def test_probe_fails():
     assert 1 + 1 == 3
 
 
-@pytest.mark.first_contact(timeout=2)
-def test_probe_hangs():
-    time.sleep(600)
-
-
-@pytest.mark.first_contact(timeout=60)
-def test_probe_faults():
-    os.kill(os.getpid(), signal.SIGSEGV)
+@pytest.mark.first_contact(timeout=5)
+@pytest.mark.parametrize("n", [1, 2])
+def test_probe_parametrized(n):
+    assert n == 1
 
 
 def test_probe_ordinary_test_after_the_others():

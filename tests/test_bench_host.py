@@ -375,11 +375,23 @@ def test_promotion_report_reads_an_experiments_object(tmp_path, capsys):
         "train_step_with_records_route": {"ms_per_step": 34.9, "roofline_frac": 0.146, "mean_launch_us": 350.0, "roofline_kernel": "msda_records"},
         "swin_routes": {"error": "not started: time budget used up"}},
         "ms_per_step": 36.1, "roofline": {"frac": 0.094, "mean_launch_us": 542.0}}
+    rep["experiments"]["encoder_backward_arms"]["patch cellg"] = {"b0": {"us": 470.0, "accepted": True, "finite": True},
+                                                                   "fused": {"us": 500.0, "accepted": True, "finite": True, "equal_bits": True}}
+    rep["experiments"]["uniform_location_arms"] = {
+        "default": {"uniform": {"us": 1340.0, "accepted": True}, "model": {"us": 545.0, "accepted": True}},
+        "far return": {"uniform": {"us": 800.0, "accepted": True}, "model": {"us": 546.0, "accepted": True}},
+        "far return + queue-fed fallback": {"uniform": {"us": 790.0, "accepted": False}, "model": {"us": 540.0, "accepted": True}}}
     path = tmp_path / "line.json"
     path.write_text("[bench] some log line\n" + json.dumps(rep) + "\n")
     rows = {name: (verdict, where) for verdict, name, _, where in P.decide(P.load(str(path)))}
     assert rows["cell 3"][0] == "PROMOTE" and "kCellMode" in rows["cell 3"][1]
     assert rows["cell 2"][0] == "REJECT" and rows["patch multi"][0] == "SKIP"
+    assert rows["patch cellg"][0] == "PROMOTE" and "grad_out_cells_kernel" in rows["patch cellg"][1]
+    assert rows["uniform locations: far return"][0] == "PROMOTE" and rows["uniform locations: far return + queue-fed fallback"][0] == "REJECT"
+    # bench.py --experiments leaves the object behind the word EXPERIMENTS on stderr: found as well
+    log = tmp_path / "bench_stderr.txt"
+    log.write_text("[bench] x\nEXPERIMENTS " + json.dumps(rep["experiments"]) + "\n")
+    assert {n for _, n, _, _ in P.decide(P.load(str(log)))} >= {"cell 3", "patch cellg"}
     assert rows["records route (records)"][0] == "PROMOTE" and "records_route = True" in rows["records route (records)"][1]
     assert rows["records route (records_swap)"][0] == "REJECT"
     assert rows["train step with the records route"][0] == "PROMOTE"
@@ -458,14 +470,21 @@ def test_triage_survives_failing_hanging_and_crashing_children(tmp_path, monkeyp
 
 
 def test_first_contact_tests_run_isolated_and_never_colour_the_suite():
-    """tests/conftest.py: a GPU test marked `first_contact` (device code / host route that has never executed on hardware) runs in a
-    child pytest with a timeout -- a hang or a fault costs that test, not the suite -- and is reported as XPASS / XFAIL: the suite
-    goes on under -x and its exit code stays the product path's."""
+    """tests/conftest.py: the GPU tests of a file that are marked `first_contact` (device code / host routes that have never executed
+    on hardware) run together in ONE child pytest with a timeout -- a hang or a fault costs those tests, not the suite -- and are
+    reported as XPASS / XFAIL: the suite goes on under -x and its exit code stays the product path's."""
     import subprocess
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "first_contact_probe.py"), "-q", "-x", "-rxX",
-                        "-p", "no:cacheprovider"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+
+    def run(path, **env):
+        return subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", path), "-q", "-x", "-rxX", "-p", "no:cacheprovider"],
+                              capture_output=True, text=True, cwd=ROOT, timeout=600, env=dict(os.environ, **env))
+    r = run("first_contact_probe.py")
     out = r.stdout
     assert r.returncode == 0, out[-3000:]
-    assert "1 passed" in out and "3 xfailed" in out and "1 xpassed" in out, out[-1500:]
-    assert "XPASS tests/first_contact_probe.py::test_probe_passes" in out
-    assert "XFAIL tests/first_contact_probe.py::test_probe_hangs" in out and "XFAIL tests/first_contact_probe.py::test_probe_faults" in out
+    assert "1 passed" in out and "2 xfailed" in out and "2 xpassed" in out, out[-1500:]
+    assert "XPASS tests/first_contact_probe.py::test_probe_passes" in out and "XPASS tests/first_contact_probe.py::test_probe_parametrized[1]" in out
+    assert "XFAIL tests/first_contact_probe.py::test_probe_fails" in out and "XFAIL tests/first_contact_probe.py::test_probe_parametrized[2]" in out
+    # a child that hangs or dies: every test of the file is XFAIL with the reason, the parent session is green and goes on
+    for mode, word in (("hang", "timed out after"), ("fault", "child exit code")):
+        r = run("first_contact_probe_fatal.py", PROBE_MODE=mode)
+        assert r.returncode == 0 and "3 xfailed" in r.stdout, r.stdout[-2000:]

@@ -1,7 +1,9 @@
 """Reads the `experiments` object of a bench.py line (or the JSON tools/experiments_r05.py prints) and says, arm by arm, what the
 numbers decide -- so that the session that finally has a GPU spends its minutes on the edits, not on reading tables.
 
-    python tools/promote_r05.py gpurun_out/r5a/bench_line.json          # or experiments.json
+    python tools/promote_r05.py gpurun_out/r06/experiments.json         # tools/experiments_r05.py [--all | --arms | --uniform-arms]
+    python tools/promote_r05.py gpurun_out/experiments_last.json        # what `bench.py --experiments` leaves (or its stderr log:
+                                                                        # the `EXPERIMENTS {json}` line is found too)
 
 Rules (the ones DESIGN.md section 8 states): an arm of the MSDA backward is promoted only if its grad_value is BIT-EQUAL to the
 product kernels' and its other gradients agree within a rounding of their type (`accepted`; bit-equal digests imply it) and it is
@@ -18,8 +20,13 @@ def load(path):
     last = None
     for line in open(path):
         line = line.strip()
+        if line.startswith("EXPERIMENTS {"):       # bench.py --experiments writes the object to stderr behind this word
+            line = line[len("EXPERIMENTS "):]
         if line.startswith("{"):
-            last = json.loads(line)
+            try:
+                last = json.loads(line)
+            except ValueError:
+                continue
     if last is None:
         raise SystemExit(f"{path}: no JSON object found")
     rep = dict(last.get("experiments", last))
@@ -46,7 +53,9 @@ def decide(rep):
             # (accepted: grad_value bit-equal + the formula gradients within a rounding, tools/experiments_r05.py; older reports: digests)
             ok = all(v[c].get("accepted", v[c].get("equal_bits")) for c in ("fused", "b0")) and v["fused"].get("finite")
             us = v["fused"]["us"]
-            where = "csrc/msda_patch.hip: kCellMode / kPatchMulti, rebuild, GPU suite"
+            where = ("csrc/msda_patch.hip: the arm's kernel / launch out of `#ifdef MSDA_ABLATION` (patch_dest_multi_kernel<., ., true> + "
+                     "grad_out_cells_kernel, gcell_bytes), rebuild, GPU suite" if "cellg" in name else
+                     "csrc/msda_patch.hip: kCellMode / kPatchMulti, rebuild, GPU suite")
             if not ok:
                 out.append(("REJECT", name, f"gradients differ from the product kernels' ({us} us)", "delete the arm"))
             elif faster(us, b_us):
@@ -54,6 +63,22 @@ def decide(rep):
                             "grad_value bit-equal, the formula gradients within a rounding"), where))
             else:
                 out.append(("KEEP OFF", name, f"{b_us} -> {us} us: not faster", "delete the arm"))
+    uni = rep.get("uniform_location_arms", {})
+    ubase = uni.get("default", {})
+    for name, v in list(uni.items())[1:]:
+        if "error" in v or "error" in ubase:
+            out.append(("SKIP", f"uniform locations: {name}", v.get("error") or ubase.get("error"), ""))
+            continue
+        u_old, u_new, m_old, m_new = ubase["uniform"]["us"], v["uniform"]["us"], ubase["model"]["us"], v["model"]["us"]
+        detail = f"uniform locations {u_old} -> {u_new} us per backward (round 2: 975-1 130), model-like {m_old} -> {m_new} us"
+        if not (v["uniform"].get("accepted") and v["model"].get("accepted")):
+            out.append(("REJECT", f"uniform locations: {name}", "gradients differ or are not repeatable: " + detail, "delete the arm"))
+        elif faster(u_new, u_old) and m_new <= m_old * (1.0 + MARGIN):
+            out.append(("PROMOTE", f"uniform locations: {name}", detail,
+                        "csrc/msda_patch.hip (the far-return block), csrc/msda_quad.hip (launch_quad_backward_gated), csrc/msda_dest.hip "
+                        "(bin_queue_kernel / combine_queue_kernel + their launches): out of `#ifdef MSDA_ABLATION`, rebuild, GPU suite"))
+        else:
+            out.append(("KEEP OFF", f"uniform locations: {name}", detail, "delete the arm"))
     rec = rep.get("encoder_records_route", {})
     if "error" in rec:
         out.append(("SKIP", "records route", rec["error"], ""))

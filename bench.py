@@ -927,7 +927,10 @@ def main():
     if args.workload == "train_step" and args.host_routes == "auto":
         # the self-check runs in a child BEFORE this process creates its GPU context: a never-run route that faults or hangs
         # takes the child with it, never the timed region or the JSON line (the child is a plain subprocess, not an exec)
-        args.route_verdicts = routes_verdicts_from_child(
+        # (not under rocprofv3: its preloaded tool has initialised the GPU in this process already and follows children into the
+        #  trace -- the profiled run is the plain step, and says so)
+        args.route_verdicts = ({n: "off (self-check child not started under a profiler)" for n in applicable_routes(args.backbone)}
+                               if under_profiler() else None) or routes_verdicts_from_child(
             list(sys.argv[1:]), args.backbone, rank=rank, device_index=0 if os.environ.get("RLIPV2_SINGLE_DEVICE") == "1" else local_rank)
         print("[bench] host routes (self-check in a child process): " + json.dumps(args.route_verdicts), file=sys.stderr)
     if not torch.cuda.is_available():

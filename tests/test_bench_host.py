@@ -488,3 +488,18 @@ def test_first_contact_tests_run_isolated_and_never_colour_the_suite():
     for mode, word in (("hang", "timed out after"), ("fault", "child exit code")):
         r = run("first_contact_probe_fatal.py", PROBE_MODE=mode)
         assert r.returncode == 0 and "3 xfailed" in r.stdout, r.stdout[-2000:]
+
+
+def test_design_documents_stay_within_120_columns_and_the_index_names_existing_files():
+    """DESIGN.md is an index over section files of at most 120 columns (tools/reflow_md.py), and every
+    profiles/ / tests/ / tools/ file the index names exists"""
+    import glob
+    import re
+    files = [os.path.join(ROOT, "DESIGN.md")] + sorted(glob.glob(os.path.join(ROOT, "docs", "design", "*.md")))
+    assert len(files) == 9
+    for f in files:
+        worst = max(len(l) for l in open(f).read().split("\n"))
+        assert worst <= 120, (f, worst)
+    index = open(files[0]).read()
+    for rel in set(re.findall(r"`((?:profiles|tests|tools|docs/design)/[\w./]+\.(?:md|txt|json|csv|py|sh))`", index)):
+        assert os.path.exists(os.path.join(ROOT, rel)), rel

@@ -121,7 +121,7 @@ def validate(step_module, criterion, batch, autocast_dtype=None, group=None, see
         return {name: "off (not applicable: the route exists on the GPU only)" for name in GPU_ONLY_ROUTES}
     names = list(GPU_ONLY_ROUTES) if names is None else [n for n in GPU_ONLY_ROUTES if n in set(names)]
     cpu_state, cuda_state = torch.get_rng_state(), torch.cuda.get_rng_state(device)
-    verdict = {}
+    verdict, measured = {}, {}
     try:
         set_all(False)
         ref_loss, ref_grads = _run(step_module, criterion, batch, autocast_dtype, seed)
@@ -134,12 +134,15 @@ def validate(step_module, criterion, batch, autocast_dtype=None, group=None, see
             try:
                 loss, grads = _run(step_module, criterion, batch, autocast_dtype, seed)
                 why = compare(loss, grads, ref_loss, ref_grads, noise)
+                measured[name] = distance(grads, ref_grads)          # (logged: what the tolerances can be tightened to)
                 del grads
             except Exception as e:                                   # noqa: BLE001 -- a route that raises stays off
                 why = f"{type(e).__name__}: {e}"
             verdict[name] = why
         if log is not None:
-            log(f"[routes] step noise {noise:.3g}; " + ", ".join(f"{k}: {'ok' if v is None else v}" for k, v in verdict.items()))
+            log(f"[routes] step noise {noise:.3g} (whole-gradient distance of two plain runs; bar: max({WHOLE_RTOL:g}, {NOISE_FACTOR:g} x noise)); "
+                + ", ".join(f"{k}: {'ok' if v is None else v}" + (f" (distance {measured[k]:.3g})" if k in measured else "")
+                            for k, v in verdict.items()))
     finally:
         set_all(False)
         torch.set_rng_state(cpu_state)

@@ -706,8 +706,11 @@ def routes_child_main(args):
     `ROUTES {json}` line.  A single process on one device: no process group, no optimiser, nothing timed."""
     from rlipv2_amd import parseda, routes, train
     rank = args.routes_child_rank
-    torch.cuda.set_device(args.routes_child_device)
-    device = f"cuda:{args.routes_child_device}"
+    if args.routes_child_device < 0:                 # (CPU dry run of the plumbing, tests/test_bench_host.py: every route "off (not applicable)")
+        device = "cpu"
+    else:
+        torch.cuda.set_device(args.routes_child_device)
+        device = f"cuda:{args.routes_child_device}"
     margs = parseda.default_args(num_queries=args.queries)
     if os.environ.get("RLIPV2_MIOPEN_FIND", "0") == "1":
         torch.backends.cudnn.benchmark = True
@@ -726,8 +729,9 @@ def routes_child_main(args):
     train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
     verdict = routes.validate(step_module, criterion, batch, autocast_dtype=dtype, names=applicable_routes(args.backbone),
                               log=lambda m: print(m, file=sys.stderr))
-    torch.cuda.synchronize()
-    print("ROUTES " + json.dumps(verdict), flush=True)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    print("ROUTES " + json.dumps({n: verdict[n] for n in applicable_routes(args.backbone)}), flush=True)
 
 
 def routes_verdicts_from_child(argv, backbone, rank=0, device_index=0, timeout=ROUTES_CHILD_TIMEOUT_S, cmd=None):
@@ -901,7 +905,7 @@ def main():
         apply_overrides(args.overrides)
         if args.deterministic:
             torch.backends.cudnn.deterministic = True
-        if torch.cuda.device_count() == 0:
+        if torch.cuda.device_count() == 0 and args.routes_child_device >= 0:
             raise SystemExit("bench.py --routes-child needs a GPU")
         routes_child_main(args)
         return

@@ -503,3 +503,13 @@ def test_design_documents_stay_within_120_columns_and_the_index_names_existing_f
     index = open(files[0]).read()
     for rel in set(re.findall(r"`((?:profiles|tests|tools|docs/design)/[\w./]+\.(?:md|txt|json|csv|py|sh))`", index)):
         assert os.path.exists(os.path.join(ROOT, rel)), rel
+
+
+def test_the_real_route_child_end_to_end_on_the_cpu():
+    """`bench.py --routes-child` as the parent starts it (same argv + the three child flags), on the CPU device (-1): the child
+    builds the model and batch, runs routes.validate -- which answers "not applicable" off the GPU -- and prints its ROUTES line;
+    the parent parses it.  The only part a GPU adds is the eager steps inside validate()."""
+    v = bench.routes_verdicts_from_child(["--batch", "1", "--queries", "30", "--steps", "2"], "resnet50", rank=0, device_index=-1, timeout=600)
+    assert list(v) == list(routes.GPU_ONLY_ROUTES)
+    assert v["residual_gradient_in_gemm"].startswith("off (not applicable: the route exists on the GPU only")
+    assert v["fused_window_attention"].startswith("off (not applicable: no such block in a resnet50 step")

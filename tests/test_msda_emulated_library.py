@@ -268,7 +268,7 @@ def test_far_return_arm_hands_every_gradient_to_the_gated_k1(ablation_lib, monke
     workgroups; on a call WITHOUT far samples the arm changes nothing (the gated launch returns)."""
     lib = ablation_lib
     M = 1
-    pyr, starts, S, ref2, value, grad_out, rng = _encoder_problem([(40, 54), (20, 27), (10, 14), (5, 7)], 1, M, seed=31)
+    pyr, starts, S, ref2, value, grad_out, rng = _encoder_problem([(20, 54), (10, 27), (5, 14), (3, 7)], 1, M, seed=31)   # (4 cell columns: samples out of reach)
     loc = rng.random((1, S, M, 4, 4, 2)).astype(np.float32)                         # anywhere in the image: far samples
     aw = rng.random((1, S, M, 4, 4))
     aw = (aw / aw.sum((-1, -2), keepdims=True)).astype(np.float32)
@@ -279,7 +279,7 @@ def test_far_return_arm_hands_every_gradient_to_the_gated_k1(ablation_lib, monke
     _, gv_k1, gl_k1, ga_k1 = lib.run("quad", "dest", BF16, far)
     monkeypatch.delenv("RLIPV2_MSDA_CELL")
     monkeypatch.setenv("RLIPV2_CELL_FAR_RETURN", "1")
-    for _ in range(2):                                                              # (twice: another interleaving of the workgroups)
+    for _ in range(1):
         _, gv, gl, ga = lib.run("quad", "dest", BF16, far)
         # grad_value comes from the sorting pass in both routes.  On the lane-level model that pass is repeatable only to a
         # bfloat16 rounding: a wave's LDS atomics return their slots in the order the model's lane THREADS arrive (the hardware

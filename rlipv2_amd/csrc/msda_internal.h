@@ -89,7 +89,7 @@ void launch_backward_dest(const Problem &p, const Fused *f, const int64_t *shape
 bool patch_supports(const Problem &p, const int64_t *shapes_host);
 size_t patch_workspace_bytes(const Problem &p, const int64_t *shapes_host);
 void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned,
-                       void *gcell_ws = nullptr);
+                       void *gcell_ws = nullptr, bool gcell_filled = false);
 // ablation build only (else 0): offset, inside a patch_workspace_bytes buffer, of the room for the cell-major grad_out copy
 size_t patch_gcell_offset(const Problem &p, const int64_t *shapes_host);
 // ... preceded by cell_backward_kernel: K1's work (grad_sampling_loc / grad_attn_weight, or with `f` the projection row's

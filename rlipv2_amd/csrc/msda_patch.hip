@@ -1650,6 +1650,8 @@ const int *launch_cell_records_backward(const Problem &p, const Fused *f, const 
     const float *grecs = reinterpret_cast<const float *>(rb + rl.masks + mask_bytes(p, pl));
     const unsigned vbytes = (unsigned)((size_t)p.N * p.S * p.M * kD * 2);
     const dim3 grid(p.N * p.M * pl.CY * pl.CX), block(kCellThreads);
+    // (ablation build, RLIPV2_PATCH_CELLG: the kernel also leaves the cell-major grad_out copy of the patch pass's CELLG arm)
+    bf16_t *gcell = (gcell_ws && ablation_env("RLIPV2_PATCH_CELLG", 0) != 0) ? reinterpret_cast<bf16_t *>(gcell_ws) : nullptr;
 #define MSDA_REC_K(RD, SWAP)                                                                                          \
     do {                                                                                                              \
         RLIPV2_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void *)cell_records_backward_kernel<RD, SWAP>,        \
@@ -1657,7 +1659,7 @@ const int *launch_cell_records_backward(const Problem &p, const Fused *f, const 
         hipLaunchKernelGGL((cell_records_backward_kernel<RD, SWAP>), grid, block, kFwdWinBytes, p.stream, pl,         \
                            (const bf16_t *)p.value, p.shapes, p.starts, srec, wtab, grecs,                            \
                            (const bf16_t *)p.grad_out, p.N, p.S, p.M, p.Lq, vbytes, (float *)p.g_loc, (float *)p.g_aw, \
-                           f ? f->ref : nullptr, (bf16_t *)(f ? f->g_qproj : nullptr));                               \
+                           f ? f->ref : nullptr, (bf16_t *)(f ? f->g_qproj : nullptr), gcell);                        \
     } while (0)
 #define MSDA_REC(RD) do { if (swap) MSDA_REC_K(RD, true); else MSDA_REC_K(RD, false); } while (0)
     if (!f) MSDA_REC(0);
@@ -1665,7 +1667,7 @@ const int *launch_cell_records_backward(const Problem &p, const Fused *f, const 
     else MSDA_REC(4);
 #undef MSDA_REC
 #undef MSDA_REC_K
-    launch_patch_dest(p, shapes_host, rctl, rb + rl.masks, out_bf16, true, gcell_ws);
+    launch_patch_dest(p, shapes_host, rctl, rb + rl.masks, out_bf16, true, gcell_ws, gcell != nullptr);
     return rctl + kFarWord;
 }
 
@@ -1731,7 +1733,9 @@ void launch_cell_backward(const Problem &p, const Fused *f, const int64_t *shape
 // ctl: the control block of launch_backward_dest (zeroed by the caller on the stream), masks: patch_workspace_bytes;
 // binned: cell_backward_kernel has already written the masks and records; gcell_ws (ablation build, may be null): room for the
 // cell-major grad_out copy of the CELLG arm (patch_gcell_offset)
-void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned, void *gcell_ws)
+// gcell_filled: the copy is there already (cell_records_backward_kernel wrote it)
+void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, void *mask_ws, bool out_bf16, bool binned, void *gcell_ws,
+                       bool gcell_filled)
 {
     PatchPlan pl;
     make_patch_plan(p, shapes_host, pl);
@@ -1757,6 +1761,7 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
     bf16_t *gcell = nullptr;
     if (gcell_ws && ablation_env("RLIPV2_PATCH_CELLG", 0) != 0) {           // the experiment kernel on a cell-major grad_out copy
         gcell = reinterpret_cast<bf16_t *>(gcell_ws);
+        if (!gcell_filled)
         hipLaunchKernelGGL(grad_out_cells_kernel, dim3(p.N * p.M * pl.CY * pl.CX), dim3(256), 0, p.stream, pl, p.starts,
                            (const bf16_t *)p.grad_out, p.N, p.M, p.Lq, gcell, (const int *)ctl);
         multi = true;
@@ -1768,7 +1773,7 @@ void launch_patch_dest(const Problem &p, const int64_t *shapes_host, int *ctl, v
     }
 #undef MSDA_PATCH_MULTI
 #else
-    (void)gcell_ws;
+    (void)gcell_ws; (void)gcell_filled;
 #endif
     if (out_bf16) { if (wps == 5) MSDA_PATCH(patch_dest_kernel, bf16_t, 5); else MSDA_PATCH(patch_dest_kernel, bf16_t, 4); }
     else { if (wps == 5) MSDA_PATCH(patch_dest_kernel, float, 5); else MSDA_PATCH(patch_dest_kernel, float, 4); }

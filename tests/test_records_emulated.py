@@ -27,11 +27,24 @@ BF16, FLAG_BF16_GV, FLAG_SWAP, CELL = 2, 0x200, 0x400, 6
 FULL = os.environ.get("RLIPV2_TEST_EMU_FULL", "0") == "1"     # the default suite runs one problem per code path (~2.5 min)
 
 
+def _build(tmp_path_factory, name, defines=""):
+    so = str(tmp_path_factory.mktemp(name) / "libmsda_emu.so")
+    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900,
+                   env=dict(os.environ, EMU_DEFINES=defines))
+    return _bind(ctypes.CDLL(so))
+
+
 @pytest.fixture(scope="module")
 def lib(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("emu_records") / "libmsda_emu.so")
-    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900)
-    L = ctypes.CDLL(so)
+    return _build(tmp_path_factory, "emu_records")
+
+
+@pytest.fixture(scope="module")
+def ablation_lib(tmp_path_factory):
+    return _build(tmp_path_factory, "emu_records_ablation", "-DMSDA_ABLATION")
+
+
+def _bind(L):
     vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     d = [i] * 7
     L.msda_records_bytes.argtypes = [i, vp, *d]
@@ -45,6 +58,7 @@ def lib(tmp_path_factory):
     L.msda_fused_forward_hs.argtypes = [i, i, vp, vp, vp, vp, vp, vp, i, *d, vp, vp, vp, vp]
     L.msda_fused_backward_ws.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, i, vp, *d, vp, vp, vp, sz, vp]
     return L
+
 
 
 def p(a):
@@ -115,6 +129,40 @@ def test_op_signature_bit_equal_to_the_product_route(lib, name, pyr, M, spread):
         assert lib.msda_records_backward(flags, BF16, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), None, 0, p(gob), *dims, p(gv2),
                                          p(gl2), p(ga2), None, p(records), rec_bytes, p(ws), ws_bytes, None) == 0
         assert np.array_equal(gv2, gv) and np.array_equal(gl2.view(np.uint32), gl.view(np.uint32)) and np.array_equal(ga2.view(np.uint32), ga.view(np.uint32))
+
+
+def test_records_route_with_the_cell_major_grad_out_copy_fused_in(ablation_lib, monkeypatch):
+    """Round 6, ablation build + RLIPV2_PATCH_CELLG=1: cell_records_backward_kernel -- which holds every query's grad_out row anyway
+    -- also leaves the cell-major copy that patch_dest_multi_kernel<., ., CELLG> reads (no grad_out_cells_kernel launch).  Bar: the
+    same bits as before, i.e. the whole comparison of the test above on the ablation library with the arm switched on (the product
+    route inside it then runs the arm with its stand-alone copy kernel, itself bit-equal to the product kernels:
+    tests/test_backward_emulated.py)."""
+    monkeypatch.setenv("RLIPV2_PATCH_CELLG", "1")
+    test_op_signature_bit_equal_to_the_product_route(ablation_lib, *CASES[0])
+    monkeypatch.delenv("RLIPV2_PATCH_CELLG")
+    # ... and the arm really ran: with the switch off the same library takes the product patch kernel; the results agree bit for bit
+    # across the two (checked inside each call against the product route of ITS setting), so compare the two settings directly
+    name, pyr, M, spread = CASES[0]
+    pyr, starts, S, value, loc, aw = make_problem(pyr, M, spread, seed=7)
+    gob = np.ascontiguousarray(bf16_bits(np.random.default_rng(3).standard_normal((1, S, M * 32))))
+    vb = np.ascontiguousarray(bf16_bits(value))
+    sh, st = np.ascontiguousarray(pyr, dtype=np.int64), np.ascontiguousarray(starts, dtype=np.int64)
+    dims = (1, S, M, 32, 4, S, 4)
+    L = ablation_lib
+    rec_bytes, ws_bytes = L.msda_records_bytes(BF16, p(sh), *dims), L.msda_backward_workspace_bytes(BF16, p(sh), *dims)
+    got = []
+    for cellg in ("0", "1"):
+        monkeypatch.setenv("RLIPV2_PATCH_CELLG", cellg)
+        records, out = np.zeros(rec_bytes, dtype=np.uint8), np.zeros((1, S, M * 32), dtype=np.uint16)
+        assert L.msda_records_forward(BF16, p(vb), p(sh), p(st), p(sh), None, None, 0, p(loc), p(aw), *dims, p(out), p(records), rec_bytes, None) == 0
+        gv, gl, ga = np.zeros_like(vb), np.full(loc.shape, np.nan, np.float32), np.full(aw.shape, np.nan, np.float32)
+        ws = np.full(ws_bytes + 64, 0xA5, dtype=np.uint8)                       # (garbage: the copy must have been written before it is read)
+        assert L.msda_records_backward(FLAG_BF16_GV | FLAG_SWAP, BF16, p(vb), p(sh), p(st), p(sh), p(loc), p(aw), None, 0, p(gob), *dims,
+                                       p(gv), p(gl), p(ga), None, p(records), rec_bytes, p(ws), ws_bytes, None) == 0
+        assert np.all(ws[ws_bytes:] == 0xA5)
+        got.append((gv, gl.view(np.uint32), ga.view(np.uint32)))
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("refdim", [2, 4] if FULL else [2])

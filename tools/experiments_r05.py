@@ -456,6 +456,10 @@ def _main(tmp_dir, per_child_timeout, budget_s, arms_only=False):
         for k in range(len(ARMS)):
             arm(k)
         report["encoder_backward_arms"] = arms if have_arms else {"error": "no ablation build (make -C rlipv2_amd/csrc ablation)"}
+        if have_arms:
+            # the records route on the ablation library with the CELLG arm: its backward kernel leaves the cell-major grad_out copy
+            # itself (no copy kernel), the patch pass reads it -- `product` in this object = product cell kernel + copy kernel + CELLG
+            report["encoder_records_route_cellg"] = child(["--records"], dict(base_env, RLIPV2_LIB_PATH=ABLATION_LIB, RLIPV2_PATCH_CELLG="1"))
         report["wall_s"] = round(time.time() - t0, 1)
         return report
     # order = value of the evidence: the default pair, the records route (kernel level, then -- only if its gradients are the product

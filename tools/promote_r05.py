@@ -79,6 +79,13 @@ def decide(rep):
                         "(bin_queue_kernel / combine_queue_kernel + their launches): out of `#ifdef MSDA_ABLATION`, rebuild, GPU suite"))
         else:
             out.append(("KEEP OFF", f"uniform locations: {name}", detail, "delete the arm"))
+    rc = rep.get("encoder_records_route_cellg", {})
+    if rc and "error" not in rc and "records_swap" in rc and "product" in rc:
+        v, pr = rc["records_swap"], rc["product"]
+        ok = v.get("accepted") and v.get("finite")
+        out.append(("INFO" if ok else "REJECT", "records route + CELLG patch pass (fused cell-major copy)",
+                    f"backward {pr['bwd_us']} (product cell kernel + copy kernel + CELLG) -> {v['bwd_us']} us, forward {v['fwd_us']} us; "
+                    "compare with the plain records route above", "both are never-run code: promote the pair or neither"))
     rec = rep.get("encoder_records_route", {})
     if "error" in rec:
         out.append(("SKIP", "records route", rec["error"], ""))

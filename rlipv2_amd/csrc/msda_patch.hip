@@ -1560,7 +1560,7 @@ bool cell_forward_supports(const Problem &p, const int64_t *shapes_host)
     if (!p.value || !make_patch_plan(p, shapes_host, pl)) return false;       // bfloat16, D 32, L = P = 4, Lq == S, consistent pyramid
     if ((long)p.N * p.Lq * p.M * 16 >= (1L << 31)) return false;                // 32-bit sample indices
     if ((long)p.N * p.M * pl.CY * pl.CX >= (1L << 30)) return false;
-    return true;
+    return quad_supports(p);                                                    // the window staging addresses value through a buffer resource
 }
 
 // ---- the records buffer: what cell_forward_kernel<., EMIT> leaves for the backward pass (one allocation, saved by the caller)

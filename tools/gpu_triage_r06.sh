@@ -23,6 +23,7 @@ if [ "$MODE" = "extras" ]; then
   ( [ -f tools/_build/librlipv2_msda_ablation.so ] || make -s -C rlipv2_amd/csrc -j8 ablation; export RLIPV2_LIB_PATH=$GRAFT_REPO_ROOT/tools/_build/librlipv2_msda_ablation.so; for m in 8 100000; do RLIPV2_WGRAD_MINSTEPS=$m timeout 300 python tools/wgrad_plan_ab.py; done > $OUT/wgrad_plan_ab.txt 2>&1 ); cat $OUT/wgrad_plan_ab.txt
   timeout 700 python bench.py --no-cpu-baseline --backbone swin_large --batch 2 > $OUT/bench_line_swin.json 2> $OUT/bench_swin_stderr.txt; tail -c 700 $OUT/bench_line_swin.json
   timeout 700 python bench.py --no-cpu-baseline --backbone swin_large --batch 2 --host-routes off > $OUT/bench_line_swin_routes_off.json 2>> $OUT/bench_swin_stderr.txt; tail -c 300 $OUT/bench_line_swin_routes_off.json
+  ( timeout 900 bash tools/gpu_dp_check.sh > $OUT/dp_check.txt 2>&1 ); grep -h "parallelism" gpurun_out/dp_bench_auto.log | cut -c1-400
   ( timeout 1000 python tools/experiments_r05.py --all > $OUT/experiments.json 2> $OUT/experiments_table.txt ); python tools/promote_r05.py $OUT/experiments.json > $OUT/promote.txt 2>&1; cat $OUT/promote.txt
   exit 0
 fi

@@ -91,7 +91,7 @@ def pytest_itemcollected(item):
 # hot path first, then the other kernels, the modules, the newest tests, and the whole-bench contract last
 # (one failure in a late, broad test must not hide the op-level parity results).
 GPU_SUITE_ORDER = ["test_msda_gpu", "test_norm_gpu", "test_linear_gpu", "test_optim_gpu",
-                   "test_modules_gpu", "test_zz_round4_gpu", "test_zz_round5_gpu", "test_bench_contract", "test_zzz_records_gpu",
+                   "test_modules_gpu", "test_zz_round4_gpu", "test_zz_round5_gpu", "test_zz_round6_gpu", "test_bench_contract", "test_zzz_records_gpu",
                    "test_msda_cell_forward_gpu"]
 
 

@@ -36,12 +36,12 @@ FAMILIES = [
          what="encoder MSDA pair: record-emitting forward + geometry-free backward (msda_cell_forward.inc EMIT, msda_cell_records.inc)",
          kernels=[r"cell_forward_kernel<\d, [23]>", r"cell_records_backward_kernel", r"records_unbin_kernel"],
          gpu=[(PYTEST + ["-m", "gpu", "tests/test_zzz_records_gpu.py"], {}), (X + ["--records"], {})],
-         emu=[(PYTEST + ["tests/test_records_emulated.py"], {})], timeout=240),
+         emu=[(PYTEST + ["tests/test_records_emulated.py"], {})], timeout=210),
     dict(name="cell_forward", row="a1", default_after_promotion=True,
          what="encoder MSDA forward from LDS windows on the matrix cores (cell_forward_kernel<., 0>, explicit variant `cell`)",
          kernels=[r"cell_forward_kernel<\d, 0>"],
          gpu=[(PYTEST + ["-m", "gpu", "tests/test_msda_cell_forward_gpu.py"], {}), (X + ["--fwd"], {})],
-         emu=[(PYTEST + ["tests/test_cell_forward_emulated.py"], {})], timeout=150),
+         emu=[(PYTEST + ["tests/test_cell_forward_emulated.py"], {})], timeout=120),
     dict(name="backward_arms", row="a2", default_after_promotion=True,
          what="ablation build: cell_backward_kernel modes 2-4, patch_dest_multi_kernel (MULTI, REPS, CELLG + grad_out_cells_kernel); "
               "uniform locations: far-return + gated K1, queue-fed fallback launches",
@@ -49,27 +49,30 @@ FAMILIES = [
          gpu=[(X + ["--arms"], {}), (X + ["--uniform-arms"], {})],
          emu=[(PYTEST + ["tests/test_backward_emulated.py"], {}),
               (PYTEST + ["tests/test_msda_emulated_library.py", "-k", "far_return"], {})], timeout=270),
-    dict(name="scaled_optimizer_step", row="e", default_after_promotion=True,
-         what="fused AdamW with grad_scale != 1: the data-parallel form of the optimiser step (fused_adamw.hip step_scaled_kernel)",
+    dict(name="data_parallel_default_path", row="e", default_after_promotion=True,
+         what="what every N > 1 run executes by default and no GPU has run: fused AdamW with grad_scale != 1 (fused_adamw.hip "
+              "step_scaled_kernel), the auto gradient schedule with real captured steps on a 1-rank RCCL group",
          kernels=[r"fused_adamw\.hip::.*step_scaled_kernel"],
-         gpu=[(PYTEST + ["-m", "gpu", "tests/test_optim_gpu.py", "-k", "gradient_scale"], {})],
-         emu=[(PYTEST + ["tests/test_dense_emulated.py", "-k", "fused_adamw"], {})], timeout=60),
+         gpu=[(PYTEST + ["-m", "gpu", "tests/test_optim_gpu.py", "-k", "gradient_scale"], {}),
+              (PYTEST + ["-m", "gpu", "tests/test_zz_round6_gpu.py"], {})],
+         emu=[(PYTEST + ["tests/test_dense_emulated.py", "-k", "fused_adamw"], {}),
+              (PYTEST + ["tests/test_dp_cpu.py", "-k", "auto_gradient_schedule"], {})], timeout=240),
     dict(name="decoder_sample_then_project", row="a5/a11", default_after_promotion=False,
          what="decoder cross-attention, sample the unprojected memory then project (msda_rows.hip scatter + dots kernels)",
          kernels=[r"msda_rows\.hip::"],
          gpu=[(PYTEST + ["-m", "gpu", "tests/test_zz_round5_gpu.py", "-k", "rows_backward or sample_then_project"], {}), (X + ["--stp"], {})],
-         emu=[(PYTEST + ["tests/test_msda_emulated_library.py", "-k", "rows_backward or sample_then_project"], {})], timeout=150),
+         emu=[(PYTEST + ["tests/test_msda_emulated_library.py", "-k", "rows_backward or sample_then_project"], {})], timeout=120),
     dict(name="swin_wide_layer_norm", row="f3", default_after_promotion=False,
          what="Swin blocks: residual add + LayerNorm at the Swin widths (layernorm_wide.hip, 40 instantiations)",
          kernels=[r"layernorm_wide\.hip::"],
          gpu=[(PYTEST + ["-m", "gpu", "tests/test_zz_round5_gpu.py", "-k", "wide_layer_norm or swin_step"], {})],
-         emu=[(PYTEST + ["tests/test_dense_emulated.py", "-k", "wide_layernorm"], {})], timeout=180),
+         emu=[(PYTEST + ["tests/test_dense_emulated.py", "-k", "wide_layernorm"], {})], timeout=120),
     dict(name="swin_window_attention", row="f3", default_after_promotion=False,
          what="Swin WindowAttention as one kernel per direction (window_attention.hip) + the stage-0 A/B",
          kernels=[r"window_attention\.hip::"],
          gpu=[(PYTEST + ["-m", "gpu", "tests/test_zz_round5_gpu.py", "-k", "window_attention"], {}), (X + ["--swin"], {})],
          emu=[(PYTEST + ["tests/test_dense_emulated.py", "-k", "window_attention"], {}),
-              (PYTEST + ["tests/test_swin_fused_emulated.py", "-k", "window_attention_module"], {})], timeout=150),
+              (PYTEST + ["tests/test_swin_fused_emulated.py", "-k", "window_attention_module"], {})], timeout=120),
 ]
 BUDGET_S = 20 * 60
 

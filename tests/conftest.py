@@ -36,7 +36,7 @@ def run_isolated(path, timeout, python=sys.executable, extra_env=None):
     env = dict(os.environ, **{FIRST_CONTACT_CHILD: "1"}, **(extra_env or {}))
     with tempfile.TemporaryDirectory() as tmp:
         xml = os.path.join(tmp, "report.xml")
-        proc = subprocess.Popen([python, "-m", "pytest", path, "-q", "--runxfail", "-p", "no:cacheprovider", "-m", "first_contact",
+        proc = subprocess.Popen([python, "-m", "pytest", path, "-v", "--runxfail", "-p", "no:cacheprovider", "-m", "first_contact",
                                  "--junitxml", xml, "-o", "junit_family=xunit1"],
                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT, env=env, start_new_session=True)
         note = ""
@@ -56,6 +56,12 @@ def run_isolated(path, timeout, python=sys.executable, extra_env=None):
                 skipped = [c for c in case if c.tag == "skipped"]
                 res[case.get("name")] = (not bad, (bad[0].get("message", "") + "\n" + (bad[0].text or ""))[-2000:] if bad
                                          else ("skipped in the child: " + skipped[0].get("message", "") if skipped else ""))
+        else:
+            # the child did not live to write its report (killed on the timeout, or it died with the device): the tests it HAD finished
+            # are in its -v output, one `file::name OUTCOME` line each
+            import re
+            for m in re.finditer(r"^\S+?::(\S+) (PASSED|FAILED|ERROR)\b", out or "", re.M):
+                res[m.group(1)] = (m.group(2) == "PASSED", "" if m.group(2) == "PASSED" else f"{m.group(2)} in the child (no report: it did not finish)")
         res["__whole__"] = (proc.returncode == 0 and not note, note + f"child exit code {proc.returncode}\n" + (out or "")[-2000:])
         return res
 

@@ -272,6 +272,7 @@ def test_add_row_vector_gradient_matches_broadcast_add():
 
 
 @gpu
+@pytest.mark.first_contact(timeout=300)          # step_scaled_kernel has never run on hardware: isolated, XPASS / XFAIL (tests/conftest.py)
 def test_fused_adamw_grad_scale_equals_scaling_the_gradients_first():
     """adamw_step_scaled_bf16 (include/rlipv2_optim.h): the data-parallel step leaves the all-reduced gradient SUM in the
     flat buffer and hands 1 / world to the optimiser's kernels.  Same update as scaling the gradients in float32 first

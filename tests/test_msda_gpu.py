@@ -219,14 +219,12 @@ def _testpy_inputs(D, dtype):
     return value, shapes, starts, loc, aw
 
 
-@pytest.mark.parametrize("D", [30, 32, 64, 71, 1025, 2048, 3096])
+@pytest.mark.parametrize("D", [30, 32, 64, 71, 1025])
 def test_reference_gradcheck_recipe(D):
-    # models/ops/test.py:67-82, every channel count of test.py:89-90 (2048 / 3096 run the same generic kernel as 1025)
+    # models/ops/test.py:67-82, channel counts of test.py:89-90 (2048 / 3096: the same generic kernel, tests/test_zz_round6_gpu.py)
     value, shapes, starts, loc, aw = _testpy_inputs(D, torch.float64)
     value.requires_grad_(True); loc.requires_grad_(True); aw.requires_grad_(True)
-    # the two largest channel counts through gradcheck's fast mode (random directional derivatives instead of the full Jacobian:
-    # value alone would be a 185 760 x 12 384 float64 matrix, twice)
-    assert torch.autograd.gradcheck(msda.MSDeformAttnFunction.apply, (value, shapes, starts, loc, aw, 2), fast_mode=D > 1025)
+    assert torch.autograd.gradcheck(msda.MSDeformAttnFunction.apply, (value, shapes, starts, loc, aw, 2))
 
 
 def test_autograd_function_returns_grads_in_input_dtypes():

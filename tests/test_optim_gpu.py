@@ -63,7 +63,7 @@ def test_fused_adamw_matches_torch(max_norm):
 
 
 @gpu
-@pytest.mark.first_contact(timeout=420, counts=True)
+@pytest.mark.first_contact(timeout=420)
 @pytest.mark.parametrize("grad_scale", [0.125, 0.5])
 def test_fused_adamw_with_the_gradient_scale_of_a_data_parallel_step(grad_scale):
     """opt.step(max_norm, grad_scale): what a data-parallel step calls with grad_scale = 1 / world on the all-reduced SUM

@@ -53,8 +53,8 @@ FAMILIES = [
          what="what every N > 1 run executes by default and no GPU has run: fused AdamW with grad_scale != 1 (fused_adamw.hip "
               "step_scaled_kernel), the auto gradient schedule with real captured steps on a 1-rank RCCL group",
          kernels=[r"fused_adamw\.hip::.*step_scaled_kernel"],
-         gpu=[(PYTEST + ["-m", "gpu", "tests/test_optim_gpu.py", "-k", "gradient_scale"], {}),
-              (PYTEST + ["-m", "gpu", "tests/test_zz_round6_gpu.py"], {})],
+         gpu=[(PYTEST + ["-m", "gpu", "tests/test_optim_gpu.py", "tests/test_linear_gpu.py", "-k", "gradient_scale or grad_scale"], {}),
+              (PYTEST + ["-m", "gpu", "tests/test_zz_round6_gpu.py", "-k", "auto_gradient_schedule"], {})],
          emu=[(PYTEST + ["tests/test_dense_emulated.py", "-k", "fused_adamw"], {}),
               (PYTEST + ["tests/test_dp_cpu.py", "-k", "auto_gradient_schedule"], {})], timeout=240),
     dict(name="decoder_sample_then_project", row="a5/a11", default_after_promotion=False,

@@ -101,7 +101,15 @@ GPU_SUITE_ORDER = ["test_msda_gpu", "test_norm_gpu", "test_linear_gpu", "test_op
                    "test_msda_cell_forward_gpu"]
 
 
+# Tests of the PRODUCT's default paths that no GPU has run yet (written in rounds 4-5) and that are allowed to fail the suite: at the
+# very end, so that under -x a first-run failure in one of them cannot hide any other evidence.
+NEVER_RUN_PRODUCT_TESTS = ("test_full_parseda_bf16_gradients_against_float32_on_rounded_weights",
+                           "test_step_cache_keeps_one_off_shapes_eager_and_evicts", "test_two_rank_bench_prints_one_line")
+
+
 def gpu_suite_rank(nodeid):
+    if any(t in nodeid for t in NEVER_RUN_PRODUCT_TESTS):
+        return len(GPU_SUITE_ORDER) + 1
     name = os.path.basename(nodeid.split("::")[0])[:-3]
     return GPU_SUITE_ORDER.index(name) if name in GPU_SUITE_ORDER else GPU_SUITE_ORDER.index("test_bench_contract") - 0.5
 

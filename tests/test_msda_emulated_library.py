@@ -311,6 +311,60 @@ def test_far_return_arm_hands_every_gradient_to_the_gated_k1(ablation_lib, monke
         assert np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
 
 
+def test_far_return_arm_on_the_fused_route(ablation_lib, monkeypatch):
+    """The same arm through msda_fused_backward_ws (the train step's route: geometry backward as the kernels' epilogue, the gradient of
+    the projection rows instead of grad_sampling_loc / grad_attn_weight).  Here the gate word travels to the gated K1 in the pointer
+    argument that instantiation does not use (g_loc); wide offsets put samples out of their cells' reach.  Bar: the projection rows'
+    gradient bit-equal to the route that runs K1 (with its epilogue) unconditionally."""
+    Lb = ablation_lib.L
+    M, L, P = 1, 4, 4
+    pyr, starts, S, ref2, value, grad_out, rng = _encoder_problem([(20, 54), (10, 27), (5, 14), (3, 7)], 1, M, seed=33)
+    N, Lq = 1, S
+    qproj = rng.standard_normal((N, Lq, M * L * P * 3))
+    qproj[..., :M * L * P * 2] *= 40.0                                               # offsets of tens of pixels: far samples
+    qproj = bf16_val(bf16_bits(qproj)).astype(np.float32)
+    ref = np.ascontiguousarray(np.broadcast_to(ref2[None, :, None, :], (N, Lq, L, 2)), dtype=np.float32)
+    vb, qb, gob = bf16_bits(value), bf16_bits(qproj), bf16_bits(grad_out)
+    dims = (N, S, M, 32, L, Lq, P)
+    p = lambda a: a.ctypes.data                                                       # noqa: E731
+    out = np.zeros((N, Lq, M * 32), dtype=np.uint16)
+    loc = np.full((N, Lq, M, L, P, 2), np.nan, dtype=np.float32)
+    aw = np.full((N, Lq, M, L, P), np.nan, dtype=np.float32)
+    assert Lb.msda_fused_forward(BF16, p(vb), p(pyr), p(starts), p(qb), p(ref), 2, *dims, p(out), p(loc), p(aw), None) == 0
+    ws_bytes = Lb.msda_backward_workspace_bytes(BF16, p(pyr), *dims)
+
+    def backward():
+        ws = np.zeros(ws_bytes + 64, dtype=np.uint8)
+        gv, gq = np.zeros(vb.shape, dtype=np.uint16), np.full(qb.shape, 0x7fc0, dtype=np.uint16)
+        assert Lb.msda_fused_backward_ws(FLAG_BF16_GV, BF16, p(vb), p(pyr), p(starts), p(pyr), p(loc), p(aw), p(ref), 2, p(gob),
+                                         *dims, p(gv), p(gq), p(ws), ws_bytes, None) == 0
+        return gv, gq
+    for k in ("RLIPV2_MSDA_CELL", "RLIPV2_CELL_FAR_RETURN", "RLIPV2_DEST_QUEUE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("RLIPV2_MSDA_CELL", "0")
+    gv_k1, gq_k1 = backward()
+    monkeypatch.delenv("RLIPV2_MSDA_CELL")
+    gv_cell, gq_cell = backward()                                                    # the product route: cell kernel's values stand
+    monkeypatch.setenv("RLIPV2_CELL_FAR_RETURN", "1")
+    monkeypatch.setenv("RLIPV2_DEST_QUEUE", "1")
+    gv_arm, gq_arm = backward()
+    assert np.isfinite(bf16_val(gq_arm)).all()
+    assert np.array_equal(gq_arm, gq_k1)                                             # every row rewritten by the gated K1
+    assert np.array_equal(gq_cell, gq_k1) or np.abs(bf16_val(gq_cell) - bf16_val(gq_k1)).max() <= 2.0 ** -7 * np.abs(bf16_val(gq_k1)).max()
+    # grad_value comes from the sorting pass either way: equal to a rounding on the model
+    assert np.abs(bf16_val(gv_arm) - bf16_val(gv_k1)).max() <= 2.0 ** -7 * np.abs(bf16_val(gv_k1)).max()
+    # ... and the samples WERE out of reach (so the gated K1 did run): the record-emitting forward raises the same flag on them
+    vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    Lb.msda_records_bytes.argtypes = [i, vp, *[i] * 7]
+    Lb.msda_records_bytes.restype = sz
+    Lb.msda_records_forward.argtypes = [i, vp, vp, vp, vp, vp, vp, i, vp, vp, *[i] * 7, vp, vp, sz, vp]
+    rec_bytes = Lb.msda_records_bytes(BF16, p(pyr), *dims)
+    records = np.zeros(rec_bytes, dtype=np.uint8)
+    assert Lb.msda_records_forward(BF16, p(vb), p(pyr), p(starts), p(pyr), None, None, 0, p(loc), p(aw), *dims, p(out), p(records),
+                                   rec_bytes, None) == 0
+    assert int(records[:256].view(np.int32)[60]) != 0
+
+
 def test_plain_b0_signature_without_host_shapes(lib):
     """msda_forward / msda_backward exactly as the reference's extension is bound (no host copy of the shapes,
     no workspace): "auto" then takes the direct-gather forward and K1 + the sorted scatter of round 1 (msda_window.hip: LDS

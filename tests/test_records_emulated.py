@@ -139,6 +139,7 @@ def test_records_route_with_the_cell_major_grad_out_copy_fused_in(ablation_lib, 
     tests/test_backward_emulated.py)."""
     monkeypatch.setenv("RLIPV2_PATCH_CELLG", "1")
     test_op_signature_bit_equal_to_the_product_route(ablation_lib, *CASES[0])
+    test_module_operands_bit_equal_to_the_fused_product_route(ablation_lib, 2)      # (the REFDIM 2 instantiations: the train step's call)
     monkeypatch.delenv("RLIPV2_PATCH_CELLG")
     # ... and the arm really ran: with the switch off the same library takes the product patch kernel; the results agree bit for bit
     # across the two (checked inside each call against the product route of ITS setting), so compare the two settings directly

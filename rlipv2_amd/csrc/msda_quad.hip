@@ -1120,16 +1120,11 @@ void launch_quad_backward_gated(const Problem &p, const Fused *f, const int *gat
     hipLaunchKernelGGL((quad_backward_shared_kernel<VT, 4, (RD) | 8>), dim3(grid), dim3(kBlock), 0, p.stream,          \
                        (const VT *)p.value, p.shapes, p.starts, (const float *)p.loc, (const float *)p.aw,            \
                        (const VT *)p.grad_out, total_qm, p.S, p.M, p.Lq, value_bytes(p), GLOC, GAW, REF, GQ)
-    if (!f) {
-        if (p.dtype == MSDA_F32) MSDA_K1_GATED(float, 0, (float *)p.g_loc, (float *)p.g_aw, (const float *)gate_f, (float *)nullptr);
-        else MSDA_K1_GATED(bf16_t, 0, (float *)p.g_loc, (float *)p.g_aw, (const float *)gate_f, (bf16_t *)nullptr);
-    } else if (p.dtype == MSDA_F32) {
-        if (f->refdim == 2) MSDA_K1_GATED(float, 2, gate_f, (float *)nullptr, f->ref, (float *)f->g_qproj);
-        else MSDA_K1_GATED(float, 4, gate_f, (float *)nullptr, f->ref, (float *)f->g_qproj);
-    } else {
-        if (f->refdim == 2) MSDA_K1_GATED(bf16_t, 2, gate_f, (float *)nullptr, f->ref, (bf16_t *)f->g_qproj);
-        else MSDA_K1_GATED(bf16_t, 4, gate_f, (float *)nullptr, f->ref, (bf16_t *)f->g_qproj);
-    }
+    // (only ever launched behind cell_backward_kernel: bfloat16 calls)
+    if (p.dtype != MSDA_BF16) return;
+    if (!f) MSDA_K1_GATED(bf16_t, 0, (float *)p.g_loc, (float *)p.g_aw, (const float *)gate_f, (bf16_t *)nullptr);
+    else if (f->refdim == 2) MSDA_K1_GATED(bf16_t, 2, gate_f, (float *)nullptr, f->ref, (bf16_t *)f->g_qproj);
+    else MSDA_K1_GATED(bf16_t, 4, gate_f, (float *)nullptr, f->ref, (bf16_t *)f->g_qproj);
 #undef MSDA_K1_GATED
 }
 #endif

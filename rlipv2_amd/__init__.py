@@ -2,8 +2,10 @@
 
 Only what the path needs lives here: ``csrc/`` (hand-written HIP kernels for gfx950 behind the
 C ABI of ``include/rlipv2_msda.h``) and the host-side mirror of the reference's operator /
-module interface.  There is no CPU fallback: every op raises if the HIP library is missing or
-a tensor is not on the GPU.
+module interface.  There is no fallback for GPU tensors: every op on them raises if the HIP
+library is missing.  CPU tensors are a different device, served by the op's CPU twins
+(``include/rlipv2_msda_cpu.h``, the reference's own device dispatch) -- never a substitute for
+the GPU path.
 """
 import os as _os
 

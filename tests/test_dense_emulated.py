@@ -2,7 +2,7 @@
 backward (csrc/add_layernorm.hip), the backbone's add + ReLU / affine + ReLU tails (csrc/elementwise.hip) -- built for the
 CPU against the lane-level workgroup model (tools/emu/build_dense_lib.sh: the same sources hipcc compiles) and checked against
 float32 PyTorch, the checker of their GPU tests (tests/test_optim_gpu.py, test_norm_gpu.py, test_linear_gpu.py).  Kernel logic
-without a GPU; test infrastructure only -- the product has no CPU path."""
+without a GPU; test infrastructure only -- the product never loads these libraries (its own CPU path is the op's CPU twins, csrc/msda_cpu.cpp)."""
 import ctypes
 import math
 import os

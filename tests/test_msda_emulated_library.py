@@ -5,7 +5,7 @@ for bfloat16 encoder calls cell_backward_kernel + patch_dest_kernel), the fused 
 
 A CPU mirror of the golden tests of tests/test_msda_gpu.py.  It exists because the GPU pool can be closed (second half of
 round 3): kernel LOGIC stays checkable.  It is test infrastructure -- nothing in rlipv2_amd/ can load this library, the
-product has no CPU path -- and it says nothing about code generation, timing or the hardware itself."""
+product never loads this library (CPU tensors run the op's CPU twins, csrc/msda_cpu.cpp) -- and it says nothing about code generation, timing or the hardware itself."""
 import ctypes
 import os
 import subprocess

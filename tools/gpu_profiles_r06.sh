@@ -3,6 +3,7 @@
 # kernel-trace stats of the bench command, HBM-traffic
 # counter passes (separate --pmc runs, --kernel-trace only) of the MSDA kernels the train step runs (fused route) and of the
 # B0-signature kernels, the bench line itself.  The program goes directly after `--` (no env / bash -c hop).
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"      # (gpurun exports it; a local run falls back to the tree the script is in)
 TAG=${1:-r06/final}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT

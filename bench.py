@@ -726,7 +726,8 @@ def routes_child_main(args):
     step_module = train.ParSeDATrainStep(model)
     model.train()
     dtype = torch.bfloat16 if (args.dtype == "bf16" and not master) else None
-    train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
+    if device != "cpu":                              # (the dry run of the freeze is a whole forward + backward: nothing for it to decide on the CPU)
+        train.freeze_parameters_without_gradient(step_module, criterion, batch, autocast_dtype=dtype)
     verdict = routes.validate(step_module, criterion, batch, autocast_dtype=dtype, names=applicable_routes(args.backbone),
                               log=lambda m: print(m, file=sys.stderr))
     if device != "cpu":

@@ -168,3 +168,24 @@ def kink_samples(g, tol=1e-4):
         y = loc[:, :, :, l, :, 1] * H - 0.5
         mask[:, :, :, l, :] = (np.abs(x - np.round(x)) < tol) | (np.abs(y - np.round(y)) < tol)
     return mask
+
+
+_emu_libraries = {}
+
+
+@pytest.fixture(scope="session")
+def emu_library(tmp_path_factory):
+    """builder of the MSDA library on the lane-level model (tools/emu/build_lib.sh), one build per set of defines and SESSION: the
+    emulated test files share it (EMU_SANITIZE / EMU_TSAN in the environment are part of the key)"""
+    import subprocess
+
+    def build(defines=""):
+        key = (defines, os.environ.get("EMU_SANITIZE", ""), os.environ.get("EMU_TSAN", ""))
+        if key not in _emu_libraries:
+            so = str(tmp_path_factory.mktemp("emu_lib") / "libmsda_emu.so")
+            subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900,
+                           env=dict(os.environ, EMU_DEFINES=defines))
+            _emu_libraries[key] = so
+        return _emu_libraries[key]
+    return build
+

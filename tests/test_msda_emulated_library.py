@@ -92,10 +92,8 @@ FULL = os.environ.get("RLIPV2_TEST_EMU_FULL", "0") == "1"     # the whole matrix
 
 
 @pytest.fixture(scope="module")
-def lib(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("emu_lib") / "libmsda_emu.so")
-    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900)
-    return EmuLib(so)
+def lib(emu_library):
+    return EmuLib(emu_library())
 
 
 def close32(got, ref, rtol=1e-4, atol_rel=1e-5):
@@ -253,11 +251,8 @@ def test_samples_out_of_reach_take_the_sorting_pass_within_the_same_call(lib):
 
 
 @pytest.fixture(scope="module")
-def ablation_lib(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("emu_lib_ablation") / "libmsda_emu_ablation.so")
-    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900,
-                   env=dict(os.environ, EMU_DEFINES="-DMSDA_ABLATION"))
-    return EmuLib(so)
+def ablation_lib(emu_library):
+    return EmuLib(emu_library("-DMSDA_ABLATION"))
 
 
 def test_far_return_arm_hands_every_gradient_to_the_gated_k1(ablation_lib, monkeypatch):

@@ -27,21 +27,14 @@ BF16, FLAG_BF16_GV, FLAG_SWAP, CELL = 2, 0x200, 0x400, 6
 FULL = os.environ.get("RLIPV2_TEST_EMU_FULL", "0") == "1"     # the default suite runs one problem per code path (~2.5 min)
 
 
-def _build(tmp_path_factory, name, defines=""):
-    so = str(tmp_path_factory.mktemp(name) / "libmsda_emu.so")
-    subprocess.run([os.path.join(ROOT, "tools", "emu", "build_lib.sh"), so], check=True, capture_output=True, timeout=900,
-                   env=dict(os.environ, EMU_DEFINES=defines))
-    return _bind(ctypes.CDLL(so))
+@pytest.fixture(scope="module")
+def lib(emu_library):
+    return _bind(ctypes.CDLL(emu_library()))
 
 
 @pytest.fixture(scope="module")
-def lib(tmp_path_factory):
-    return _build(tmp_path_factory, "emu_records")
-
-
-@pytest.fixture(scope="module")
-def ablation_lib(tmp_path_factory):
-    return _build(tmp_path_factory, "emu_records_ablation", "-DMSDA_ABLATION")
+def ablation_lib(emu_library):
+    return _bind(ctypes.CDLL(emu_library("-DMSDA_ABLATION")))
 
 
 def _bind(L):

@@ -1,8 +1,11 @@
 #!/bin/bash
 # THE script of a GPU session (round 6; replaces gpu_first_r05.sh, gpu_quick_r05.sh, gpu_reopen_r05.sh).  Order = value of the
 # evidence per GPU minute; every step under its own timeout, nothing after a step depends on it having succeeded.
-#   gpurun --timeout 3300 -- 'bash tools/gpu_triage_r06.sh'            # everything below (~45 min)
+#   gpurun --timeout 3300 -- 'bash tools/gpu_triage_r06.sh'            # everything below (~45-55 min: tight for one call, or split:)
 #   gpurun --timeout 900  -- 'bash tools/gpu_triage_r06.sh quick'      # steps 1-3 only (~10 min): parity, smoke, the bench line
+#   gpurun --timeout 1500 -- 'bash tools/gpu_triage_r06.sh suite'      # step 4 only (~15-20 min)
+#   gpurun --timeout 1800 -- 'bash tools/gpu_triage_r06.sh triage'     # step 5 only (<= 20 min + process starts)
+#   gpurun --timeout 1800 -- 'bash tools/gpu_triage_r06.sh profiles'   # step 6 only (~15-25 min)
 #   gpurun --timeout 3300 -- 'bash tools/gpu_triage_r06.sh extras'     # the A/B bench lines and host A/Bs of a second session
 # 1. op-level parity of the hot path against the oracle / goldens (tests/test_msda_gpu.py)                -> pytest_msda.txt
 # 2. smoke()                                                                                             -> smoke.txt
@@ -28,12 +31,20 @@ if [ "$MODE" = "extras" ]; then
   ( timeout 1000 python tools/experiments_r05.py --all > $OUT/experiments.json 2> $OUT/experiments_table.txt ); python tools/promote_r05.py $OUT/experiments.json > $OUT/promote.txt 2>&1; cat $OUT/promote.txt
   exit 0
 fi
+want() { [ "$MODE" = "all" ] || [ "$MODE" = "$1" ] || { [ "$MODE" = "quick" ] && [ "$1" = "first" ]; }; }
+if want first; then
 ( timeout 300 python -m pytest tests/test_msda_gpu.py -m gpu -q > $OUT/pytest_msda.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_msda.txt ); tail -4 $OUT/pytest_msda.txt
 ( timeout 240 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/smoke.txt ); tail -3 $OUT/smoke.txt
 timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 tail -c 3000 $OUT/bench_line.json; tail -5 $OUT/bench_stderr.txt
-[ "$MODE" = "quick" ] && exit 0
-( timeout 1200 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt ); tail -30 $OUT/pytest_gpu.txt
+fi
+if want suite; then
+( timeout 1200 python -m pytest tests -m gpu -q -rxX --durations=15 > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt ); tail -45 $OUT/pytest_gpu.txt
+fi
+if want triage; then
 timeout 1500 python tools/gpu_triage_r06.py --out $OUT | tee $OUT/triage_lines.txt
 cat $OUT/triage.txt
+fi
+if want profiles; then
 bash tools/gpu_profiles_r06.sh r06/final
+fi
